@@ -1,0 +1,187 @@
+/*
+ * rnnwf.h - C ABI of librnnwf_hip.so: the MI355X-native VMC inner loop of RNN wave functions.
+ *
+ * The reference (MatteoMartinelli97/RNNWavefunctions) has no FFI: its boundary for this path is
+ * the Python API of its RNNwavefunction classes and local-energy estimators, executed by
+ * TensorFlow 1.13 through tf.Session.run.  Each entry point below names the reference interface
+ * it stands in for (paths relative to the reference root).  The Python host code under
+ * rnnwavefunctions_amd/ binds these symbols with ctypes and re-creates the reference's
+ * signatures on top (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - plain C types only; all pointers are HOST pointers owned by the caller unless a name
+ *     ends in _dev; the library owns all device memory inside the opaque handle;
+ *   - every function returns 0 on success and a negative rnnwf_status otherwise; the message
+ *     is available from rnnwf_last_error(); nothing aborts the process;
+ *   - a handle is bound to one HIP device and one HIP stream; it is not thread-safe; calls are
+ *     synchronous with respect to the host unless stated otherwise;
+ *   - spin configurations are int32 arrays of 0/1, row-major (numsamples, N) for the 1D models
+ *     and (numsamples, Nx, Ny) for the 2D MDRNN model, exactly as the reference feeds its
+ *     placeholders (1DTFIM/TrainingRNN_1DTFIM.py:192).
+ */
+#ifndef RNNWF_H
+#define RNNWF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RNNWF_ABI_VERSION 1
+
+typedef struct rnnwf_handle rnnwf_handle;
+
+typedef enum {
+    RNNWF_OK = 0,
+    RNNWF_ERR_INVALID = -1,     /* bad argument / unsupported configuration            */
+    RNNWF_ERR_HIP = -2,         /* a HIP runtime call failed                           */
+    RNNWF_ERR_STATE = -3,       /* call order violated (e.g. parameters not committed) */
+    RNNWF_ERR_COMM = -4,        /* RCCL failure                                        */
+    RNNWF_ERR_NOMEM = -5
+} rnnwf_status;
+
+/* Which reference wave function the handle implements. */
+typedef enum {
+    RNNWF_MODEL_GRU1D = 0,       /* 1DTFIM/RNNwavefunction.py:7-118          pRNN, f32 cell, f64 log-sum   */
+    RNNWF_MODEL_GRU1D_PARITY = 1,/* 1DTFIM/RNNwavefunction_paritysym.py:7-145 same sampler, symmetrised P   */
+    RNNWF_MODEL_CRNN_U1 = 2,     /* J1J2/ComplexRNNwavefunction.py:15-169    cRNN, f32/complex64, U(1) mask */
+    RNNWF_MODEL_GRU1D_F64 = 3,   /* 2DTFIM_1DRNN/RNNwavefunction.py:8-130    pRNN over a raster path, f64   */
+    RNNWF_MODEL_MDRNN2D = 4      /* 2DTFIM_2DRNN/RNNwavefunction.py:5-200 + MDRNNcell.py:6-66, f64          */
+} rnnwf_model;
+
+typedef enum { RNNWF_F32 = 0, RNNWF_F64 = 1 } rnnwf_dtype;
+
+#define RNNWF_MAX_LAYERS 4
+
+typedef struct {
+    int32_t abi_version;              /* RNNWF_ABI_VERSION                                        */
+    int32_t model;                    /* rnnwf_model                                              */
+    int32_t nx;                       /* systemsize (1D) or systemsize_x (2D)                     */
+    int32_t ny;                       /* 1 for 1D models, systemsize_y for 2D                     */
+    int32_t num_layers;               /* len(units) of the reference ctor                         */
+    int32_t units[RNNWF_MAX_LAYERS];  /* units[n]                                                 */
+    int32_t device;                   /* HIP device ordinal                                       */
+    int32_t reserved[6];
+} rnnwf_config;
+
+/* ---- life cycle ------------------------------------------------------------------------------
+ * rnnwf_create      <- RNNwavefunction.__init__ (1DTFIM/RNNwavefunction.py:8-33,
+ *                      J1J2/ComplexRNNwavefunction.py:16-43, 2DTFIM_2DRNN/RNNwavefunction.py:6-33)
+ *                      plus the tf.Session it would be run in (1DTFIM/TrainingRNN_1DTFIM.py:119-123). */
+int rnnwf_create(const rnnwf_config* cfg, rnnwf_handle** out);
+int rnnwf_destroy(rnnwf_handle* h);
+/* Message of the last failure on this handle (h == NULL: of the last failed rnnwf_create). */
+const char* rnnwf_last_error(const rnnwf_handle* h);
+/* "hip-gfx950" */
+const char* rnnwf_backend_name(void);
+int rnnwf_abi_version(void);
+
+/* ---- parameters ------------------------------------------------------------------------------
+ * Stand in for the TF variables of the reference graph and for tf.train.Saver restore
+ * (1DTFIM/TrainingRNN_1DTFIM.py:166,172-183).  `tf_name` is the TF variable name WITHOUT the scope
+ * prefix, e.g. "multi_rnn_cell/cell_0/cudnn_compatible_gru_cell/gates/kernel", "wf_dense/bias",
+ * "Wh_rnn_0".  `count` is the element count and must match the variable's shape; `dtype` is the
+ * type of the caller's buffer (converted to the model's arithmetic type).
+ * rnnwf_commit_params re-packs all parameters into the MFMA-fragment image the kernels stage in
+ * LDS and uploads it; it must be called after the last rnnwf_set_param and before any compute. */
+int rnnwf_set_param(rnnwf_handle* h, const char* tf_name, const void* data, int64_t count, int32_t dtype);
+int rnnwf_get_param(rnnwf_handle* h, const char* tf_name, void* data, int64_t count, int32_t dtype);
+int rnnwf_commit_params(rnnwf_handle* h);
+/* Number of scalar parameters (the count the reference prints, TrainingRNN_1DTFIM.py:127-136). */
+int64_t rnnwf_num_params(const rnnwf_handle* h);
+
+/* ---- wave function ---------------------------------------------------------------------------
+ * rnnwf_sample   <- sess.run(wf.sample(numsamples, 2))   (1DTFIM/RNNwavefunction.py:35-74,
+ *                   J1J2/ComplexRNNwavefunction.py:45-103, 2DTFIM_2DRNN/RNNwavefunction.py:35-118).
+ *   Draws `numsamples` configurations.  The uniform of (global sample g = sample_offset + row,
+ *   site n) is Philox4x32-10(key = seed, counter = (g, n/4, step))[n%4] >> 8, so shards of one
+ *   batch drawn with different sample_offset on different devices are disjoint pieces of the
+ *   same stream.  out_samples: (numsamples, N) int32; out_log (optional, may be NULL): the
+ *   log-probability (f64) of each drawn configuration (2*Re log psi for the cRNN).            */
+int rnnwf_sample(rnnwf_handle* h, int64_t numsamples, uint64_t seed, uint64_t step, int64_t sample_offset,
+                 int32_t* out_samples, double* out_log);
+
+/* rnnwf_log_prob <- sess.run(wf.log_probability(ph, 2), {ph: samples})
+ *                   (1DTFIM/RNNwavefunction.py:76-118, RNNwavefunction_paritysym.py:80-145,
+ *                    2DTFIM_1DRNN/RNNwavefunction.py:84-130, 2DTFIM_2DRNN/RNNwavefunction.py:120-200)
+ *   out: (B,) f64.  For RNNWF_MODEL_CRNN_U1 it returns 2*Re log psi.                          */
+int rnnwf_log_prob(rnnwf_handle* h, const int32_t* samples, int64_t B, double* out);
+
+/* rnnwf_log_amp  <- sess.run(wf.log_amplitude(ph, 2), {ph: samples})
+ *                   (J1J2/ComplexRNNwavefunction.py:105-169).  out_re_im: (B, 2) f32 = complex64. */
+int rnnwf_log_amp(rnnwf_handle* h, const int32_t* samples, int64_t B, float* out_re_im);
+
+/* ---- local-energy estimators -----------------------------------------------------------------
+ * rnnwf_tfim_eloc <- Ising_local_energies(Jz, Bx, samples, queue_samples, log_probs_tensor,
+ *                    samples_placeholder, log_probs, sess)   (1DTFIM/TrainingRNN_1DTFIM.py:13-75)
+ *   Fused formulation: one teacher-forced pass that checkpoints the hidden state after every
+ *   site, then every single-spin-flip configuration is scored from its flipped site onwards only;
+ *   `queue_samples` is never materialised.  Jz: (N,) f64 (Jz[N-1] unused, as in the reference).
+ *   eloc: (numsamples,) f64.  log_probs (optional): ((N+1)*numsamples,) f64, row 0 = log P(s),
+ *   row i+1 = log P(s with spin i flipped) - the reference's `log_probs` scratch (:65,:70).   */
+int rnnwf_tfim_eloc(rnnwf_handle* h, const int32_t* samples, int64_t numsamples, const double* Jz, double Bx,
+                    double* eloc, double* log_probs);
+
+/* rnnwf_tfim2d_eloc <- Ising2D_local_energies(Jz, Bx, Nx, Ny, samples, ...)
+ *   (2DTFIM_2DRNN/Training2DRNN_2DTFIM.py:13-83 for RNNWF_MODEL_MDRNN2D, samples (ns, Nx, Ny);
+ *    2DTFIM_1DRNN/Training1DRNN_2DTFIM.py:13-81 for RNNWF_MODEL_GRU1D_F64, samples (ns, Nx*Ny)).
+ *   Jz: (Nx, Ny) f64 row-major.                                                                */
+int rnnwf_tfim2d_eloc(rnnwf_handle* h, const int32_t* samples, int64_t numsamples, const double* Jz, double Bx,
+                      double* eloc, double* log_probs);
+
+/* rnnwf_j1j2_eloc <- J1J2Slices + chunked log_amplitude + E_loc loop
+ *   (J1J2/TrainingRNN_J1J2.py:95-127, :255-279), with J1J2MatrixElements' `periodic` and
+ *   `Marshall_sign` flags (:12) implemented as documented (the reference's J1J2Slices passes
+ *   Marshall_sign into the `periodic` slot, :118; the Python facade reproduces that quirk).
+ *   J1, J2, Bz: (N,) f64.  eloc_re_im: (numsamples, 2) f32.  n_connected (optional): total
+ *   number of configurations scored (diagonal + off-diagonal), the reference's `len_sigmas`.  */
+int rnnwf_j1j2_eloc(rnnwf_handle* h, const int32_t* samples, int64_t numsamples, const double* J1,
+                    const double* J2, const double* Bz, int32_t periodic, int32_t marshall,
+                    float* eloc_re_im, int64_t* n_connected);
+
+/* ---- fused VMC step (sample + local energy + moments, nothing leaves HBM but the moments) -----
+ * rnnwf_vmc_step <- one iteration of the loop at 1DTFIM/TrainingRNN_1DTFIM.py:199-207 /
+ *   J1J2/TrainingRNN_J1J2.py:241-282 / the Training scripts of the two 2DTFIM folders, without the optimizer:
+ *   samples = sess.run(samples_); local_energies = <estimator>(...); meanE; varE.
+ *   `couplings` is model specific: TFIM1D: Jz (N) then Bx (1)              -> N+1 doubles
+ *                                  TFIM2D: Jz (Nx*Ny) then Bx (1)          -> Nx*Ny+1 doubles
+ *                                  J1J2  : J1 (N), J2 (N), Bz (N), periodic, marshall -> 3N+2 doubles
+ *   moments[4] (out) = { sum Re E, sum (Re E)^2, n, sum Im E } over THIS handle's samples
+ *   (combine across devices with rnnwf_allreduce_moments).  out_samples / out_eloc may be NULL
+ *   (out_eloc is (numsamples,) f64 for TFIM, (numsamples,2) f32 for J1J2).                     */
+int rnnwf_vmc_step(rnnwf_handle* h, int64_t numsamples, uint64_t seed, uint64_t step, int64_t sample_offset,
+                   const double* couplings, int64_t n_couplings, int32_t* out_samples, void* out_eloc,
+                   double* moments);
+
+/* ---- multi-GPU: one RCCL all-reduce of the energy moments -------------------------------------
+ * The reference is single-process; these add the one data-parallel collective of SURVEY.md 8e.
+ * One process per GPU: rank 0 calls rnnwf_comm_unique_id and ships the 128 bytes to the other
+ * ranks by any means (the Python host uses the launcher's store); every rank then calls
+ * rnnwf_comm_init.  rnnwf_allreduce_moments sums `count` doubles in place over all ranks
+ * (ncclAllReduce, ncclDouble, ncclSum on the handle's stream) - population mean/variance follow
+ * as S1/n and S2/n - (S1/n)^2 (np.mean / np.var, TrainingRNN_1DTFIM.py:206-207).              */
+#define RNNWF_UNIQUE_ID_BYTES 128
+int rnnwf_comm_unique_id(void* id_out);
+int rnnwf_comm_init(rnnwf_handle* h, const void* id, int32_t rank, int32_t nranks);
+int rnnwf_allreduce_moments(rnnwf_handle* h, double* moments, int32_t count);
+int rnnwf_comm_destroy(rnnwf_handle* h);
+
+/* ---- measurement ------------------------------------------------------------------------------
+ * HIP-event timing of the kernels on the handle's stream (bench.py's roofline leg).
+ * kernel ids: 0 = base pass (sample / teacher-forced + checkpoints), 1 = flip pass (dominant),
+ *             2 = local-energy assembly + moments.  total_ms / launches accumulate since the
+ *             last rnnwf_timing_reset.  work[0] = cell evaluations, work[1] = MFMA flops issued
+ *             (padding included) by the flip pass since the last reset.                         */
+int rnnwf_timing_enable(rnnwf_handle* h, int32_t on);
+int rnnwf_timing_reset(rnnwf_handle* h);
+int rnnwf_timing_get(rnnwf_handle* h, int32_t kernel_id, double* total_ms, int64_t* launches, double* work);
+/* hipDeviceSynchronize on the handle's device (bench.py brackets its timed region with it). */
+int rnnwf_synchronize(rnnwf_handle* h);
+/* Device properties for reports: cu_count, clock_mhz, hbm_bytes. */
+int rnnwf_device_info(rnnwf_handle* h, int32_t* cu_count, int32_t* clock_mhz, int64_t* hbm_bytes, char* name64);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RNNWF_H */

@@ -1,0 +1,59 @@
+"""Build librnnwf_hip.so (hipcc, gfx950) in-tree: ``python -m rnnwavefunctions_amd.build``.
+
+The shared library is the whole product below the Python facade; it links only against the
+HIP runtime (RCCL is dlopen'ed at communicator creation).  hipcc cross-compiles without a GPU.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
+LIB = os.path.join(LIBDIR, "librnnwf_hip.so")
+SOURCES = ["rnnwf_api.hip", "prnn.hip", "crnn.hip", "mdrnn.hip", "comm.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
+         "-ffp-contract=fast"]
+
+
+def _newest_header():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(os.path.dirname(HERE), "include", "rnnwf.h"))
+    return max(os.path.getmtime(h) for h in hs)
+
+
+def _compile(src, extra):
+    obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+    path = os.path.join(CSRC, src)
+    if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), _newest_header()) and not extra:
+        return obj, ""
+    cmd = [HIPCC] + FLAGS + extra + ["-c", path, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, " ".join(cmd), r.stderr[-6000:]))
+    return obj, r.stderr
+
+
+def build(verbose=False, extra_flags=(), jobs=None):
+    os.makedirs(OBJDIR, exist_ok=True)
+    extra = list(extra_flags)
+    with ThreadPoolExecutor(max_workers=jobs or min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        results = list(ex.map(lambda s: _compile(s, extra), SOURCES))
+    objs = [o for o, _ in results]
+    if verbose:
+        for _, log in results:
+            if log.strip():
+                print(log, file=sys.stderr)
+    if (not os.path.exists(LIB)) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (" ".join(cmd), r.stderr[-4000:]))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(verbose="-v" in sys.argv))

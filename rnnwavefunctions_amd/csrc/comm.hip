@@ -1,0 +1,96 @@
+// comm.hip - the one collective of the path: an RCCL all-reduce of the energy moments.
+// librccl.so is loaded lazily with dlopen so that single-GPU use never pays for it.
+#include <dlfcn.h>
+
+#include <cstring>
+
+#include "models.h"
+
+namespace {
+typedef struct { char internal[128]; } ncclUniqueId_;
+typedef int (*GetUniqueId_t)(ncclUniqueId_*);
+typedef int (*CommInitRank_t)(void**, int, ncclUniqueId_, int);
+typedef int (*AllReduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*CommDestroy_t)(void*);
+typedef const char* (*GetErrorString_t)(int);
+
+struct Rccl {
+    void* lib = nullptr;
+    GetUniqueId_t get_unique_id = nullptr;
+    CommInitRank_t comm_init_rank = nullptr;
+    AllReduce_t all_reduce = nullptr;
+    CommDestroy_t comm_destroy = nullptr;
+    GetErrorString_t error_string = nullptr;
+    std::string err;
+    bool load() {
+        if (lib) return true;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!lib) { err = std::string("dlopen(librccl.so) failed: ") + dlerror(); return false; }
+        get_unique_id = (GetUniqueId_t)dlsym(lib, "ncclGetUniqueId");
+        comm_init_rank = (CommInitRank_t)dlsym(lib, "ncclCommInitRank");
+        all_reduce = (AllReduce_t)dlsym(lib, "ncclAllReduce");
+        comm_destroy = (CommDestroy_t)dlsym(lib, "ncclCommDestroy");
+        error_string = (GetErrorString_t)dlsym(lib, "ncclGetErrorString");
+        if (!get_unique_id || !comm_init_rank || !all_reduce || !comm_destroy) { err = "librccl.so lacks the nccl* symbols"; return false; }
+        return true;
+    }
+} g_rccl;
+
+constexpr int kNcclFloat64 = 8;  // ncclDouble
+constexpr int kNcclSum = 0;
+static_assert(sizeof(ncclUniqueId_) == RNNWF_UNIQUE_ID_BYTES, "unique id size");
+}  // namespace
+
+extern "C" int rnnwf_comm_unique_id(void* id_out) {
+    if (!id_out || !g_rccl.load()) return RNNWF_ERR_COMM;
+    ncclUniqueId_ id;
+    if (g_rccl.get_unique_id(&id) != 0) return RNNWF_ERR_COMM;
+    memcpy(id_out, &id, sizeof id);
+    return RNNWF_OK;
+}
+
+extern "C" int rnnwf_comm_init(rnnwf_handle* h, const void* id, int32_t rank, int32_t nranks) {
+    if (!h || !id) return RNNWF_ERR_INVALID;
+    if (rank < 0 || rank >= nranks) return h->fail(RNNWF_ERR_INVALID, "rnnwf_comm_init: rank %d outside [0,%d)", rank, nranks);
+    if (!g_rccl.load()) return h->fail(RNNWF_ERR_COMM, "%s", g_rccl.err.c_str());
+    if (h->comm) rnnwf_comm_destroy(h);
+    RNNWF_HIP(h, hipSetDevice(h->cfg.device));
+    ncclUniqueId_ uid;
+    memcpy(&uid, id, sizeof uid);
+    const int rc = g_rccl.comm_init_rank(&h->comm, nranks, uid, rank);
+    if (rc != 0) {
+        h->comm = nullptr;
+        return h->fail(RNNWF_ERR_COMM, "ncclCommInitRank failed: %s", g_rccl.error_string ? g_rccl.error_string(rc) : "?");
+    }
+    h->rank = rank;
+    h->nranks = nranks;
+    return RNNWF_OK;
+}
+
+extern "C" int rnnwf_allreduce_moments(rnnwf_handle* h, double* moments, int32_t count) {
+    if (!h || !moments || count < 1 || count > 64) return RNNWF_ERR_INVALID;
+    if (!h->comm) {
+        if (h->nranks == 1) return RNNWF_OK;  // single device: the local moments are the global ones
+        return h->fail(RNNWF_ERR_STATE, "rnnwf_allreduce_moments: communicator not initialised");
+    }
+    RNNWF_HIP(h, hipSetDevice(h->cfg.device));
+    if (int rc = rnnwf::ensure(h, h->moments, 64 * sizeof(double))) return rc;
+    memcpy(h->pinned, moments, (size_t)count * sizeof(double));
+    RNNWF_HIP(h, hipMemcpyAsync(h->moments.p, h->pinned, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    const int rc = g_rccl.all_reduce(h->moments.p, h->moments.p, (size_t)count, kNcclFloat64, kNcclSum, h->comm, h->stream);
+    if (rc != 0) return h->fail(RNNWF_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.error_string ? g_rccl.error_string(rc) : "?");
+    RNNWF_HIP(h, hipMemcpyAsync(h->pinned, h->moments.p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+    memcpy(moments, h->pinned, (size_t)count * sizeof(double));
+    return RNNWF_OK;
+}
+
+extern "C" int rnnwf_comm_destroy(rnnwf_handle* h) {
+    if (!h) return RNNWF_ERR_INVALID;
+    if (h->comm && g_rccl.comm_destroy) g_rccl.comm_destroy(h->comm);
+    h->comm = nullptr;
+    h->nranks = 1;
+    h->rank = 0;
+    return RNNWF_OK;
+}

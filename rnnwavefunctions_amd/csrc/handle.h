@@ -1,0 +1,121 @@
+// handle.h - the opaque handle behind include/rnnwf.h (host side).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/rnnwf.h"
+
+namespace rnnwf {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct KernelTimer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    double total_ms = 0.0;
+    int64_t launches = 0;
+};
+
+struct ParamSpec {
+    std::vector<int64_t> shape;
+    std::vector<double> value;  // stored in f64, converted to the model type when packed
+    bool set = false;
+};
+
+}  // namespace rnnwf
+
+struct rnnwf_handle {
+    rnnwf_config cfg{};
+    int model = 0;
+    bool f64 = false;
+    int H = 0;       // num_units
+    int NFULL = 0;   // padded hidden size = 16 NFULL + 4
+    int N = 0;       // chain length (nx * ny)
+    int Nx = 1, Ny = 1;
+    int cu_count = 0;
+    std::string err;
+    hipStream_t stream = nullptr;
+    std::map<std::string, rnnwf::ParamSpec> params;
+    bool committed = false;
+
+    // device buffers (grown on demand, owned by the handle)
+    rnnwf::DevBuf wimg, samples_i32, bits, bits2, hck, lpq, lpq2, out_lp, out_lp2, eloc, moments, coupl, maps;
+    // J1J2 / cRNN
+    rnnwf::DevBuf camp, tiles, tile_count, cbase, cout;
+    // MDRNN
+    rnnwf::DevBuf rowbuf;
+    void* pinned = nullptr;  // small pinned staging (moments)
+
+    bool timing_on = false;
+    rnnwf::KernelTimer timers[3];
+    double work[2] = {0.0, 0.0};
+
+    void* comm = nullptr;  // ncclComm_t
+    int rank = 0, nranks = 1;
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+};
+
+#define RNNWF_HIP(h, call)                                                                          \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return (h)->fail(RNNWF_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+namespace rnnwf {
+
+inline int ensure(rnnwf_handle* h, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return 0;
+    if (b.p) RNNWF_HIP(h, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    const size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) return h->fail(RNNWF_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    b.cap = want;
+    return 0;
+}
+
+// HIP-event bracket around one launch on the handle's stream
+struct TimedLaunch {
+    rnnwf_handle* h;
+    int id;
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    TimedLaunch(rnnwf_handle* h_, int id_) : h(h_), id(id_) {
+        if (!h->timing_on) return;
+        KernelTimer& t = h->timers[id];
+        if (!t.pool.empty()) {
+            ev = t.pool.back();
+            t.pool.pop_back();
+        } else {
+            hipEventCreate(&ev.first);
+            hipEventCreate(&ev.second);
+        }
+        hipEventRecord(ev.first, h->stream);
+    }
+    ~TimedLaunch() {
+        if (!h->timing_on) return;
+        hipEventRecord(ev.second, h->stream);
+        h->timers[id].pending.push_back(ev);
+    }
+};
+
+}  // namespace rnnwf

@@ -1,0 +1,49 @@
+// layout.h - shared (host + device) description of the weight image the kernels stage in LDS.
+//
+// Orientation (see DESIGN.md "Recurrent operand layout"): every recurrent step computes
+//     D^T[row, chain] = sum_k Wt[row, k] * h[k, chain]
+// with the 16x16x4 MFMA: A = Wt (rows = gate pre-activations), B = h^T (columns = 16 chains of one
+// wave).  The C/D fragment of lane (c = lane & 15, q = lane >> 4), register r, is then exactly the
+// B fragment the NEXT step needs (unit 16 m + 4 r + q <-> k-step 4 m + r, lane quarter q), so the
+// hidden state never leaves registers and never crosses lanes.
+//
+// GRU tiles (NT = 3 NFULL + 1, hidden size padded to HP = 16 NFULL + 4):
+//   tile g*NFULL + m (g = 0 r-gate, 1 u-gate, 2 candidate-hidden), m < NFULL : units 16m .. 16m+15
+//   tile 3*NFULL ("mixed")  : register r = gate r of unit 16 NFULL + q  (r = 3 unused)
+// K-steps: KT = 4 NFULL + 1 (k = 4 kt + q).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace rnnwf {
+
+constexpr int kChains = 16;  // chains (spin configurations) per wave: the N dimension of the 16x16x4 MFMA
+
+template <typename T, int NFULL_, int NOUT_>
+struct GruLayout {
+    static constexpr int NFULL = NFULL_;
+    static constexpr int NOUT = NOUT_;              // 2: positive RNN head; 4: amplitude + phase heads
+    static constexpr int HP = 16 * NFULL + 4;       // padded hidden size
+    static constexpr int KT = 4 * NFULL + 1;        // k-steps of 4
+    static constexpr int NT = 3 * NFULL + 1;        // 16-row output tiles
+    static constexpr int VW = 16 / (int)sizeof(T);  // A values per 16-byte LDS vector
+    static constexpr int NG = (KT - 1) / VW;        // full vectors per (tile, lane)
+    // byte offsets of the sections, every one 16-byte aligned
+    static constexpr size_t OFF_AVEC = 0;                                            // [NT][NG][64] x 16 B
+    static constexpr size_t OFF_AREM = OFF_AVEC + (size_t)NT * NG * 64 * 16;         // [NT][64] T   (kt = KT-1)
+    static constexpr size_t OFF_BINIT = OFF_AREM + (size_t)NT * 64 * sizeof(T);      // [3][NT][4 q][4 r] T
+    static constexpr size_t SZ_BINIT_VARIANT = ((size_t)NT * 16 + 4) * sizeof(T);    // +4 T pad: de-alias banks
+    static constexpr size_t OFF_XC = OFF_BINIT + 3 * SZ_BINIT_VARIANT;               // [3][NFULL+1][4][4] T
+    static constexpr size_t SZ_XC_VARIANT = ((size_t)(NFULL + 1) * 16 + 4) * sizeof(T);
+    static constexpr size_t OFF_WD = OFF_XC + 3 * SZ_XC_VARIANT;                     // [KT][4 q][NOUT] T
+    static constexpr size_t OFF_BD = OFF_WD + (size_t)KT * 4 * NOUT * sizeof(T);     // [NOUT] T (padded to 32 B)
+    static constexpr size_t BYTES = ((OFF_BD + 32 + 15) / 16) * 16;
+};
+
+// row index inside a 16-row tile  <->  (lane quarter q of the C/D fragment, register r)
+//   f32 16x16x4 : row = 4 q + r          f64 16x16x4 : row = q + 4 r
+template <typename T> inline void row_to_qr(int row, int& q, int& r);
+template <> inline void row_to_qr<float>(int row, int& q, int& r) { q = row >> 2; r = row & 3; }
+template <> inline void row_to_qr<double>(int row, int& q, int& r) { q = row & 3; r = row >> 2; }
+
+}  // namespace rnnwf

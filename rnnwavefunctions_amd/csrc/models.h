@@ -1,0 +1,54 @@
+// models.h - host-side entry points of each wave-function family (one .hip translation unit each) and
+// the helpers they share (implemented in rnnwf_api.hip).
+#pragma once
+#include <vector>
+
+#include "handle.h"
+
+namespace rnnwf {
+
+// ---- shared helpers (rnnwf_api.hip) --------------------------------------------------------------
+int upload_samples(rnnwf_handle* h, const int32_t* samples, int64_t B);
+int pack_device(rnnwf_handle* h, int64_t B, DevBuf& bits, int reverse, const int32_t* col_of_pos_dev);
+int unpack_device(rnnwf_handle* h, const DevBuf& bits, int64_t B, const int32_t* pos_of_col_dev);
+int upload_and_pack(rnnwf_handle* h, const int32_t* samples, int64_t B, DevBuf& bits, int reverse,
+                    const int32_t* col_of_pos_dev);
+int unpack_and_download(rnnwf_handle* h, const DevBuf& bits, int64_t B, int32_t* out, const int32_t* pos_of_col_dev);
+int run_moments(rnnwf_handle* h, const void* eloc_dev, int64_t ns, bool complex_f32, double* moments_host);
+int run_tfim_eloc(rnnwf_handle* h, const uint32_t* bits, const double* lpq, int64_t ns, int Nx, int Ny,
+                  const int32_t* pos_of_site_dev, const double* Jz_dev, double Bx, double* eloc_dev);
+int run_parity_combine(rnnwf_handle* h, const double* a, const double* b, int64_t n, double* out);
+
+// ---- weight image ---------------------------------------------------------------------------------
+int model_pack_image(rnnwf_handle* h, std::vector<char>& img);  // dispatches to the family below
+int prnn_pack_image(rnnwf_handle* h, std::vector<char>& img);
+int crnn_pack_image(rnnwf_handle* h, std::vector<char>& img);
+int mdrnn_pack_image(rnnwf_handle* h, std::vector<char>& img);
+
+// ---- positive GRU RNN (prnn.hip): models GRU1D, GRU1D_PARITY, GRU1D_F64 ---------------------------
+int prnn_sample(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t step, int64_t offset, int32_t* out, double* out_log);
+int prnn_log_prob(rnnwf_handle* h, const int32_t* samples, int64_t B, double* out);
+int prnn_tfim_eloc(rnnwf_handle* h, const int32_t* samples, int64_t ns, int Nx, int Ny, const double* Jz, double Bx,
+                   double* eloc, double* log_probs);
+int prnn_vmc_step(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t step, int64_t offset, const double* couplings,
+                  int32_t* out_samples, double* out_eloc, double* moments);
+
+// ---- complex GRU RNN with U(1) mask (crnn.hip) -----------------------------------------------------
+int crnn_sample(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t step, int64_t offset, int32_t* out, double* out_log);
+int crnn_log_amp(rnnwf_handle* h, const int32_t* samples, int64_t B, float* out_re_im, double* out_logp);
+int crnn_j1j2_eloc(rnnwf_handle* h, const int32_t* samples, int64_t ns, const double* J1, const double* J2,
+                   const double* Bz, int periodic, int marshall, float* eloc, int64_t* ncon);
+int crnn_vmc_step(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t step, int64_t offset, const double* couplings,
+                  int32_t* out_samples, float* out_eloc, double* moments);
+
+// ---- 2D MDRNN (mdrnn.hip) ---------------------------------------------------------------------------
+int mdrnn_sample(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t step, int64_t offset, int32_t* out, double* out_log);
+int mdrnn_log_prob(rnnwf_handle* h, const int32_t* samples, int64_t B, double* out);
+int mdrnn_tfim_eloc(rnnwf_handle* h, const int32_t* samples, int64_t ns, const double* Jz, double Bx, double* eloc,
+                    double* log_probs);
+int mdrnn_vmc_step(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t step, int64_t offset, const double* couplings,
+                   int32_t* out_samples, double* out_eloc, double* moments);
+
+}  // namespace rnnwf
+
+extern "C" int rnnwf_comm_destroy(rnnwf_handle* h);

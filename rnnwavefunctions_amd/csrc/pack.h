@@ -1,0 +1,104 @@
+// pack.h - host-side packing of TF-named parameters into the LDS weight image of layout.h.
+#pragma once
+#include <cstring>
+#include <vector>
+
+#include "handle.h"
+#include "layout.h"
+
+namespace rnnwf {
+
+static const char* kGruPre = "multi_rnn_cell/cell_0/cudnn_compatible_gru_cell/";
+
+inline const std::vector<double>& pv(const rnnwf_handle* h, const std::string& name) {
+    return h->params.at(name).value;
+}
+
+// Packs the single-layer cuDNN-compatible GRU + Dense head(s).
+template <typename T, int NFULL, int NOUT>
+std::vector<char> pack_gru_image(const rnnwf_handle* h) {
+    using L = GruLayout<T, NFULL, NOUT>;
+    const int H = h->H;
+    std::vector<char> img(L::BYTES, 0);
+    const std::string pre = kGruPre;
+    const auto& Wg = pv(h, pre + "gates/kernel");                         // [2+H, 2H], cols r | u
+    const auto& bg = pv(h, pre + "gates/bias");                           // [2H]
+    const auto& Wci = pv(h, pre + "candidate/input_projection/kernel");   // [2, H]
+    const auto& bci = pv(h, pre + "candidate/input_projection/bias");     // [H]
+    const auto& Wch = pv(h, pre + "candidate/hidden_projection/kernel");  // [H, H]
+    const auto& bch = pv(h, pre + "candidate/hidden_projection/bias");    // [H]
+
+    auto decode = [&](int tile, int q, int r, int& gate, int& unit) -> bool {
+        if (tile < 3 * NFULL) {
+            gate = tile / NFULL;
+            unit = 16 * (tile % NFULL) + 4 * r + q;
+        } else {
+            if (r == 3) return false;
+            gate = r;
+            unit = 16 * NFULL + q;
+        }
+        return unit < H;
+    };
+    auto wt = [&](int gate, int unit, int k) -> double {  // W^T[row(gate,unit)][k]
+        if (k >= H) return 0.0;
+        if (gate == 0) return Wg[(size_t)(2 + k) * 2 * H + unit];
+        if (gate == 1) return Wg[(size_t)(2 + k) * 2 * H + H + unit];
+        return Wch[(size_t)k * H + unit];
+    };
+    T* avec = reinterpret_cast<T*>(img.data() + L::OFF_AVEC);
+    T* arem = reinterpret_cast<T*>(img.data() + L::OFF_AREM);
+    for (int tile = 0; tile < L::NT; ++tile)
+        for (int row = 0; row < 16; ++row) {
+            int q, r, gate, unit;
+            row_to_qr<T>(row, q, r);
+            if (!decode(tile, q, r, gate, unit)) continue;
+            for (int kq = 0; kq < 4; ++kq) {       // lane quarter of the A operand = k mod 4
+                const int lane = (kq << 4) | row;
+                for (int g = 0; g < L::NG; ++g)
+                    for (int j = 0; j < L::VW; ++j)
+                        avec[(((size_t)tile * L::NG + g) * 64 + lane) * L::VW + j] =
+                            (T)wt(gate, unit, 4 * (g * L::VW + j) + kq);
+                arem[(size_t)tile * 64 + lane] = (T)wt(gate, unit, 4 * (L::KT - 1) + kq);
+            }
+        }
+    for (int v = 0; v < 3; ++v) {  // v = 0: zero input; v = 1, 2: one-hot of spin 0, 1
+        T* binit = reinterpret_cast<T*>(img.data() + L::OFF_BINIT + v * L::SZ_BINIT_VARIANT);
+        T* xc = reinterpret_cast<T*>(img.data() + L::OFF_XC + v * L::SZ_XC_VARIANT);
+        for (int tile = 0; tile < L::NT; ++tile)
+            for (int q = 0; q < 4; ++q)
+                for (int r = 0; r < 4; ++r) {
+                    int gate, unit;
+                    if (!decode(tile, q, r, gate, unit)) continue;
+                    double b;
+                    if (gate == 0) b = bg[unit] + (v ? Wg[(size_t)(v - 1) * 2 * H + unit] : 0.0);
+                    else if (gate == 1) b = bg[H + unit] + (v ? Wg[(size_t)(v - 1) * 2 * H + H + unit] : 0.0);
+                    else b = bch[unit];
+                    binit[tile * 16 + q * 4 + r] = (T)b;
+                }
+        for (int m = 0; m <= NFULL; ++m)
+            for (int q = 0; q < 4; ++q)
+                for (int r = 0; r < 4; ++r) {
+                    if (m == NFULL && r != 0) continue;
+                    const int unit = m < NFULL ? 16 * m + 4 * r + q : 16 * NFULL + q;
+                    if (unit >= H) continue;
+                    xc[m * 16 + q * 4 + r] = (T)(bci[unit] + (v ? Wci[(size_t)(v - 1) * H + unit] : 0.0));
+                }
+    }
+    T* wd = reinterpret_cast<T*>(img.data() + L::OFF_WD);
+    T* bd = reinterpret_cast<T*>(img.data() + L::OFF_BD);
+    const char* heads[2] = {NOUT == 2 ? "wf_dense" : "wf_dense_ampl", "wf_dense_phase"};
+    for (int hd = 0; hd < NOUT / 2; ++hd) {
+        const auto& Wd = pv(h, std::string(heads[hd]) + "/kernel");  // [H, 2]
+        const auto& bdv = pv(h, std::string(heads[hd]) + "/bias");   // [2]
+        for (int kt = 0; kt < L::KT; ++kt)
+            for (int q = 0; q < 4; ++q) {
+                const int unit = 4 * kt + q;
+                if (unit >= H) continue;
+                for (int o = 0; o < 2; ++o) wd[(kt * 4 + q) * NOUT + hd * 2 + o] = (T)Wd[(size_t)unit * 2 + o];
+            }
+        for (int o = 0; o < 2; ++o) bd[hd * 2 + o] = (T)bdv[o];
+    }
+    return img;
+}
+
+}  // namespace rnnwf

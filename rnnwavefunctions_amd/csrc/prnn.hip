@@ -1,0 +1,273 @@
+// prnn.hip - host side of the positive GRU RNN wave function (models GRU1D, GRU1D_PARITY, GRU1D_F64):
+// sample / log_probability / fused TFIM local energies / fused VMC step.
+#include <algorithm>
+
+#include "gru_kernels.h"
+#include "models.h"
+#include "pack.h"
+
+using namespace rnnwf;
+
+namespace {
+
+constexpr size_t kHckBudget = (size_t)48 << 30;  // bytes of hidden-state checkpoints per pass
+constexpr int64_t kLogProbChunk = (int64_t)1 << 20;
+
+template <typename T, int NFULL, int WAVES>
+struct Launch {
+    using L = GruLayout<T, NFULL, 2>;
+    static int blocks_per_cu(rnnwf_handle* h, const void* fn, int* out) {
+        RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES));
+        int nb = 0;
+        RNNWF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, WAVES * 64, L::BYTES));
+        *out = std::max(nb, 1);
+        return 0;
+    }
+    static int base(rnnwf_handle* h, const PrnnArgs& a) {
+        static int bpc = 0;
+        const void* fn = (const void*)prnn_base_kernel<T, NFULL, WAVES>;
+        if (!bpc) if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
+        const int64_t need = (a.nsb + WAVES - 1) / WAVES;
+        const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
+        TimedLaunch tl(h, 0);
+        prnn_base_kernel<T, NFULL, WAVES><<<grid, WAVES * 64, L::BYTES, h->stream>>>(a);
+        RNNWF_HIP(h, hipGetLastError());
+        return 0;
+    }
+    static int flip(rnnwf_handle* h, const PrnnArgs& a) {
+        static int bpc = 0;
+        const void* fn = (const void*)prnn_flip_kernel<T, NFULL, WAVES>;
+        if (!bpc) if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
+        const int64_t need = (a.ntiles + WAVES - 1) / WAVES;
+        const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
+        TimedLaunch tl(h, 1);
+        prnn_flip_kernel<T, NFULL, WAVES><<<grid, WAVES * 64, L::BYTES, h->stream>>>(a);
+        RNNWF_HIP(h, hipGetLastError());
+        return 0;
+    }
+    static std::vector<char> pack(const rnnwf_handle* h) { return pack_gru_image<T, NFULL, 2>(h); }
+    static size_t hck_bytes_per_block() { return (size_t)L::KT * 64 * sizeof(T); }
+    static double mfma_flops_per_step() { return (double)L::NT * L::KT * 2048.0; }
+};
+
+// one place that maps (dtype, NFULL) to an instantiation
+#define PRNN_DISPATCH(h, EXPR)                                                              \
+    do {                                                                                    \
+        if (!(h)->f64) {                                                                    \
+            switch ((h)->NFULL) {                                                           \
+                case 1: { using K = Launch<float, 1, 4>; EXPR; }                            \
+                case 2: { using K = Launch<float, 2, 4>; EXPR; }                            \
+                case 3: { using K = Launch<float, 3, 4>; EXPR; }                            \
+                case 4: { using K = Launch<float, 4, 4>; EXPR; }                            \
+                case 6: { using K = Launch<float, 6, 12>; EXPR; }                           \
+            }                                                                               \
+        } else {                                                                            \
+            switch ((h)->NFULL) {                                                           \
+                case 1: { using K = Launch<double, 1, 4>; EXPR; }                           \
+                case 2: { using K = Launch<double, 2, 4>; EXPR; }                           \
+                case 3: { using K = Launch<double, 3, 4>; EXPR; }                           \
+                case 4: { using K = Launch<double, 4, 8>; EXPR; }                           \
+            }                                                                               \
+        }                                                                                   \
+    } while (0)
+
+int launch_base(rnnwf_handle* h, const PrnnArgs& a) {
+    PRNN_DISPATCH(h, return K::base(h, a));
+    return h->fail(RNNWF_ERR_INVALID, "no pRNN kernel for NFULL=%d f64=%d", h->NFULL, (int)h->f64);
+}
+int launch_flip(rnnwf_handle* h, const PrnnArgs& a) {
+    PRNN_DISPATCH(h, return K::flip(h, a));
+    return h->fail(RNNWF_ERR_INVALID, "no pRNN kernel for NFULL=%d f64=%d", h->NFULL, (int)h->f64);
+}
+size_t hck_bytes_per_block(rnnwf_handle* h) {
+    PRNN_DISPATCH(h, return K::hck_bytes_per_block());
+    return 0;
+}
+double mfma_flops_per_step(rnnwf_handle* h) {
+    PRNN_DISPATCH(h, return K::mfma_flops_per_step());
+    return 0;
+}
+
+PrnnArgs base_args(rnnwf_handle* h, int64_t ns) {
+    PrnnArgs a{};
+    a.wimg = h->wimg.p;
+    a.N = h->N;
+    a.ns = ns;
+    a.nsb = (ns + kChains - 1) / kChains;
+    return a;
+}
+
+// row_of_pos map for the reversed pass of the parity-symmetric model: position n of the reversed chain
+// is site N-1-n, so its flip lands in lpq row (N-1-n)+1.
+int ensure_reverse_map(rnnwf_handle* h) {
+    const int N = h->N;
+    if (h->maps.p) return 0;
+    std::vector<int32_t> m(N);
+    for (int n = 0; n < N; ++n) m[n] = N - n;
+    if (int rc = ensure(h, h->maps, (size_t)N * 4)) return rc;
+    RNNWF_HIP(h, hipMemcpy(h->maps.p, m.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// Fused local energies of ns chains whose packed spins are already in h->bits (and, for the parity
+// model, reversed in h->bits2): base pass with checkpoints -> flip pass -> assembly.  Leaves E_loc in
+// h->eloc and the log-prob queue in h->lpq.
+int eloc_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, uint64_t step, int64_t offset,
+                   int Nx, int Ny, const double* Jz_dev, double Bx) {
+    const int N = h->N;
+    const int64_t nsb = (ns + kChains - 1) / kChains;
+    const bool parity = h->model == RNNWF_MODEL_GRU1D_PARITY;
+    const size_t hck_bytes = (size_t)std::max(N - 1, 1) * nsb * hck_bytes_per_block(h);
+    if (int rc = ensure(h, h->lpq, (size_t)(N + 1) * ns * 8)) return rc;
+    if (int rc = ensure(h, h->eloc, (size_t)ns * 8)) return rc;
+    if (Bx != 0.0) if (int rc = ensure(h, h->hck, hck_bytes)) return rc;
+
+    PrnnArgs a = base_args(h, ns);
+    a.bits = (uint32_t*)h->bits.p;
+    a.hck = Bx != 0.0 ? h->hck.p : nullptr;
+    a.lpq = (double*)h->lpq.p;
+    a.sampling = sampling ? 1 : 0;
+    a.seed = seed; a.step = step; a.sample_offset = offset;
+    if (int rc = launch_base(h, a)) return rc;
+    if (Bx != 0.0 && N > 1) {
+        a.ntiles = (int64_t)(N - 1) * nsb;
+        a.sampling = 0;
+        if (int rc = launch_flip(h, a)) return rc;
+        h->work[0] += (double)ns * N * (N - 1) / 2.0;
+        h->work[1] += (double)nsb * N * (N - 1) / 2.0 * mfma_flops_per_step(h);
+    }
+    if (parity) {
+        // second direction on the reversed chains, then log(0.5 (e^a + e^b)) row by row
+        if (sampling) {  // reversed bits from the freshly drawn spins
+            if (int rc = unpack_device(h, h->bits, ns, nullptr)) return rc;
+            if (int rc = pack_device(h, ns, h->bits2, 1, nullptr)) return rc;
+        }
+        if (int rc = ensure_reverse_map(h)) return rc;
+        if (int rc = ensure(h, h->lpq2, (size_t)(N + 1) * ns * 8)) return rc;
+        PrnnArgs b = base_args(h, ns);
+        b.bits = (uint32_t*)h->bits2.p;
+        b.hck = a.hck;
+        b.lpq = (double*)h->lpq2.p;
+        b.row_of_pos = (const int32_t*)h->maps.p;
+        if (int rc = launch_base(h, b)) return rc;
+        if (Bx != 0.0 && N > 1) {
+            b.ntiles = (int64_t)(N - 1) * nsb;
+            if (int rc = launch_flip(h, b)) return rc;
+            h->work[0] += (double)ns * N * (N - 1) / 2.0;
+            h->work[1] += (double)nsb * N * (N - 1) / 2.0 * mfma_flops_per_step(h);
+        }
+        if (int rc = run_parity_combine(h, (const double*)h->lpq.p, (const double*)h->lpq2.p, (int64_t)(N + 1) * ns,
+                                        (double*)h->lpq.p)) return rc;
+    }
+    return run_tfim_eloc(h, (const uint32_t*)h->bits.p, (const double*)h->lpq.p, ns, Nx, Ny, nullptr, Jz_dev, Bx,
+                         (double*)h->eloc.p);
+}
+
+int64_t max_chains_per_pass(rnnwf_handle* h) {
+    const size_t per_block = (size_t)std::max(h->N - 1, 1) * hck_bytes_per_block(h);
+    const int64_t blocks = std::max<int64_t>(1, (int64_t)(kHckBudget / per_block));
+    return blocks * kChains;
+}
+
+}  // namespace
+
+int rnnwf::prnn_pack_image(rnnwf_handle* h, std::vector<char>& img) {
+    PRNN_DISPATCH(h, { img = K::pack(h); return 0; });
+    return h->fail(RNNWF_ERR_INVALID, "no pRNN kernel for NFULL=%d f64=%d", h->NFULL, (int)h->f64);
+}
+
+int rnnwf::prnn_log_prob(rnnwf_handle* h, const int32_t* samples, int64_t B, double* out) {
+    const int N = h->N;
+    const bool parity = h->model == RNNWF_MODEL_GRU1D_PARITY;
+    for (int64_t off = 0; off < B; off += kLogProbChunk) {
+        const int64_t nb = std::min(kLogProbChunk, B - off);
+        if (int rc = upload_and_pack(h, samples + off * N, nb, h->bits, 0, nullptr)) return rc;
+        if (int rc = ensure(h, h->out_lp, (size_t)nb * 8)) return rc;
+        PrnnArgs a = base_args(h, nb);
+        a.bits = (uint32_t*)h->bits.p;
+        a.out_lp = (double*)h->out_lp.p;
+        if (int rc = launch_base(h, a)) return rc;
+        if (parity) {
+            if (int rc = pack_device(h, nb, h->bits2, 1, nullptr)) return rc;
+            if (int rc = ensure(h, h->out_lp2, (size_t)nb * 8)) return rc;
+            a.bits = (uint32_t*)h->bits2.p;
+            a.out_lp = (double*)h->out_lp2.p;
+            if (int rc = launch_base(h, a)) return rc;
+            if (int rc = run_parity_combine(h, (const double*)h->out_lp.p, (const double*)h->out_lp2.p, nb,
+                                            (double*)h->out_lp.p)) return rc;
+        }
+        RNNWF_HIP(h, hipMemcpyAsync(out + off, h->out_lp.p, (size_t)nb * 8, hipMemcpyDeviceToHost, h->stream));
+        RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    return RNNWF_OK;
+}
+
+int rnnwf::prnn_sample(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t step, int64_t offset, int32_t* out,
+                       double* out_log) {
+    const int N = h->N;
+    const int W = (N + 31) / 32;
+    if (int rc = ensure(h, h->bits, (size_t)W * ns * 4)) return rc;
+    if (int rc = ensure(h, h->out_lp, (size_t)ns * 8)) return rc;
+    PrnnArgs a = base_args(h, ns);
+    a.bits = (uint32_t*)h->bits.p;
+    a.out_lp = (double*)h->out_lp.p;
+    a.sampling = 1;
+    a.seed = seed; a.step = step; a.sample_offset = offset;
+    if (int rc = launch_base(h, a)) return rc;
+    if (int rc = unpack_and_download(h, h->bits, ns, out, nullptr)) return rc;
+    if (out_log) {
+        if (h->model == RNNWF_MODEL_GRU1D_PARITY) {  // symmetrised probability of the drawn configurations
+            if (int rc = pack_device(h, ns, h->bits2, 1, nullptr)) return rc;
+            if (int rc = ensure(h, h->out_lp2, (size_t)ns * 8)) return rc;
+            PrnnArgs b = base_args(h, ns);
+            b.bits = (uint32_t*)h->bits2.p;
+            b.out_lp = (double*)h->out_lp2.p;
+            if (int rc = launch_base(h, b)) return rc;
+            if (int rc = run_parity_combine(h, (const double*)h->out_lp.p, (const double*)h->out_lp2.p, ns,
+                                            (double*)h->out_lp.p)) return rc;
+        }
+        RNNWF_HIP(h, hipMemcpyAsync(out_log, h->out_lp.p, (size_t)ns * 8, hipMemcpyDeviceToHost, h->stream));
+    }
+    RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+    return RNNWF_OK;
+}
+
+int rnnwf::prnn_tfim_eloc(rnnwf_handle* h, const int32_t* samples, int64_t ns, int Nx, int Ny, const double* Jz,
+                          double Bx, double* eloc, double* log_probs) {
+    const int N = h->N;
+    if (int rc = ensure(h, h->coupl, (size_t)N * 8)) return rc;
+    RNNWF_HIP(h, hipMemcpyAsync(h->coupl.p, Jz, (size_t)N * 8, hipMemcpyHostToDevice, h->stream));
+    const int64_t chunk = max_chains_per_pass(h);
+    for (int64_t off = 0; off < ns; off += chunk) {
+        const int64_t nb = std::min(chunk, ns - off);
+        if (int rc = upload_and_pack(h, samples + off * N, nb, h->bits, 0, nullptr)) return rc;
+        if (h->model == RNNWF_MODEL_GRU1D_PARITY)
+            if (int rc = pack_device(h, nb, h->bits2, 1, nullptr)) return rc;
+        if (int rc = eloc_on_device(h, nb, false, 0, 0, 0, Nx, Ny, (const double*)h->coupl.p, Bx)) return rc;
+        RNNWF_HIP(h, hipMemcpyAsync(eloc + off, h->eloc.p, (size_t)nb * 8, hipMemcpyDeviceToHost, h->stream));
+        if (log_probs)
+            RNNWF_HIP(h, hipMemcpy2DAsync(log_probs + off, (size_t)ns * 8, h->lpq.p, (size_t)nb * 8, (size_t)nb * 8,
+                                          (size_t)N + 1, hipMemcpyDeviceToHost, h->stream));
+        RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    return RNNWF_OK;
+}
+
+int rnnwf::prnn_vmc_step(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t step, int64_t offset,
+                         const double* couplings, int32_t* out_samples, double* out_eloc, double* moments) {
+    const int N = h->N;
+    const int W = (N + 31) / 32;
+    if (ns > max_chains_per_pass(h))
+        return h->fail(RNNWF_ERR_NOMEM, "rnnwf_vmc_step: %lld samples exceed the checkpoint budget; split the batch",
+                       (long long)ns);
+    if (int rc = ensure(h, h->bits, (size_t)W * ns * 4)) return rc;
+    if (int rc = ensure(h, h->coupl, (size_t)N * 8)) return rc;
+    RNNWF_HIP(h, hipMemcpyAsync(h->coupl.p, couplings, (size_t)N * 8, hipMemcpyHostToDevice, h->stream));
+    const double Bx = couplings[N];
+    const int Nx = h->model == RNNWF_MODEL_GRU1D_F64 ? h->Nx : 1;
+    const int Ny = h->model == RNNWF_MODEL_GRU1D_F64 ? h->Ny : N;
+    if (int rc = eloc_on_device(h, ns, true, seed, step, offset, Nx, Ny, (const double*)h->coupl.p, Bx)) return rc;
+    if (out_samples) if (int rc = unpack_and_download(h, h->bits, ns, out_samples, nullptr)) return rc;
+    if (out_eloc) RNNWF_HIP(h, hipMemcpyAsync(out_eloc, h->eloc.p, (size_t)ns * 8, hipMemcpyDeviceToHost, h->stream));
+    return run_moments(h, h->eloc.p, ns, false, moments);
+}

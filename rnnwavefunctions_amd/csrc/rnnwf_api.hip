@@ -1,0 +1,436 @@
+// rnnwf_api.hip - C ABI (include/rnnwf.h) over the gfx950 kernels: handle life cycle, parameters,
+// pRNN sample / log_prob / TFIM local energies, fused VMC step, timing.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "handle.h"
+#include "models.h"
+#include "pack.h"
+#include "util_kernels.h"
+
+using namespace rnnwf;
+
+static std::string g_create_error;
+
+// -------------------------------------------------------------------------------------------------
+// parameter table per model
+// -------------------------------------------------------------------------------------------------
+static void declare(rnnwf_handle* h, const std::string& name, std::vector<int64_t> shape) {
+    ParamSpec s;
+    s.shape = shape;
+    int64_t n = 1;
+    for (auto d : shape) n *= d;
+    s.value.assign((size_t)n, 0.0);
+    h->params[name] = s;
+}
+
+static void declare_params(rnnwf_handle* h) {
+    const int64_t H = h->H;
+    if (h->model == RNNWF_MODEL_MDRNN2D) {
+        declare(h, "Wh_rnn_0", {H, H});
+        declare(h, "Uh_rnn_0", {2, H});
+        declare(h, "Wv_rnn_0", {H, H});
+        declare(h, "Uv_rnn_0", {2, H});
+        declare(h, "b_rnn_0", {H});
+        declare(h, "wf_dense/kernel", {H, 2});
+        declare(h, "wf_dense/bias", {2});
+        return;
+    }
+    const std::string pre = kGruPre;
+    declare(h, pre + "gates/kernel", {2 + H, 2 * H});
+    declare(h, pre + "gates/bias", {2 * H});
+    declare(h, pre + "candidate/input_projection/kernel", {2, H});
+    declare(h, pre + "candidate/input_projection/bias", {H});
+    declare(h, pre + "candidate/hidden_projection/kernel", {H, H});
+    declare(h, pre + "candidate/hidden_projection/bias", {H});
+    if (h->model == RNNWF_MODEL_CRNN_U1) {
+        declare(h, "wf_dense_ampl/kernel", {H, 2});
+        declare(h, "wf_dense_ampl/bias", {2});
+        declare(h, "wf_dense_phase/kernel", {H, 2});
+        declare(h, "wf_dense_phase/bias", {2});
+    } else {
+        declare(h, "wf_dense/kernel", {H, 2});
+        declare(h, "wf_dense/bias", {2});
+    }
+}
+
+static int pick_nfull(int H, bool f64, bool mdrnn) {
+    const int cand[] = {1, 2, 3, 4, 6};
+    for (int nf : cand) {
+        if (16 * nf + 4 < H) continue;
+        if (f64 && !mdrnn && nf > 4) return -1;   // f64 GRU image must fit the 160 KiB LDS
+        return nf;
+    }
+    return -1;
+}
+
+// -------------------------------------------------------------------------------------------------
+// life cycle
+// -------------------------------------------------------------------------------------------------
+extern "C" const char* rnnwf_backend_name(void) { return "hip-gfx950"; }
+extern "C" int rnnwf_abi_version(void) { return RNNWF_ABI_VERSION; }
+
+extern "C" const char* rnnwf_last_error(const rnnwf_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int rnnwf_create(const rnnwf_config* cfg, rnnwf_handle** out) {
+    auto bad = [&](const std::string& m) {
+        g_create_error = m;
+        return (int)RNNWF_ERR_INVALID;
+    };
+    if (!cfg || !out) return bad("rnnwf_create: null argument");
+    *out = nullptr;
+    if (cfg->abi_version != RNNWF_ABI_VERSION) return bad("rnnwf_create: ABI version mismatch");
+    if (cfg->model < 0 || cfg->model > RNNWF_MODEL_MDRNN2D) return bad("rnnwf_create: unknown model");
+    if (cfg->nx < 1 || cfg->ny < 1) return bad("rnnwf_create: system size must be positive");
+    if (cfg->num_layers != 1)
+        return bad("rnnwf_create: only single-layer wave functions (len(units) == 1) are implemented on gfx950");
+    if (cfg->units[0] < 1) return bad("rnnwf_create: units[0] must be positive");
+    const bool two_d = cfg->model == RNNWF_MODEL_MDRNN2D || cfg->model == RNNWF_MODEL_GRU1D_F64;
+    if (!two_d && cfg->ny != 1) return bad("rnnwf_create: ny must be 1 for the 1D models");
+    if (cfg->model == RNNWF_MODEL_CRNN_U1 && (cfg->nx % 2)) return bad("rnnwf_create: the U(1) cRNN needs an even number of sites");
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        g_create_error = std::string("rnnwf_create: no HIP device available (") + hipGetErrorString(e) + ")";
+        return RNNWF_ERR_HIP;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) return bad("rnnwf_create: device ordinal out of range");
+
+    rnnwf_handle* h = new rnnwf_handle();
+    h->cfg = *cfg;
+    h->model = cfg->model;
+    h->f64 = cfg->model == RNNWF_MODEL_GRU1D_F64 || cfg->model == RNNWF_MODEL_MDRNN2D;
+    h->H = cfg->units[0];
+    h->Nx = cfg->nx;
+    h->Ny = cfg->ny;
+    h->N = cfg->nx * cfg->ny;
+    h->NFULL = pick_nfull(h->H, h->f64, h->model == RNNWF_MODEL_MDRNN2D);
+    if (h->NFULL < 0) {
+        delete h;
+        return bad("rnnwf_create: num_units too large for the LDS-resident kernels (f32: <= 100, f64 GRU: <= 68)");
+    }
+    auto fail_hip = [&](const char* what, hipError_t err) {
+        g_create_error = std::string("rnnwf_create: ") + what + ": " + hipGetErrorString(err);
+        delete h;
+        return (int)RNNWF_ERR_HIP;
+    };
+    if ((e = hipSetDevice(cfg->device)) != hipSuccess) return fail_hip("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, cfg->device)) != hipSuccess) return fail_hip("hipGetDeviceProperties", e);
+    h->cu_count = prop.multiProcessorCount;
+    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return fail_hip("hipStreamCreate", e);
+    if ((e = hipHostMalloc(&h->pinned, 4096, hipHostMallocDefault)) != hipSuccess) return fail_hip("hipHostMalloc", e);
+    declare_params(h);
+    *out = h;
+    return RNNWF_OK;
+}
+
+static void free_buf(DevBuf& b) {
+    if (b.p) hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+extern "C" int rnnwf_destroy(rnnwf_handle* h) {
+    if (!h) return RNNWF_OK;
+    hipSetDevice(h->cfg.device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    rnnwf_comm_destroy(h);
+    DevBuf* bufs[] = {&h->wimg, &h->samples_i32, &h->bits, &h->bits2, &h->hck, &h->lpq, &h->lpq2, &h->out_lp,
+                      &h->out_lp2, &h->eloc, &h->moments, &h->coupl, &h->maps, &h->camp, &h->tiles,
+                      &h->tile_count, &h->cbase, &h->cout, &h->rowbuf};
+    for (DevBuf* b : bufs) free_buf(*b);
+    for (auto& t : h->timers) {
+        for (auto& ev : t.pending) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+        for (auto& ev : t.pool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    }
+    if (h->pinned) hipHostFree(h->pinned);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return RNNWF_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// parameters
+// -------------------------------------------------------------------------------------------------
+static int find_param(rnnwf_handle* h, const char* name, int64_t count, ParamSpec** out) {
+    if (!name) return h->fail(RNNWF_ERR_INVALID, "parameter name is null");
+    auto it = h->params.find(name);
+    if (it == h->params.end()) return h->fail(RNNWF_ERR_INVALID, "unknown parameter '%s' for this model", name);
+    if ((int64_t)it->second.value.size() != count)
+        return h->fail(RNNWF_ERR_INVALID, "parameter '%s' has %lld elements, caller passed %lld", name,
+                       (long long)it->second.value.size(), (long long)count);
+    *out = &it->second;
+    return 0;
+}
+
+extern "C" int rnnwf_set_param(rnnwf_handle* h, const char* name, const void* data, int64_t count, int32_t dtype) {
+    if (!h || !data) return RNNWF_ERR_INVALID;
+    ParamSpec* p;
+    if (int rc = find_param(h, name, count, &p)) return rc;
+    if (dtype == RNNWF_F32) for (int64_t i = 0; i < count; ++i) p->value[i] = ((const float*)data)[i];
+    else if (dtype == RNNWF_F64) for (int64_t i = 0; i < count; ++i) p->value[i] = ((const double*)data)[i];
+    else return h->fail(RNNWF_ERR_INVALID, "unknown dtype %d", dtype);
+    p->set = true;
+    h->committed = false;
+    return RNNWF_OK;
+}
+
+extern "C" int rnnwf_get_param(rnnwf_handle* h, const char* name, void* data, int64_t count, int32_t dtype) {
+    if (!h || !data) return RNNWF_ERR_INVALID;
+    ParamSpec* p;
+    if (int rc = find_param(h, name, count, &p)) return rc;
+    if (dtype == RNNWF_F32) for (int64_t i = 0; i < count; ++i) ((float*)data)[i] = (float)p->value[i];
+    else if (dtype == RNNWF_F64) for (int64_t i = 0; i < count; ++i) ((double*)data)[i] = p->value[i];
+    else return h->fail(RNNWF_ERR_INVALID, "unknown dtype %d", dtype);
+    return RNNWF_OK;
+}
+
+extern "C" int64_t rnnwf_num_params(const rnnwf_handle* h) {
+    int64_t n = 0;
+    if (h) for (auto& kv : h->params) n += (int64_t)kv.second.value.size();
+    return n;
+}
+
+extern "C" int rnnwf_commit_params(rnnwf_handle* h) {
+    if (!h) return RNNWF_ERR_INVALID;
+    for (auto& kv : h->params)
+        if (!kv.second.set) return h->fail(RNNWF_ERR_STATE, "parameter '%s' was never set", kv.first.c_str());
+    RNNWF_HIP(h, hipSetDevice(h->cfg.device));
+    std::vector<char> img;
+    if (int rc = model_pack_image(h, img)) return rc;
+    if (int rc = ensure(h, h->wimg, img.size())) return rc;
+    RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+    RNNWF_HIP(h, hipMemcpy(h->wimg.p, img.data(), img.size(), hipMemcpyHostToDevice));
+    h->committed = true;
+    return RNNWF_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// common helpers
+// -------------------------------------------------------------------------------------------------
+static int check_ready(rnnwf_handle* h) {
+    if (!h) return RNNWF_ERR_INVALID;
+    if (!h->committed) return h->fail(RNNWF_ERR_STATE, "parameters not committed (call rnnwf_commit_params)");
+    RNNWF_HIP(h, hipSetDevice(h->cfg.device));
+    return 0;
+}
+
+int rnnwf::upload_samples(rnnwf_handle* h, const int32_t* samples, int64_t B) {
+    if (int rc = ensure(h, h->samples_i32, (size_t)B * h->N * 4)) return rc;
+    RNNWF_HIP(h, hipMemcpyAsync(h->samples_i32.p, samples, (size_t)B * h->N * 4, hipMemcpyHostToDevice, h->stream));
+    return 0;
+}
+
+// packs the (B, N) int32 matrix currently held in h->samples_i32
+int rnnwf::pack_device(rnnwf_handle* h, int64_t B, DevBuf& bits, int reverse, const int32_t* col_of_pos_dev) {
+    const int N = h->N;
+    const int W = (N + 31) / 32;
+    if (int rc = ensure(h, bits, (size_t)W * B * 4)) return rc;
+    dim3 grid((unsigned)((B + 255) / 256), (unsigned)W);
+    pack_bits_kernel<<<grid, 256, 0, h->stream>>>((const int32_t*)h->samples_i32.p, B, N, col_of_pos_dev, reverse,
+                                                   (uint32_t*)bits.p);
+    RNNWF_HIP(h, hipGetLastError());
+    return 0;
+}
+
+int rnnwf::upload_and_pack(rnnwf_handle* h, const int32_t* samples, int64_t B, DevBuf& bits, int reverse,
+                           const int32_t* col_of_pos_dev) {
+    if (int rc = upload_samples(h, samples, B)) return rc;
+    return pack_device(h, B, bits, reverse, col_of_pos_dev);
+}
+
+// bits -> h->samples_i32 (device), optionally on to the host
+int rnnwf::unpack_device(rnnwf_handle* h, const DevBuf& bits, int64_t B, const int32_t* pos_of_col_dev) {
+    const int N = h->N;
+    if (int rc = ensure(h, h->samples_i32, (size_t)B * N * 4)) return rc;
+    const int64_t total = B * N;
+    unpack_bits_kernel<<<(unsigned)((total + 255) / 256), 256, 0, h->stream>>>((const uint32_t*)bits.p, B, N,
+                                                                                pos_of_col_dev, (int32_t*)h->samples_i32.p);
+    RNNWF_HIP(h, hipGetLastError());
+    return 0;
+}
+
+int rnnwf::unpack_and_download(rnnwf_handle* h, const DevBuf& bits, int64_t B, int32_t* out,
+                               const int32_t* pos_of_col_dev) {
+    if (int rc = unpack_device(h, bits, B, pos_of_col_dev)) return rc;
+    RNNWF_HIP(h, hipMemcpyAsync(out, h->samples_i32.p, (size_t)B * h->N * 4, hipMemcpyDeviceToHost, h->stream));
+    return 0;
+}
+
+int rnnwf::run_moments(rnnwf_handle* h, const void* eloc_dev, int64_t ns, bool complex_f32, double* moments_host) {
+    if (int rc = ensure(h, h->moments, 4 * sizeof(double))) return rc;
+    {
+        TimedLaunch tl(h, 2);
+        if (complex_f32)
+            moments_kernel<float><<<1, 1024, 0, h->stream>>>((const float*)eloc_dev, ns, 2, 1, (double*)h->moments.p);
+        else
+            moments_kernel<double><<<1, 1024, 0, h->stream>>>((const double*)eloc_dev, ns, 1, 0, (double*)h->moments.p);
+    }
+    RNNWF_HIP(h, hipGetLastError());
+    if (moments_host) {
+        RNNWF_HIP(h, hipMemcpyAsync(h->pinned, h->moments.p, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+        memcpy(moments_host, h->pinned, 4 * sizeof(double));
+    }
+    return 0;
+}
+
+int rnnwf::run_tfim_eloc(rnnwf_handle* h, const uint32_t* bits, const double* lpq, int64_t ns, int Nx, int Ny,
+                         const int32_t* pos_of_site_dev, const double* Jz_dev, double Bx, double* eloc_dev) {
+    TimedLaunch tl(h, 2);
+    tfim_eloc_kernel<<<(unsigned)((ns + 255) / 256), 256, 0, h->stream>>>(bits, lpq, ns, Nx, Ny, pos_of_site_dev, Jz_dev,
+                                                                          Bx, eloc_dev);
+    RNNWF_HIP(h, hipGetLastError());
+    return 0;
+}
+
+int rnnwf::run_parity_combine(rnnwf_handle* h, const double* a, const double* b, int64_t n, double* out) {
+    parity_combine_kernel<<<(unsigned)((n + 255) / 256), 256, 0, h->stream>>>(a, b, n, out);
+    RNNWF_HIP(h, hipGetLastError());
+    return 0;
+}
+
+int rnnwf::model_pack_image(rnnwf_handle* h, std::vector<char>& img) {
+    if (h->model == RNNWF_MODEL_MDRNN2D) return mdrnn_pack_image(h, img);
+    if (h->model == RNNWF_MODEL_CRNN_U1) return crnn_pack_image(h, img);
+    return prnn_pack_image(h, img);
+}
+
+// -------------------------------------------------------------------------------------------------
+// public compute entry points: dispatch on the model
+// -------------------------------------------------------------------------------------------------
+static bool is_prnn(const rnnwf_handle* h) {
+    return h->model == RNNWF_MODEL_GRU1D || h->model == RNNWF_MODEL_GRU1D_PARITY || h->model == RNNWF_MODEL_GRU1D_F64;
+}
+
+extern "C" int rnnwf_sample(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t step, int64_t offset,
+                            int32_t* out_samples, double* out_log) {
+    if (int rc = check_ready(h)) return rc;
+    if (ns < 1 || !out_samples) return h->fail(RNNWF_ERR_INVALID, "rnnwf_sample: numsamples must be >= 1 and out_samples non-null");
+    if (is_prnn(h)) return prnn_sample(h, ns, seed, step, offset, out_samples, out_log);
+    if (h->model == RNNWF_MODEL_CRNN_U1) return crnn_sample(h, ns, seed, step, offset, out_samples, out_log);
+    return mdrnn_sample(h, ns, seed, step, offset, out_samples, out_log);
+}
+
+extern "C" int rnnwf_log_prob(rnnwf_handle* h, const int32_t* samples, int64_t B, double* out) {
+    if (int rc = check_ready(h)) return rc;
+    if (B < 0 || (B > 0 && (!samples || !out))) return h->fail(RNNWF_ERR_INVALID, "rnnwf_log_prob: bad arguments");
+    if (B == 0) return RNNWF_OK;
+    if (is_prnn(h)) return prnn_log_prob(h, samples, B, out);
+    if (h->model == RNNWF_MODEL_CRNN_U1) return crnn_log_amp(h, samples, B, nullptr, out);
+    return mdrnn_log_prob(h, samples, B, out);
+}
+
+extern "C" int rnnwf_log_amp(rnnwf_handle* h, const int32_t* samples, int64_t B, float* out_re_im) {
+    if (int rc = check_ready(h)) return rc;
+    if (h->model != RNNWF_MODEL_CRNN_U1) return h->fail(RNNWF_ERR_INVALID, "rnnwf_log_amp: only the complex RNN has amplitudes");
+    if (B < 0 || (B > 0 && (!samples || !out_re_im))) return h->fail(RNNWF_ERR_INVALID, "rnnwf_log_amp: bad arguments");
+    if (B == 0) return RNNWF_OK;
+    return crnn_log_amp(h, samples, B, out_re_im, nullptr);
+}
+
+extern "C" int rnnwf_tfim_eloc(rnnwf_handle* h, const int32_t* samples, int64_t ns, const double* Jz, double Bx,
+                               double* eloc, double* log_probs) {
+    if (int rc = check_ready(h)) return rc;
+    if (h->model != RNNWF_MODEL_GRU1D && h->model != RNNWF_MODEL_GRU1D_PARITY)
+        return h->fail(RNNWF_ERR_INVALID, "rnnwf_tfim_eloc: needs a 1D positive RNN handle");
+    if (ns < 1 || !samples || !Jz || !eloc) return h->fail(RNNWF_ERR_INVALID, "rnnwf_tfim_eloc: bad arguments");
+    return prnn_tfim_eloc(h, samples, ns, 1, h->N, Jz, Bx, eloc, log_probs);
+}
+
+extern "C" int rnnwf_tfim2d_eloc(rnnwf_handle* h, const int32_t* samples, int64_t ns, const double* Jz, double Bx,
+                                 double* eloc, double* log_probs) {
+    if (int rc = check_ready(h)) return rc;
+    if (ns < 1 || !samples || !Jz || !eloc) return h->fail(RNNWF_ERR_INVALID, "rnnwf_tfim2d_eloc: bad arguments");
+    if (h->model == RNNWF_MODEL_GRU1D_F64) return prnn_tfim_eloc(h, samples, ns, h->Nx, h->Ny, Jz, Bx, eloc, log_probs);
+    if (h->model == RNNWF_MODEL_MDRNN2D) return mdrnn_tfim_eloc(h, samples, ns, Jz, Bx, eloc, log_probs);
+    return h->fail(RNNWF_ERR_INVALID, "rnnwf_tfim2d_eloc: needs a 2D handle (GRU1D_F64 or MDRNN2D)");
+}
+
+extern "C" int rnnwf_j1j2_eloc(rnnwf_handle* h, const int32_t* samples, int64_t ns, const double* J1, const double* J2,
+                               const double* Bz, int32_t periodic, int32_t marshall, float* eloc, int64_t* ncon) {
+    if (int rc = check_ready(h)) return rc;
+    if (h->model != RNNWF_MODEL_CRNN_U1) return h->fail(RNNWF_ERR_INVALID, "rnnwf_j1j2_eloc: needs a complex RNN handle");
+    if (ns < 1 || !samples || !J1 || !J2 || !Bz || !eloc) return h->fail(RNNWF_ERR_INVALID, "rnnwf_j1j2_eloc: bad arguments");
+    return crnn_j1j2_eloc(h, samples, ns, J1, J2, Bz, periodic, marshall, eloc, ncon);
+}
+
+extern "C" int rnnwf_vmc_step(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t step, int64_t offset,
+                              const double* couplings, int64_t n_couplings, int32_t* out_samples, void* out_eloc,
+                              double* moments) {
+    if (int rc = check_ready(h)) return rc;
+    if (ns < 1 || !couplings || !moments) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_step: bad arguments");
+    if (is_prnn(h)) {
+        if (n_couplings != h->N + 1) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_step: TFIM needs N+1 couplings (Jz, Bx)");
+        return prnn_vmc_step(h, ns, seed, step, offset, couplings, out_samples, (double*)out_eloc, moments);
+    }
+    if (h->model == RNNWF_MODEL_MDRNN2D) {
+        if (n_couplings != h->N + 1) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_step: TFIM needs Nx*Ny+1 couplings (Jz, Bx)");
+        return mdrnn_vmc_step(h, ns, seed, step, offset, couplings, out_samples, (double*)out_eloc, moments);
+    }
+    if (n_couplings != 3 * h->N + 2) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_step: J1J2 needs 3N+2 couplings");
+    return crnn_vmc_step(h, ns, seed, step, offset, couplings, out_samples, (float*)out_eloc, moments);
+}
+
+// -------------------------------------------------------------------------------------------------
+// measurement
+// -------------------------------------------------------------------------------------------------
+extern "C" int rnnwf_timing_enable(rnnwf_handle* h, int32_t on) {
+    if (!h) return RNNWF_ERR_INVALID;
+    h->timing_on = on != 0;
+    return RNNWF_OK;
+}
+
+static int drain_timers(rnnwf_handle* h) {
+    RNNWF_HIP(h, hipSetDevice(h->cfg.device));
+    RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+    for (auto& t : h->timers) {
+        for (auto& ev : t.pending) {
+            float ms = 0.f;
+            RNNWF_HIP(h, hipEventElapsedTime(&ms, ev.first, ev.second));
+            t.total_ms += ms;
+            t.launches += 1;
+            t.pool.push_back(ev);
+        }
+        t.pending.clear();
+    }
+    return 0;
+}
+
+extern "C" int rnnwf_timing_reset(rnnwf_handle* h) {
+    if (!h) return RNNWF_ERR_INVALID;
+    if (int rc = drain_timers(h)) return rc;
+    for (auto& t : h->timers) { t.total_ms = 0.0; t.launches = 0; }
+    h->work[0] = h->work[1] = 0.0;
+    return RNNWF_OK;
+}
+
+extern "C" int rnnwf_timing_get(rnnwf_handle* h, int32_t id, double* total_ms, int64_t* launches, double* work) {
+    if (!h || id < 0 || id > 2) return RNNWF_ERR_INVALID;
+    if (int rc = drain_timers(h)) return rc;
+    if (total_ms) *total_ms = h->timers[id].total_ms;
+    if (launches) *launches = h->timers[id].launches;
+    if (work) { work[0] = h->work[0]; work[1] = h->work[1]; }
+    return RNNWF_OK;
+}
+
+extern "C" int rnnwf_synchronize(rnnwf_handle* h) {
+    if (!h) return RNNWF_ERR_INVALID;
+    RNNWF_HIP(h, hipSetDevice(h->cfg.device));
+    RNNWF_HIP(h, hipDeviceSynchronize());
+    return RNNWF_OK;
+}
+
+extern "C" int rnnwf_device_info(rnnwf_handle* h, int32_t* cu, int32_t* mhz, int64_t* hbm, char* name64) {
+    if (!h) return RNNWF_ERR_INVALID;
+    hipDeviceProp_t prop;
+    RNNWF_HIP(h, hipGetDeviceProperties(&prop, h->cfg.device));
+    if (cu) *cu = prop.multiProcessorCount;
+    if (mhz) *mhz = prop.clockRate / 1000;
+    if (hbm) *hbm = (int64_t)prop.totalGlobalMem;
+    if (name64) { strncpy(name64, prop.name, 63); name64[63] = 0; }
+    return RNNWF_OK;
+}

@@ -1,0 +1,212 @@
+"""GPU parity tests of the positive-RNN path: HIP kernels (through the C ABI) vs the CPU oracle.
+
+Tolerances (fp32 cell, north_star: <E>/N within 1e-4 of the reference):
+  log P(sigma)      : |hip - oracle| <= 2e-6 * N + 2e-6   (both are fp32 evaluations; the oracle in
+                      fp64 differs from the fp32 oracle by about the same amount, asserted below)
+  E_loc             : relative 2e-5 per sample
+  samples           : identical rows except near-ties |u - p0| < 1e-5 (rare, counted)
+"""
+import numpy as np
+import pytest
+
+from conftest import all_configs, golden_params
+from oracle import estimators as E
+from oracle import models as M
+from oracle import philox
+from rnnwavefunctions_amd import params as P
+
+pytestmark = pytest.mark.gpu
+
+SCOPE = "RNNwavefunction"
+
+
+def make_wf(model, N, H, prm, ny=1):
+    from rnnwavefunctions_amd import _lib
+    wf = _lib.NativeWavefunction(model, N, ny, (H,))
+    wf.set_params(prm, scope=SCOPE)
+    return wf
+
+
+def trained_like(H, seed, dtype=np.float32, heads=("wf_dense",)):
+    return P.randomize_biases(P.scale_kernels(P.init_gru_params([H], seed=seed, dtype=dtype, heads=heads), 2.0), seed + 1)
+
+
+@pytest.mark.parametrize("N,H,B", [(10, 12, 37), (33, 20, 200), (40, 36, 64), (70, 50, 130), (20, 64, 48), (24, 100, 40)])
+def test_log_prob_matches_oracle(N, H, B):
+    from rnnwavefunctions_amd import _lib
+    prm = trained_like(H, seed=H)
+    wf = make_wf(_lib.MODEL_GRU1D, N, H, prm)
+    s = np.random.RandomState(N).randint(0, 2, (B, N)).astype(np.int32)
+    got = wf.log_prob(s)
+    ref = M.prnn_log_probability(prm, s)
+    prm64 = {k: v.astype(np.float64) for k, v in prm.items()}
+    ref64 = M.prnn_log_probability(prm64, s, dtype=np.float64)
+    err = np.abs(got - ref).max()
+    err64 = np.abs(got - ref64).max()
+    oracle_gap = np.abs(ref - ref64).max()
+    print("N=%d H=%d: |hip-oracle32|=%.2e |hip-oracle64|=%.2e |oracle32-oracle64|=%.2e" % (N, H, err, err64, oracle_gap))
+    assert err <= 2e-6 * N + 2e-6
+    assert err64 <= 2e-6 * N + 2e-6
+
+
+def test_normalisation_on_gpu():
+    from rnnwavefunctions_amd import _lib
+    N, H = 12, 20
+    prm = trained_like(H, seed=3)
+    wf = make_wf(_lib.MODEL_GRU1D, N, H, prm)
+    lp = wf.log_prob(all_configs(N))
+    assert abs(np.exp(lp).sum() - 1) < 2e-5
+
+
+def test_empty_and_bad_inputs():
+    from rnnwavefunctions_amd import _lib
+    prm = trained_like(10, seed=1)
+    wf = make_wf(_lib.MODEL_GRU1D, 8, 10, prm)
+    assert wf.log_prob(np.zeros((0, 8), dtype=np.int32)).shape == (0,)
+    with pytest.raises(ValueError):
+        wf.log_prob(np.zeros((4, 9), dtype=np.int32))
+    with pytest.raises(ValueError):
+        wf.set_params({"wf_dense/bias": np.zeros(3, dtype=np.float32)})
+    with pytest.raises(ValueError):
+        _lib.NativeWavefunction(_lib.MODEL_GRU1D, 8, 1, (10, 10))      # multi-layer: loud refusal
+    wf2 = _lib.NativeWavefunction(_lib.MODEL_GRU1D, 8, 1, (10,))
+    with pytest.raises(_lib.RnnwfError):
+        wf2.log_prob(np.zeros((4, 8), dtype=np.int32))                   # parameters never committed
+
+
+def test_tfim_eloc_matches_reference_golden(golden_estimators):
+    """G4a: the reference's own Ising_local_energies driven by the oracle log-probs (N=10, 2 chunks)."""
+    from rnnwavefunctions_amd import _lib
+    g = golden_estimators
+    prm = golden_params(g, "g4a")
+    N = g["g4a_samples"].shape[1]
+    wf = make_wf(_lib.MODEL_GRU1D, N, 12, prm)
+    ns = g["g4a_samples"].shape[0]
+    lp = np.zeros((N + 1) * ns)
+    e = wf.tfim_eloc(g["g4a_samples"], g["g4a_Jz"], float(g["g4a_Bx"]), log_probs=lp)
+    print("G4a: max|lp diff|=%.2e  max rel E diff=%.2e" % (np.abs(lp - g["g4a_logp"]).max(),
+                                                        np.abs(e / g["g4a_eloc"] - 1).max()))
+    assert np.allclose(lp, g["g4a_logp"], rtol=0, atol=3e-5)
+    assert np.allclose(e, g["g4a_eloc"], rtol=2e-5, atol=2e-5)
+    e0 = wf.tfim_eloc(g["g4a_samples"][:50], g["g4a_Jz"], 0.0)
+    assert np.allclose(e0, g["g4a_eloc_bx0"], atol=1e-12)          # Bx = 0: diagonal only, exact
+
+
+@pytest.mark.parametrize("N,H,ns", [(33, 20, 50), (65, 50, 21), (16, 100, 17)])
+def test_tfim_eloc_fused_equals_reference_formulation(N, H, ns):
+    from rnnwavefunctions_amd import _lib
+    prm = trained_like(H, seed=N)
+    wf = make_wf(_lib.MODEL_GRU1D, N, H, prm)
+    rng = np.random.RandomState(5)
+    s = rng.randint(0, 2, (ns, N)).astype(np.int32)
+    Jz = 1.0 + 0.1 * rng.standard_normal(N)
+    lp = np.zeros((N + 1) * ns)
+    e = wf.tfim_eloc(s, Jz, 1.3, log_probs=lp)
+    e_ref, lp_ref = E.ising_local_energies(Jz, 1.3, s, lambda x: M.prnn_log_probability(prm, x), return_log_probs=True)
+    print("N=%d H=%d: max|lp diff|=%.2e max rel E diff=%.2e" % (N, H, np.abs(lp - lp_ref.ravel()).max(),
+                                                               np.abs(e / e_ref - 1).max()))
+    assert np.allclose(lp, lp_ref.ravel(), rtol=0, atol=2e-6 * N + 2e-6)
+    assert np.allclose(e, e_ref, rtol=2e-5)
+    # the same numbers through the un-fused route: every flipped configuration scored from site 0
+    queue = np.repeat(s[None], N + 1, axis=0)
+    for i in range(N):
+        queue[i + 1, :, i] ^= 1
+    lp_full = wf.log_prob(queue.reshape(-1, N))
+    assert np.allclose(lp, lp_full, rtol=0, atol=1e-9 * N + 1e-7)   # prefix reuse changes nothing but rounding order
+
+
+def test_sampling_matches_oracle_stream():
+    from rnnwavefunctions_amd import _lib
+    N, H, ns = 40, 20, 1000
+    prm = trained_like(H, seed=9)
+    wf = make_wf(_lib.MODEL_GRU1D, N, H, prm)
+    s, lg = wf.sample(ns, seed=111, step=7, sample_offset=0, return_log=True)
+    u = philox.uniforms(111, 7, 0, ns, N)
+    s_ref, lg_ref = M.prnn_sample(prm, N, u)
+    bad = np.where((s != s_ref).any(axis=1))[0]
+    print("sampler: %d of %d rows differ from the oracle" % (len(bad), ns))
+    assert len(bad) <= 2
+    probs = M.prnn_site_probs(prm, s_ref)
+    for b in bad:                                                   # a differing row must be a near-tie
+        n0 = np.argmax(s[b] != s_ref[b])
+        assert abs(u[b, n0] - probs[b, n0, 0]) < 1e-5
+    good = np.setdiff1d(np.arange(ns), bad)
+    assert np.allclose(lg[good], lg_ref[good], rtol=0, atol=2e-6 * N + 2e-6)
+    # shard invariance: two half batches with the right sample_offset reproduce the full batch
+    a = wf.sample(600, seed=111, step=7, sample_offset=0)
+    b = wf.sample(400, seed=111, step=7, sample_offset=600)
+    assert np.array_equal(np.concatenate([a, b]), s)
+    # a different step gives a different batch
+    assert not np.array_equal(wf.sample(ns, seed=111, step=8), s)
+
+
+def test_parity_symmetric_model():
+    from rnnwavefunctions_amd import _lib
+    N, H, ns = 12, 20, 40
+    prm = trained_like(H, seed=4)
+    wf = make_wf(_lib.MODEL_GRU1D_PARITY, N, H, prm)
+    s = np.random.RandomState(1).randint(0, 2, (ns, N)).astype(np.int32)
+    lp = wf.log_prob(s)
+    ref = M.prnn_paritysym_log_probability(prm, s)
+    assert np.allclose(lp, ref, rtol=0, atol=5e-5)
+    assert np.allclose(lp, wf.log_prob(s[:, ::-1]), atol=1e-12)
+    Jz = np.ones(N)
+    e = wf.tfim_eloc(s, Jz, 1.0)
+    e_ref = E.ising_local_energies(Jz, 1.0, s, lambda x: M.prnn_paritysym_log_probability(prm, x))
+    assert np.allclose(e, e_ref, rtol=5e-5)
+
+
+def test_gru_f64_on_2d_lattice_matches_reference_golden(golden_estimators):
+    """G4c: 2DTFIM_1DRNN estimator (reference code) driven by the f64 oracle."""
+    from rnnwavefunctions_amd import _lib
+    g = golden_estimators
+    prm = golden_params(g, "g4c")
+    Nx, Ny = (int(v) for v in g["g4c_shape"])
+    wf = make_wf(_lib.MODEL_GRU1D_F64, Nx, 7, prm, ny=Ny)
+    s = g["g4c_samples"]
+    lp = np.zeros((Nx * Ny + 1) * s.shape[0])
+    e = wf.tfim_eloc(s, g["g4c_Jz"], float(g["g4c_Bx"]), log_probs=lp)
+    print("G4c: max|lp diff|=%.2e" % np.abs(lp - g["g4c_logp"]).max())
+    assert np.allclose(lp, g["g4c_logp"], rtol=0, atol=1e-10)
+    assert np.allclose(e, g["g4c_eloc"], rtol=1e-10)
+
+
+def test_vmc_step_is_sample_plus_eloc_plus_moments():
+    from rnnwavefunctions_amd import _lib
+    N, H, ns = 30, 50, 333
+    prm = trained_like(H, seed=2)
+    wf = make_wf(_lib.MODEL_GRU1D, N, H, prm)
+    Jz = np.ones(N)
+    out = wf.vmc_step(ns, seed=5, step=3, couplings=np.append(Jz, 1.0), want_samples=True, want_eloc=True)
+    assert np.array_equal(out["samples"], wf.sample(ns, seed=5, step=3))
+    e = wf.tfim_eloc(out["samples"], Jz, 1.0)
+    assert np.allclose(out["eloc"], e, rtol=1e-12)
+    m = out["moments"]
+    assert m[2] == ns
+    assert np.isclose(m[0] / ns, e.mean(), rtol=1e-12)
+    assert np.isclose(m[1] / ns - (m[0] / ns) ** 2, e.var(), rtol=1e-9)
+    assert wf.allreduce_moments(m).tolist() == m.tolist()           # single rank: identity
+
+
+def test_headline_config_energy_per_site_within_north_star():
+    """BASELINE config 2 (N=80, h=50, ns=10000): <E>/N of HIP vs the oracle on the same sample matrix
+    (oracle on a 64-sample subset: 81*64 chains), plus size-independent properties on the full batch."""
+    from rnnwavefunctions_amd import _lib
+    N, H, ns = 80, 50, 10000
+    prm = P.init_gru_params([H], seed=111)
+    wf = make_wf(_lib.MODEL_GRU1D, N, H, prm)
+    Jz = np.ones(N)
+    out = wf.vmc_step(ns, seed=111, step=0, couplings=np.append(Jz, 1.0), want_samples=True, want_eloc=True)
+    s, e = out["samples"], out["eloc"]
+    assert s.shape == (ns, N) and set(np.unique(s)) <= {0, 1}
+    assert np.all(np.isfinite(e))
+    sub = np.arange(0, ns, ns // 64)[:64]
+    e_ref = E.ising_local_energies(Jz, 1.0, s[sub], lambda x: M.prnn_log_probability(prm, x))
+    per_site = np.abs(e[sub] - e_ref).max() / N
+    print("cfg2: max |E_loc diff| / N over 64 samples = %.2e ; mean diff / N = %.2e" %
+          (per_site, abs(e[sub].mean() - e_ref.mean()) / N))
+    assert per_site < 1e-5
+    assert abs(e[sub].mean() - e_ref.mean()) / N < 1e-5          # north_star asks for 1e-4
+    # off-diagonal part is a sum of N positive terms times -Bx: E_loc <= diagonal energy
+    diag = -(np.where(s[:, :-1] == s[:, 1:], 1.0, -1.0)).sum(axis=1)
+    assert np.all(e < diag)
