@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py - samples*sites/sec of the VMC hot path (autoregressive sample + local energy) on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: `numsamples` configurations are drawn by the
+RNN wave function and their local energies and energy moments are computed, everything resident in
+HBM (BASELINE.json metric).  The headline workload (N=1) is BASELINE config 2:
+1D TFIM, pRNN, N=80, num_units=50, numsamples=10000.  With several GPUs every rank runs the same
+per-GPU batch (weak scaling) on its own shard of global sample indices and the moments are summed
+with ONE RCCL all-reduce per step.  torch.distributed (gloo, CPU) is used only as the launcher's
+rendezvous/barrier; no torch.cuda object is ever created - the compute path is ctypes -> C ABI -> HIP.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (model, N or (Nx,Ny), num_units, numsamples per GPU, couplings builder, description)
+    "cfg2": dict(kind="tfim1d", N=80, H=50, ns=10000, Bx=1.0,
+                 desc="1DTFIM pRNN N=80 num_units=50 numsamples=10000 (BASELINE config 2)"),
+    "cfg1": dict(kind="tfim1d", N=20, H=20, ns=500, Bx=1.0,
+                 desc="1DTFIM pRNN N=20 num_units=20 numsamples=500 (BASELINE config 1)"),
+    "cfg5": dict(kind="tfim1d", N=200, H=100, ns=32768, Bx=1.0,
+                 desc="1DTFIM pRNN N=200 num_units=100 numsamples=32768 per GPU (BASELINE config 5 shard)"),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 MFMA = vector peak
+
+
+def f_cell_gru(h):
+    """Dense flops of one GRU cell evaluation incl. Dense(2): 6h^2 + 16h."""
+    return 6 * h * h + 16 * h
+
+
+def make_wavefunction(wl, device):
+    from rnnwavefunctions_amd import _lib, params as P
+    prm = P.init_gru_params([wl["H"]], seed=111)
+    wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D, wl["N"], 1, (wl["H"],), device=device)
+    wf.set_params(prm, scope="RNNwavefunction")
+    couplings = np.append(np.ones(wl["N"]), wl["Bx"])
+    return wf, prm, couplings
+
+
+def cpu_baseline(wl, prm, target_seconds=15.0):
+    """The reference formulation (queue of N+1 configurations per sample, every one scored from
+    site 0 in <=25000-row chunks) timed on this box's host cores with the C restatement in oracle/."""
+    from oracle import cport
+    N, ns_full = wl["N"], wl["ns"]
+    threads = cport.max_threads()
+    rng = np.random.RandomState(0)
+    probe = min(64, ns_full)
+    s = rng.randint(0, 2, (probe, N)).astype(np.int32)
+    cport.ising_local_energies(prm, np.ones(N), wl["Bx"], s[:8], nthreads=threads)   # warm-up (builds the .so)
+    t0 = time.perf_counter()
+    cport.ising_local_energies(prm, np.ones(N), wl["Bx"], s, nthreads=threads)
+    rate = probe / max(time.perf_counter() - t0, 1e-6)
+    ns_cpu = int(min(ns_full, max(probe, rate * target_seconds)))
+    s = rng.randint(0, 2, (ns_cpu, N)).astype(np.int32)
+    t0 = time.perf_counter()
+    cport.ising_local_energies(prm, np.ones(N), wl["Bx"], s, nthreads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": ns_cpu * N / dt, "unit": "samples*sites/s", "cores": threads, "kind": "port",
+            "sample": "%d of %d samples of the same workload, reference formulation ((N+1)*ns chains from site 0, "
+                      "<=25000-row chunks), C/OpenMP restatement oracle/c/rnnwf_oracle.c, %.1f s" % (ns_cpu, ns_full, dt)}
+
+
+def load_traffic(workload):
+    """HBM bytes per flip-kernel launch measured with rocprofv3 --pmc (separate pass), if recorded."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get(workload)
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--numsamples", type=int, default=0, help="per-GPU batch override")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world != 1:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    wl = dict(WORKLOADS[args.workload])
+    if args.numsamples:
+        wl["ns"] = args.numsamples
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist      # launcher plumbing only: gloo rendezvous + barrier on CPU
+        dist.init_process_group(backend="gloo")
+
+    wf, prm, couplings = make_wavefunction(wl, device=local_rank)
+    if world > 1:
+        box = [wf.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        wf.comm_init(box[0], rank, world)
+
+    ns, N = wl["ns"], wl["N"]
+    offset = rank * ns                       # global sample indices of this shard
+
+    def step(it):
+        out = wf.vmc_step(ns, seed=111, step=it, couplings=couplings, sample_offset=offset)
+        m = out["moments"]
+        if world > 1:
+            m = wf.allreduce_moments(m)       # ONE RCCL all-reduce: (sum E, sum E^2, n, sum Im E)
+        return m
+
+    def barrier():
+        wf.synchronize()
+        if dist is not None:
+            dist.barrier()
+        wf.synchronize()
+
+    for it in range(args.warmup):
+        step(it)
+    wf.timing_enable(True)
+    wf.timing_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        m = step(args.warmup + it)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+
+    flip = wf.timing_get(1)
+    base = wf.timing_get(0)
+    asm = wf.timing_get(2)
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * ns * N / (dt / args.steps)
+        mean_e = m[0] / m[2]
+        var_e = m[1] / m[2] - mean_e ** 2
+        launches = max(flip["launches"], 1)
+        alg_flops_per_launch = flip["cell_evals"] / launches * f_cell_gru(wl["H"])
+        flip_ms = flip["total_ms"] / launches
+        achieved = alg_flops_per_launch / (flip_ms * 1e-3) / 1e12 if flip_ms > 0 else 0.0
+        rec = {
+            "metric": "samples*sites/sec (autoregressive sample+local_energy), 1D TFIM N=80 nh=50"
+                      if args.workload == "cfg2" else "samples*sites/sec (autoregressive sample+local_energy)",
+            "value": value, "unit": "samples*sites/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl["desc"], "numsamples_per_gpu": ns, "global_numsamples": ns * world,
+                       "sites": N, "num_units": wl["H"], "parallelism": "dp%d (sample shards, 1 RCCL all-reduce/step)" % world,
+                       "weights": "glorot-uniform RandomState(111), gate bias 1", "mean_E": mean_e, "var_E": var_e},
+            "roofline": {"bound": "mfma", "kernel": "prnn_flip_kernel", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": load_traffic(args.workload),
+                         "algorithmic_flops_per_launch": alg_flops_per_launch,
+                         "mfma_flops_issued_per_launch": flip["mfma_flops"] / launches,
+                         "avg_launch_ms": flip_ms,
+                         "base_pass_ms": base["total_ms"] / max(base["launches"], 1),
+                         "assembly_ms": asm["total_ms"] / max(asm["launches"], 1) * (asm["launches"] / launches)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            rec["cpu_baseline"] = cpu_baseline(wl, prm)
+        else:
+            rec["cpu_baseline"] = None
+        print(json.dumps(rec))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
