@@ -1,0 +1,3 @@
+"""Hot-path part of 2DTFIM_1DRNN/Training1DRNN_2DTFIM.py: Ising2D_local_energies (:13-81)."""
+from ..estimators import Ising2D_local_energies  # noqa: F401
+from .RNNwavefunction import RNNwavefunction  # noqa: F401

@@ -1,10 +1,248 @@
-// crnn.hip - complex GRU RNN with U(1) mask (J1J2/ComplexRNNwavefunction.py) - placeholder until the
-// kernels land: every entry point fails loudly.
+// crnn.hip - host side of the complex GRU RNN wave function with the U(1) mask (model CRNN_U1):
+// sample / log_amplitude / fused J1-J2 local energies / fused VMC step.
+#include <algorithm>
+
+#include "crnn_kernels.h"
 #include "models.h"
+#include "pack.h"
+
 using namespace rnnwf;
-#define NI(h) return (h)->fail(RNNWF_ERR_INVALID, "%s: complex-RNN kernels not built yet", __func__)
-int rnnwf::crnn_pack_image(rnnwf_handle* h, std::vector<char>&) { NI(h); }
-int rnnwf::crnn_sample(rnnwf_handle* h, int64_t, uint64_t, uint64_t, int64_t, int32_t*, double*) { NI(h); }
-int rnnwf::crnn_log_amp(rnnwf_handle* h, const int32_t*, int64_t, float*, double*) { NI(h); }
-int rnnwf::crnn_j1j2_eloc(rnnwf_handle* h, const int32_t*, int64_t, const double*, const double*, const double*, int, int, float*, int64_t*) { NI(h); }
-int rnnwf::crnn_vmc_step(rnnwf_handle* h, int64_t, uint64_t, uint64_t, int64_t, const double*, int32_t*, float*, double*) { NI(h); }
+
+namespace {
+
+constexpr size_t kHckBudget = (size_t)48 << 30;
+constexpr int64_t kChunk = (int64_t)1 << 20;
+
+template <int NFULL, int WAVES>
+struct CLaunch {
+    using L = GruLayout<float, NFULL, 4>;
+    static int blocks_per_cu(rnnwf_handle* h, const void* fn, int* out) {
+        RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES));
+        int nb = 0;
+        RNNWF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, WAVES * 64, L::BYTES));
+        *out = std::max(nb, 1);
+        return 0;
+    }
+    static int base(rnnwf_handle* h, const CrnnArgs& a) {
+        static int bpc = 0;
+        const void* fn = (const void*)crnn_base_kernel<NFULL, WAVES>;
+        if (!bpc) if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
+        const int64_t need = (a.nsb + WAVES - 1) / WAVES;
+        const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
+        TimedLaunch tl(h, 0);
+        crnn_base_kernel<NFULL, WAVES><<<grid, WAVES * 64, L::BYTES, h->stream>>>(a);
+        RNNWF_HIP(h, hipGetLastError());
+        return 0;
+    }
+    static int swap(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles) {
+        static int bpc = 0;
+        const void* fn = (const void*)crnn_swap_kernel<NFULL, WAVES>;
+        if (!bpc) if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
+        // the tile count lives on the device: launch the persistent grid, bounded by the worst case
+        const int64_t need = (max_tiles + WAVES - 1) / WAVES;
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
+        TimedLaunch tl(h, 1);
+        crnn_swap_kernel<NFULL, WAVES><<<grid, WAVES * 64, L::BYTES, h->stream>>>(a);
+        RNNWF_HIP(h, hipGetLastError());
+        return 0;
+    }
+    static std::vector<char> pack(const rnnwf_handle* h) { return pack_gru_image<float, NFULL, 4>(h); }
+    static size_t hck_bytes_per_block() { return (size_t)L::KT * 64 * sizeof(float); }
+};
+
+#define CRNN_DISPATCH(h, EXPR)                                  \
+    do {                                                        \
+        switch ((h)->NFULL) {                                   \
+            case 1: { using K = CLaunch<1, 4>; EXPR; }          \
+            case 2: { using K = CLaunch<2, 4>; EXPR; }          \
+            case 3: { using K = CLaunch<3, 4>; EXPR; }          \
+            case 4: { using K = CLaunch<4, 4>; EXPR; }          \
+            case 6: { using K = CLaunch<6, 12>; EXPR; }         \
+        }                                                       \
+    } while (0)
+
+int launch_base(rnnwf_handle* h, const CrnnArgs& a) {
+    CRNN_DISPATCH(h, return K::base(h, a));
+    return h->fail(RNNWF_ERR_INVALID, "no cRNN kernel for NFULL=%d", h->NFULL);
+}
+int launch_swap(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles) {
+    CRNN_DISPATCH(h, return K::swap(h, a, max_tiles));
+    return h->fail(RNNWF_ERR_INVALID, "no cRNN kernel for NFULL=%d", h->NFULL);
+}
+size_t hck_bytes_per_block(rnnwf_handle* h) {
+    CRNN_DISPATCH(h, return K::hck_bytes_per_block());
+    return 0;
+}
+
+CrnnArgs base_args(rnnwf_handle* h, int64_t ns) {
+    CrnnArgs a{};
+    a.wimg = h->wimg.p;
+    a.N = h->N;
+    a.ns = ns;
+    a.nsb = (ns + kChains - 1) / kChains;
+    return a;
+}
+
+int64_t max_chains_per_pass(rnnwf_handle* h) {
+    const size_t per_block = (size_t)std::max(h->N - 1, 1) * hck_bytes_per_block(h);
+    return std::max<int64_t>(1, (int64_t)(kHckBudget / per_block)) * kChains;
+}
+
+// J1-J2 local energies of the ns chains whose packed spins are in h->bits (drawn here when `sampling`).
+// couplings_dev: J1 (N), J2 (N), Bz (N).  Leaves complex64 E_loc in h->eloc; *ncon_host (optional) receives
+// the number of scored configurations after a stream sync.
+int j1j2_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, uint64_t step, int64_t offset,
+                   const double* couplings_dev, int periodic, int marshall) {
+    const int N = h->N;
+    const int64_t nsb = (ns + kChains - 1) / kChains;
+    const int64_t cap = 4 * ns;
+    if (int rc = ensure(h, h->hck, (size_t)std::max(N - 1, 1) * nsb * hck_bytes_per_block(h))) return rc;
+    if (int rc = ensure(h, h->cbase, (size_t)N * ns * sizeof(double2))) return rc;
+    if (int rc = ensure(h, h->cout, (size_t)ns * (sizeof(double2) + sizeof(double)))) return rc;
+    if (int rc = ensure(h, h->tile_count, (size_t)(2 * N + 8) * 4 + 64)) return rc;
+    if (int rc = ensure(h, h->tiles, (size_t)N * cap * sizeof(SwapItem))) return rc;
+    if (int rc = ensure(h, h->lpq, (size_t)ns * 2 * N * sizeof(double2))) return rc;
+    if (int rc = ensure(h, h->eloc, (size_t)ns * sizeof(float2))) return rc;
+
+    double2* tot = (double2*)h->cout.p;
+    double* diag = (double*)((char*)h->cout.p + (size_t)ns * sizeof(double2));
+    int32_t* cnt = (int32_t*)h->tile_count.p;
+    int32_t* tile_start = cnt + N;
+    int64_t* total_items = (int64_t*)((char*)h->tile_count.p + (((size_t)(2 * N + 1) * 4 + 15) / 16) * 16);
+
+    CrnnArgs a = base_args(h, ns);
+    a.bits = (uint32_t*)h->bits.p;
+    a.hck = h->hck.p;
+    a.cb = (double2*)h->cbase.p;
+    a.tot = tot;
+    a.sampling = sampling ? 1 : 0;
+    a.seed = seed; a.step = step; a.sample_offset = offset;
+    if (int rc = launch_base(h, a)) return rc;
+
+    RNNWF_HIP(h, hipMemsetAsync(cnt, 0, (size_t)N * 4, h->stream));
+    J1J2Args e{};
+    e.bits = (const uint32_t*)h->bits.p;
+    e.ns = ns; e.N = N;
+    e.J1 = couplings_dev; e.J2 = couplings_dev + N; e.Bz = couplings_dev + 2 * N;
+    e.periodic = periodic; e.marshall = marshall;
+    e.cnt = cnt; e.items = (SwapItem*)h->tiles.p; e.cap = cap;
+    e.contrib = (double2*)h->lpq.p; e.diag = diag;
+    {
+        TimedLaunch tl(h, 2);
+        dim3 grid((unsigned)((ns + 255) / 256), (unsigned)(2 * N));
+        j1j2_enumerate_kernel<<<grid, 256, 0, h->stream>>>(e);
+        RNNWF_HIP(h, hipGetLastError());
+        j1j2_tile_scan_kernel<<<1, 64, 0, h->stream>>>(cnt, N, tile_start, total_items);
+        RNNWF_HIP(h, hipGetLastError());
+        // lands in pinned[64..88) at the caller's next stream sync (see collect_totals)
+        RNNWF_HIP(h, hipMemcpyAsync((char*)h->pinned + 64, total_items, 24, hipMemcpyDeviceToHost, h->stream));
+    }
+    a.sampling = 0;
+    a.tile_start = tile_start;
+    a.cnt = cnt;
+    a.items = (const SwapItem*)h->tiles.p;
+    a.cap = cap;
+    a.contrib = (double2*)h->lpq.p;
+    const int64_t max_tiles = (int64_t)N * ((2 * ns + kChains - 1) / kChains + 2);
+    if (int rc = launch_swap(h, a, max_tiles)) return rc;
+    {
+        TimedLaunch tl(h, 2);
+        j1j2_eloc_kernel<<<(unsigned)((ns + 255) / 256), 256, 0, h->stream>>>((const double2*)h->lpq.p, diag, ns, N,
+                                                                            (float2*)h->eloc.p);
+        RNNWF_HIP(h, hipGetLastError());
+    }
+    return 0;
+}
+
+// after a stream sync: number of scored configurations (the reference's len_sigmas) and work counters
+int64_t collect_totals(rnnwf_handle* h, int64_t ns) {
+    const int64_t* t = (const int64_t*)((char*)h->pinned + 64);
+    h->work[0] += (double)t[1];
+    h->work[1] += (double)t[2] * (double)(3 * h->NFULL + 1) * (4 * h->NFULL + 1) * 2048.0;
+    return t[0] + ns;   // + one diagonal configuration per sample
+}
+
+}  // namespace
+
+int rnnwf::crnn_pack_image(rnnwf_handle* h, std::vector<char>& img) {
+    CRNN_DISPATCH(h, { img = K::pack(h); return 0; });
+    return h->fail(RNNWF_ERR_INVALID, "no cRNN kernel for NFULL=%d", h->NFULL);
+}
+
+int rnnwf::crnn_sample(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t step, int64_t offset, int32_t* out,
+                       double* out_log) {
+    const int W = (h->N + 31) / 32;
+    if (int rc = ensure(h, h->bits, (size_t)W * ns * 4)) return rc;
+    if (int rc = ensure(h, h->out_lp, (size_t)ns * 8)) return rc;
+    CrnnArgs a = base_args(h, ns);
+    a.bits = (uint32_t*)h->bits.p;
+    a.out_logp = (double*)h->out_lp.p;
+    a.sampling = 1;
+    a.seed = seed; a.step = step; a.sample_offset = offset;
+    if (int rc = launch_base(h, a)) return rc;
+    if (int rc = unpack_and_download(h, h->bits, ns, out, nullptr)) return rc;
+    if (out_log) RNNWF_HIP(h, hipMemcpyAsync(out_log, h->out_lp.p, (size_t)ns * 8, hipMemcpyDeviceToHost, h->stream));
+    RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+    return RNNWF_OK;
+}
+
+int rnnwf::crnn_log_amp(rnnwf_handle* h, const int32_t* samples, int64_t B, float* out_re_im, double* out_logp) {
+    const int N = h->N;
+    for (int64_t off = 0; off < B; off += kChunk) {
+        const int64_t nb = std::min(kChunk, B - off);
+        if (int rc = upload_and_pack(h, samples + off * N, nb, h->bits, 0, nullptr)) return rc;
+        if (int rc = ensure(h, h->camp, (size_t)nb * sizeof(float2))) return rc;
+        if (int rc = ensure(h, h->out_lp, (size_t)nb * 8)) return rc;
+        CrnnArgs a = base_args(h, nb);
+        a.bits = (uint32_t*)h->bits.p;
+        a.out_amp = (float2*)h->camp.p;
+        a.out_logp = (double*)h->out_lp.p;
+        if (int rc = launch_base(h, a)) return rc;
+        if (out_re_im)
+            RNNWF_HIP(h, hipMemcpyAsync(out_re_im + 2 * off, h->camp.p, (size_t)nb * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
+        if (out_logp)
+            RNNWF_HIP(h, hipMemcpyAsync(out_logp + off, h->out_lp.p, (size_t)nb * 8, hipMemcpyDeviceToHost, h->stream));
+        RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    return RNNWF_OK;
+}
+
+int rnnwf::crnn_j1j2_eloc(rnnwf_handle* h, const int32_t* samples, int64_t ns, const double* J1, const double* J2,
+                          const double* Bz, int periodic, int marshall, float* eloc, int64_t* ncon) {
+    const int N = h->N;
+    if (int rc = ensure(h, h->coupl, (size_t)3 * N * 8)) return rc;
+    RNNWF_HIP(h, hipMemcpyAsync(h->coupl.p, J1, (size_t)N * 8, hipMemcpyHostToDevice, h->stream));
+    RNNWF_HIP(h, hipMemcpyAsync((double*)h->coupl.p + N, J2, (size_t)N * 8, hipMemcpyHostToDevice, h->stream));
+    RNNWF_HIP(h, hipMemcpyAsync((double*)h->coupl.p + 2 * N, Bz, (size_t)N * 8, hipMemcpyHostToDevice, h->stream));
+    const int64_t chunk = max_chains_per_pass(h);
+    int64_t total = 0;
+    for (int64_t off = 0; off < ns; off += chunk) {
+        const int64_t nb = std::min(chunk, ns - off);
+        if (int rc = upload_and_pack(h, samples + off * N, nb, h->bits, 0, nullptr)) return rc;
+        if (int rc = j1j2_on_device(h, nb, false, 0, 0, 0, (const double*)h->coupl.p, periodic, marshall)) return rc;
+        RNNWF_HIP(h, hipMemcpyAsync(eloc + 2 * off, h->eloc.p, (size_t)nb * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
+        RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+        total += collect_totals(h, nb);
+    }
+    if (ncon) *ncon = total;
+    return RNNWF_OK;
+}
+
+int rnnwf::crnn_vmc_step(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t step, int64_t offset,
+                         const double* couplings, int32_t* out_samples, float* out_eloc, double* moments) {
+    const int N = h->N;
+    const int W = (N + 31) / 32;
+    if (ns > max_chains_per_pass(h))
+        return h->fail(RNNWF_ERR_NOMEM, "rnnwf_vmc_step: %lld samples exceed the checkpoint budget; split the batch",
+                       (long long)ns);
+    if (int rc = ensure(h, h->bits, (size_t)W * ns * 4)) return rc;
+    if (int rc = ensure(h, h->coupl, (size_t)3 * N * 8)) return rc;
+    RNNWF_HIP(h, hipMemcpyAsync(h->coupl.p, couplings, (size_t)3 * N * 8, hipMemcpyHostToDevice, h->stream));
+    const int periodic = couplings[3 * N] != 0.0, marshall = couplings[3 * N + 1] != 0.0;
+    if (int rc = j1j2_on_device(h, ns, true, seed, step, offset, (const double*)h->coupl.p, periodic, marshall)) return rc;
+    if (out_samples) if (int rc = unpack_and_download(h, h->bits, ns, out_samples, nullptr)) return rc;
+    if (out_eloc) RNNWF_HIP(h, hipMemcpyAsync(out_eloc, h->eloc.p, (size_t)ns * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
+    if (int rc = run_moments(h, h->eloc.p, ns, true, moments)) return rc;   // syncs the stream
+    collect_totals(h, ns);
+    return RNNWF_OK;
+}

@@ -1,0 +1,291 @@
+// crnn_kernels.h - complex RNN wave function with the U(1) zero-magnetisation mask and the J1-J2
+// local-energy path (J1J2/ComplexRNNwavefunction.py, J1J2/TrainingRNN_J1J2.py).
+//
+//   crnn_base_kernel    : masked ancestral sampling (:45-103) or teacher-forced log-amplitude (:105-169),
+//                         16 chains per wave; optional checkpoints of the hidden state after every site and
+//                         "swap base" values  cb[n][s] = sum_{m<n} log psi_m(s_m) + log psi_n(1 - s_n).
+//   j1j2_enumerate_kernel: connected configurations of J1J2MatrixElements (TrainingRNN_J1J2.py:12-93) on the
+//                         device: one item per anti-aligned bond, compacted per first-changed site `lo` with a
+//                         wavefront ballot + one atomic per wave; also the diagonal matrix element.
+//   j1j2_tile_scan_kernel: prefix sum of the per-`lo` tile counts (tiles of 16 items, longest chains first).
+//   crnn_swap_kernel    : for every item re-evaluates sites lo+1..N-1 of the swapped configuration starting
+//                         from the checkpoint of site lo, and writes  H_k exp(log psi(s') - log psi(s)).
+//   j1j2_eloc_kernel    : E_loc[s] = diag + sum_k contributions, in the reference's bond order (:277-279).
+#pragma once
+#include "gru_core.h"
+
+namespace rnnwf {
+
+struct SwapItem {      // 16 bytes
+    int32_t s;         // sample index within the launch
+    int32_t hi;        // second changed site (> lo)
+    int32_t slot;      // bond slot in the per-sample contribution row (J1 bond a -> a, J2 bond a -> N + a)
+    float coef;        // matrix element  +-J/2
+};
+
+struct CrnnArgs {
+    const void* wimg;
+    int32_t N;
+    int64_t ns, nsb;
+    uint32_t* bits;
+    void* hck;                 // [N-1][nsb][KT][64] float, nullptr: no checkpoints
+    double2* cb;               // [N][ns] swap base, nullptr: none
+    double2* tot;              // [ns] log psi(s) (re, im) in f64
+    float2* out_amp;           // [ns] complex64 log-amplitude (may be nullptr)
+    double* out_logp;          // [ns] 2 Re log psi (may be nullptr)
+    uint64_t seed, step;
+    int64_t sample_offset;
+    int32_t sampling;
+    // swap pass
+    const int32_t* tile_start; // [N+1]
+    const int32_t* cnt;        // [N] items per lo
+    const SwapItem* items;     // [N][cap]
+    int64_t cap;
+    double2* contrib;          // [ns][2N]
+};
+
+// masked, renormalised sqrt-softmax amplitudes and phases of one site (ComplexRNNwavefunction.py:83-93,143-155)
+__device__ __forceinline__ void crnn_site(const float (&z)[4], int n, int N, int num_up, float& a0, float& a1,
+                                          float& ph0, float& ph1) {
+    const float m = fmaxf(z[0], z[1]);
+    const float e0 = expf(z[0] - m), e1 = expf(z[1] - m);
+    const float s = e0 + e1;
+    a0 = sqrtf(e0 / s);
+    a1 = sqrtf(e1 / s);
+    if (2 * n >= N) {                                    // n >= N/2: enforce zero magnetisation
+        const int base = N / 2 - 1;
+        const int num_down = n - num_up;
+        a0 *= (base - num_down >= 0) ? 1.0f : 0.0f;      // [activations_down, activations_up]
+        a1 *= (base - num_up >= 0) ? 1.0f : 0.0f;
+        const float inv = 1.0f / sqrtf(fmaxf(a0 * a0 + a1 * a1, 1e-30f));   // tf.nn.l2_normalize(eps=1e-30)
+        a0 *= inv;
+        a1 *= inv;
+    }
+    ph0 = 3.14159265358979323846f * (z[2] / (1.0f + fabsf(z[2])));   // pi * softsign
+    ph1 = 3.14159265358979323846f * (z[3] / (1.0f + fabsf(z[3])));
+}
+
+template <int NFULL, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) crnn_base_kernel(CrnnArgs a) {
+    using C = GruCore<float, NFULL, 4>;
+    constexpr int KT = C::KT;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    C::stage(lds, a.wimg);
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int64_t gw = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * WAVES;
+    const int N = a.N;
+    for (int64_t sb = gw; sb < a.nsb; sb += nw) {
+        const int64_t s = sb * kChains + c;
+        const bool valid = s < a.ns;
+        const int64_t sc = valid ? s : a.ns - 1;
+        float h[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) h[kt] = 0.0f;
+        int sig_in = -1, num_up = 0;
+        uint32_t word = 0;
+        double re = 0.0, im = 0.0;
+        for (int n = 0; n < N; ++n) {
+            if (!a.sampling && (n & 31) == 0) word = a.bits[(int64_t)(n >> 5) * a.ns + sc];
+            C::step(lds, sig_in, h, lane);
+            float z[4];
+            C::head(lds, h, lane, z);
+            float a0, a1, ph0, ph1;
+            crnn_site(z, n, N, num_up, a0, a1, ph0, ph1);
+            int sig;
+            if (a.sampling) {
+                // tf.random.categorical(log(a^2)): class 0 iff u * (a0^2 + a1^2) < a0^2; a masked class has
+                // logit -inf and is skipped by TF's kernel - same outcome here since its a^2 is exactly 0
+                const float u = philox_uniform(a.seed, a.step, (uint64_t)(a.sample_offset + sc), n);
+                const double w0 = (double)a0 * (double)a0, w1 = (double)a1 * (double)a1;
+                sig = ((double)u * (w0 + w1) < w0) ? 0 : 1;
+                word |= (uint32_t)sig << (n & 31);
+                if (((n & 31) == 31 || n == N - 1) && valid && q == 0) a.bits[(int64_t)(n >> 5) * a.ns + s] = word;
+                if ((n & 31) == 31) word = 0;
+            } else {
+                sig = (word >> (n & 31)) & 1;
+            }
+            const float asel = sig ? a1 : a0, aoth = sig ? a0 : a1;
+            if (a.cb && valid && q == 0)
+                a.cb[(int64_t)n * a.ns + s] = make_double2(re + (double)logf(aoth), im + (double)(sig ? ph0 : ph1));
+            re += (double)logf(asel);
+            im += (double)(sig ? ph1 : ph0);
+            if (a.hck && n < N - 1) {
+                float* dst = reinterpret_cast<float*>(a.hck) + (((int64_t)n * a.nsb + sb) * KT) * 64 + lane;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) dst[kt * 64] = h[kt];
+            }
+            num_up += sig;
+            sig_in = sig;
+        }
+        if (valid && q == 0) {
+            if (a.tot) a.tot[s] = make_double2(re, im);
+            if (a.out_amp) a.out_amp[s] = make_float2((float)re, (float)im);
+            if (a.out_logp) a.out_logp[s] = 2.0 * re;
+        }
+    }
+}
+
+// ---- connected configurations -----------------------------------------------------------------------
+struct J1J2Args {
+    const uint32_t* bits;
+    int64_t ns;
+    int32_t N;
+    const double *J1, *J2, *Bz;   // device, (N) each
+    int32_t periodic, marshall;
+    int32_t* cnt;                 // [N] zeroed before launch
+    SwapItem* items;              // [N][cap]
+    int64_t cap;
+    double2* contrib;             // [ns][2N], every entry written here (0 for inactive bonds)
+    double* diag;                 // [ns]
+};
+
+__device__ __forceinline__ int spin_of(const uint32_t* bits, int64_t ns, int64_t s, int p) {
+    return (int)((bits[(int64_t)(p >> 5) * ns + s] >> (p & 31)) & 1);
+}
+
+// grid.y = bond slot (0..2N-1), one wave per 64 samples
+__global__ void __launch_bounds__(256) j1j2_enumerate_kernel(J1J2Args a) {
+    const int N = a.N;
+    const int slot = blockIdx.y;
+    const int dist = slot < N ? 1 : 2;
+    const int site = slot < N ? slot : slot - N;
+    const int lim = a.periodic ? N : N - dist;
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = s < a.ns;
+    const double J = site < lim ? (dist == 1 ? a.J1[site] : a.J2[site]) : 0.0;
+    bool active = false;
+    int lo = 0, hi = 0;
+    if (in_range && site < lim && J != 0.0) {
+        const int t = (site + dist) % N;
+        lo = site < t ? site : t;
+        hi = site < t ? t : site;
+        active = spin_of(a.bits, a.ns, s, lo) != spin_of(a.bits, a.ns, s, hi);
+    }
+    if (in_range) a.contrib[s * (2 * N) + slot] = make_double2(0.0, 0.0);
+    // lo is wave-uniform (it depends on the slot only): one atomic per wave, ballot-ranked slots
+    const unsigned long long mask = __ballot(active);
+    if (mask) {
+        const int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(&a.cnt[lo], __popcll(mask));
+        base = __shfl(base, __ffsll((long long)mask) - 1);
+        if (active) {
+            const int k = base + __popcll(mask & ((1ull << lane) - 1ull));
+            SwapItem it;
+            it.s = (int32_t)s;
+            it.hi = hi;
+            it.slot = slot;
+            it.coef = (float)((dist == 1 && a.marshall) ? -J / 2 : J / 2);
+            a.items[(int64_t)lo * a.cap + k] = it;
+        }
+    }
+    if (slot == 0 && in_range) {     // diagonal element, once per sample (TrainingRNN_J1J2.py:32,46-57)
+        double d = 0.0;
+        for (int i = 0; i < N; ++i) d += ((double)spin_of(a.bits, a.ns, s, i) - 0.5) * a.Bz[i];
+        const int lim1 = a.periodic ? N : N - 1, lim2 = a.periodic ? N : N - 2;
+        for (int i = 0; i < lim1; ++i)
+            d += (spin_of(a.bits, a.ns, s, i) != spin_of(a.bits, a.ns, s, (i + 1) % N) ? -0.25 : 0.25) * a.J1[i];
+        for (int i = 0; i < lim2; ++i)
+            if (a.J2[i] != 0.0)
+                d += (spin_of(a.bits, a.ns, s, i) != spin_of(a.bits, a.ns, s, (i + 2) % N) ? -0.25 : 0.25) * a.J2[i];
+        a.diag[s] = d;
+    }
+}
+
+// tile_start[lo] = sum_{l < lo} ceil(cnt[l] / 16); tile_start[N] = total;
+// totals[0] = sum cnt (off-diagonal configurations), totals[1] = sum cnt[lo] (N-1-lo) (cell evaluations),
+// totals[2] = sum tiles[lo] (N-1-lo) (wave-steps actually issued)
+__global__ void j1j2_tile_scan_kernel(const int32_t* cnt, int N, int32_t* tile_start, int64_t* totals) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int32_t acc = 0;
+    int64_t items = 0, evals = 0, wsteps = 0;
+    for (int lo = 0; lo < N; ++lo) {
+        tile_start[lo] = acc;
+        const int t = (cnt[lo] + kChains - 1) / kChains;
+        acc += t;
+        items += cnt[lo];
+        evals += (int64_t)cnt[lo] * (N - 1 - lo);
+        wsteps += (int64_t)t * (N - 1 - lo);
+    }
+    tile_start[N] = acc;
+    totals[0] = items; totals[1] = evals; totals[2] = wsteps;
+}
+
+template <int NFULL, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) crnn_swap_kernel(CrnnArgs a) {
+    using C = GruCore<float, NFULL, 4>;
+    constexpr int KT = C::KT;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    C::stage(lds, a.wimg);
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int64_t gw = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * WAVES;
+    const int N = a.N;
+    const int64_t ntiles = a.tile_start[N];
+    for (int64_t tile = gw; tile < ntiles; tile += nw) {
+        int lo = 0;                                   // largest lo with tile_start[lo] <= tile (wave-uniform)
+        {
+            int l = 0, r = N;
+            while (r - l > 1) {
+                const int mid = (l + r) >> 1;
+                if (a.tile_start[mid] <= tile) l = mid; else r = mid;
+            }
+            lo = l;
+        }
+        const int k = (int)(tile - a.tile_start[lo]) * kChains + c;
+        const bool valid = k < a.cnt[lo];
+        const SwapItem it = a.items[(int64_t)lo * a.cap + (valid ? k : 0)];
+        const int64_t s = it.s;
+        float h[KT];
+        {
+            const float* src = reinterpret_cast<const float*>(a.hck) +
+                               (((int64_t)lo * a.nsb + (s >> 4)) * KT) * 64 + (q << 4) + (s & 15);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) h[kt] = src[kt * 64];
+        }
+        int num_up = 0;                               // ups among sites < lo, then the swapped spin at lo
+        for (int w = 0; w < (lo >> 5); ++w) num_up += __popc(a.bits[(int64_t)w * a.ns + s]);
+        uint32_t word = a.bits[(int64_t)(lo >> 5) * a.ns + s];
+        num_up += __popc(word & ((1u << (lo & 31)) - 1u));
+        int sig_in = 1 - (int)((word >> (lo & 31)) & 1);
+        num_up += sig_in;
+        double re = 0.0, im = 0.0;
+        for (int n = lo + 1; n < N; ++n) {
+            if ((n & 31) == 0) word = a.bits[(int64_t)(n >> 5) * a.ns + s];
+            C::step(lds, sig_in, h, lane);
+            float z[4];
+            C::head(lds, h, lane, z);
+            float a0, a1, ph0, ph1;
+            crnn_site(z, n, N, num_up, a0, a1, ph0, ph1);
+            const int sig = (int)((word >> (n & 31)) & 1) ^ (n == it.hi ? 1 : 0);
+            re += (double)logf(sig ? a1 : a0);
+            im += (double)(sig ? ph1 : ph0);
+            num_up += sig;
+            sig_in = sig;
+        }
+        if (valid && q == 0) {
+            const double2 b = a.cb[(int64_t)lo * a.ns + s];
+            const double2 t = a.tot[s];
+            const double dre = b.x + re - t.x, dim = b.y + im - t.y;
+            const double mag = exp(dre) * (double)it.coef;
+            a.contrib[s * (2 * N) + it.slot] = make_double2(mag * cos(dim), mag * sin(dim));
+        }
+    }
+}
+
+// E_loc[s] = diag + sum over bond slots (J1 bonds by site, then J2 bonds by site: the reference's row order)
+__global__ void j1j2_eloc_kernel(const double2* __restrict__ contrib, const double* __restrict__ diag, int64_t ns,
+                                 int N, float2* __restrict__ eloc) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= ns) return;
+    double re = diag[s], im = 0.0;
+    for (int k = 0; k < 2 * N; ++k) {
+        const double2 v = contrib[s * (2 * N) + k];
+        re += v.x;
+        im += v.y;
+    }
+    eloc[s] = make_float2((float)re, (float)im);
+}
+
+}  // namespace rnnwf

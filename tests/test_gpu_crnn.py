@@ -1,0 +1,177 @@
+"""GPU parity tests of the complex-RNN / J1-J2 path (HIP through the C ABI) vs the CPU oracle.
+
+Tolerances (the reference computes this path in float32 / complex64):
+  log psi     : |hip - oracle| <= 3e-6 * N + 3e-6 on both parts (phases compared modulo nothing: both are sums
+                of per-site principal values)
+  E_loc       : |hip - oracle| <= 5e-5 * (1 + |E|) per sample (complex64 output)
+"""
+from math import ceil
+
+import numpy as np
+import pytest
+
+from conftest import golden_params
+from oracle import estimators as E
+from oracle import models as M
+from oracle import philox
+from rnnwavefunctions_amd import params as P
+
+pytestmark = pytest.mark.gpu
+HEADS = ("wf_dense_ampl", "wf_dense_phase")
+
+
+def make_wf(N, H, prm):
+    from rnnwavefunctions_amd import _lib
+    wf = _lib.NativeWavefunction(_lib.MODEL_CRNN_U1, N, 1, (H,))
+    wf.set_params(prm, scope="RNNwavefunction")
+    return wf
+
+
+def trained_like(H, seed):
+    return P.randomize_biases(P.scale_kernels(P.init_gru_params([H], seed=seed, heads=HEADS), 2.0), seed + 1)
+
+
+def zero_mag_batch(ns, N, seed):
+    rng = np.random.RandomState(seed)
+    return np.stack([rng.permutation(np.repeat([0, 1], N // 2)) for _ in range(ns)]).astype(np.int32)
+
+
+@pytest.mark.parametrize("N,H,B", [(10, 11, 50), (40, 50, 100), (34, 20, 70), (16, 100, 33)])
+def test_log_amplitude_matches_oracle(N, H, B):
+    prm = trained_like(H, seed=H)
+    wf = make_wf(N, H, prm)
+    s = zero_mag_batch(B, N, 3)
+    got = wf.log_amp(s)
+    ref = M.crnn_log_amplitude(prm, s)
+    assert got.dtype == np.complex64
+    err_re, err_im = np.abs(got.real - ref.real).max(), np.abs(got.imag - ref.imag).max()
+    print("N=%d H=%d: |d re|=%.2e |d im|=%.2e" % (N, H, err_re, err_im))
+    tol = 3e-6 * N + 3e-6
+    assert err_re <= tol and err_im <= 4 * tol
+    assert np.allclose(wf.log_prob(s), 2.0 * ref.real.astype(np.float64), atol=2 * tol)
+    # outside the zero-magnetisation sector the amplitude vanishes: Re log psi = -inf
+    bad = s.copy()
+    bad[:, 0] = bad[:, 1] = bad[:, 2] = 1
+    bad = bad[bad.sum(axis=1) != N // 2]
+    assert np.all(np.isneginf(wf.log_amp(bad).real))
+
+
+def test_masked_sampler_matches_oracle_and_conserves_magnetisation():
+    N, H, ns = 40, 50, 1000
+    prm = trained_like(H, seed=7)
+    wf = make_wf(N, H, prm)
+    s, lg = wf.sample(ns, seed=5, step=2, return_log=True)
+    assert np.all(s.sum(axis=1) == N // 2)
+    s_ref = M.crnn_sample(prm, N, philox.uniforms(5, 2, 0, ns, N))
+    bad = (s != s_ref).any(axis=1).sum()
+    print("cRNN sampler: %d of %d rows differ from the oracle" % (bad, ns))
+    assert bad <= 2
+    ok = ~(s != s_ref).any(axis=1)
+    assert np.allclose(lg[ok], 2 * M.crnn_log_amplitude(prm, s_ref[ok]).real, atol=3e-4)
+    assert np.array_equal(np.concatenate([wf.sample(300, 5, 2, 0), wf.sample(700, 5, 2, 300)]), s)
+
+
+def test_j1j2_eloc_matches_reference_golden(golden_estimators):
+    """G4d: reference J1J2Slices + the reference's E_loc expression on oracle log-amplitudes."""
+    g = golden_estimators
+    prm = golden_params(g, "g4d")
+    s = g["g4d_samples"]
+    N = s.shape[1]
+    wf = make_wf(N, 11, prm)
+    e, ncon = wf.j1j2_eloc(s, np.ones(N), float(g["g4d_J2"]) * np.ones(N), np.zeros(N))
+    assert ncon == int(g["g4d_offsets"][-1])
+    print("G4d: max |E diff| = %.2e" % np.abs(e - g["g4d_eloc"]).max())
+    assert np.allclose(e, g["g4d_eloc"], rtol=5e-5, atol=5e-5)
+
+
+@pytest.mark.parametrize("periodic,marshall,J2v", [(False, False, 0.5), (True, False, 0.5), (False, True, 0.2),
+                                                   (True, True, 0.8), (False, False, 0.0)])
+def test_j1j2_eloc_flags(periodic, marshall, J2v):
+    N, H, ns = 16, 20, 77
+    prm = trained_like(H, seed=3)
+    wf = make_wf(N, H, prm)
+    s = zero_mag_batch(ns, N, 11)
+    rng = np.random.RandomState(2)
+    J1 = 1.0 + 0.1 * rng.standard_normal(N)
+    J2 = J2v * np.ones(N)
+    Bz = 0.05 * rng.standard_normal(N)
+    e, ncon = wf.j1j2_eloc(s, J1, J2, Bz, periodic, marshall)
+    e_ref = E.j1j2_local_energies(J1, J2, Bz, s, lambda x: M.crnn_log_amplitude(prm, x), periodic, marshall)
+    _, _, offs = E.j1j2_slices(J1, J2, Bz, s, periodic, marshall)
+    assert ncon == offs[-1]
+    assert np.allclose(e, e_ref, rtol=5e-5, atol=5e-5)
+
+
+def test_j1j2_reference_style_loop_through_the_facade():
+    """J1J2/TrainingRNN_J1J2.py:247-282 written against this package, compared with the fused call."""
+    from rnnwavefunctions_amd import compat as tf
+    from rnnwavefunctions_amd.J1J2.TrainingRNN_J1J2 import (J1J2_local_energies, J1J2Slices, RNNwavefunction)
+    N, numsamples = 12, 64
+    J1, J2, Bz = np.ones(N), 0.5 * np.ones(N), np.zeros(N)
+    wf = RNNwavefunction(N, units=[20], cell=tf.CudnnCompatibleGRUCell, seed=111)
+    assert wf.num_params() == 3 * 400 + 3 * 2 * 20 + 4 * 20 + 2 * (2 * 20 + 2)     # 3h^2 + 3dh + 4h + two heads
+    sess = tf.Session(graph=wf.graph)
+    samples_ = wf.sample(numsamples=numsamples, inputdim=2)
+    inputs = tf.placeholder(dtype=tf.int32, shape=(None, N))
+    log_amps = wf.log_amplitude(inputs, inputdim=2)
+    sigmas = np.zeros((2 * N * numsamples, N), dtype=np.int32)
+    H = np.zeros(2 * N * numsamples, dtype=np.float32)
+    log_amplitudes = np.zeros(2 * N * numsamples, dtype=np.complex64)
+    sigmaH = np.zeros((2 * N, N), dtype=np.int32)
+    matrixelements = np.zeros(2 * N, dtype=np.float32)
+
+    samples = sess.run(samples_)
+    assert np.all(samples.sum(axis=1) == N // 2)
+    slices, len_sigmas = J1J2Slices(J1, J2, Bz, samples, sigmas, H, sigmaH, matrixelements, False)
+    steps = ceil(len_sigmas / 30000)
+    for i in range(steps):
+        cut = slice((i * len_sigmas) // steps, ((i + 1) * len_sigmas) // steps if i < steps - 1 else len_sigmas)
+        log_amplitudes[cut] = sess.run(log_amps, feed_dict={inputs: sigmas[cut]})
+    local_energies = np.zeros(numsamples, dtype=np.complex64)
+    for n in range(len(slices)):
+        s = slices[n]
+        local_energies[n] = H[s].dot(np.exp(log_amplitudes[s] - log_amplitudes[s][0]))
+    fused, ncon = J1J2_local_energies(J1, J2, Bz, samples, log_amps, return_num_connected=True)
+    assert ncon == len_sigmas
+    assert np.allclose(fused, local_energies, rtol=5e-5, atol=5e-5)
+    meanE, varE = np.mean(local_energies), np.var(np.real(local_energies))
+    assert np.isfinite(meanE) and varE >= 0
+
+
+def test_vmc_step_j1j2():
+    N, H, ns = 20, 50, 257
+    prm = trained_like(H, seed=4)
+    wf = make_wf(N, H, prm)
+    couplings = np.concatenate([np.ones(N), 0.5 * np.ones(N), np.zeros(N), [0.0, 0.0]])
+    out = wf.vmc_step(ns, seed=9, step=1, couplings=couplings, want_samples=True, want_eloc=True)
+    s = out["samples"]
+    assert np.array_equal(s, wf.sample(ns, seed=9, step=1))
+    e, _ = wf.j1j2_eloc(s, np.ones(N), 0.5 * np.ones(N), np.zeros(N))
+    assert np.allclose(out["eloc"], e, rtol=1e-6, atol=1e-6)
+    m = out["moments"]
+    assert m[2] == ns
+    assert np.isclose(m[0] / ns, e.real.astype(np.float64).mean(), rtol=1e-9)
+    assert np.isclose(m[3] / ns, e.imag.astype(np.float64).mean(), rtol=1e-6, atol=1e-9)
+    assert np.isclose(m[1] / ns - (m[0] / ns) ** 2, np.var(e.real.astype(np.float64)), rtol=1e-6)
+
+
+def test_config3_properties():
+    """BASELINE config 3 (N=40, J2=0.5, num_units=50, numsamples=10000): zero magnetisation everywhere,
+    finite local energies, connected-configuration count in the range the survey measured (~40 per sample),
+    and <E>/N against the oracle on a 32-sample subset."""
+    N, H, ns = 40, 50, 10000
+    prm = P.init_gru_params([H], seed=111, heads=HEADS)
+    wf = make_wf(N, H, prm)
+    couplings = np.concatenate([np.ones(N), 0.5 * np.ones(N), np.zeros(N), [0.0, 0.0]])
+    out = wf.vmc_step(ns, seed=111, step=0, couplings=couplings, want_samples=True, want_eloc=True)
+    s, e = out["samples"], out["eloc"]
+    assert np.all(s.sum(axis=1) == N // 2)
+    assert np.all(np.isfinite(e.real)) and np.all(np.isfinite(e.imag))
+    sub = np.arange(0, ns, ns // 32)[:32]
+    e_ref = E.j1j2_local_energies(np.ones(N), 0.5 * np.ones(N), np.zeros(N), s[sub],
+                                  lambda x: M.crnn_log_amplitude(prm, x))
+    per_site = np.abs(e[sub] - e_ref).max() / N
+    print("cfg3: max |E_loc diff| / N over 32 samples = %.2e" % per_site)
+    assert per_site < 1e-5
+    _, ncon = wf.j1j2_eloc(s, np.ones(N), 0.5 * np.ones(N), np.zeros(N))
+    assert 30 * ns < ncon < 50 * ns

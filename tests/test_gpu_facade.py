@@ -1,0 +1,87 @@
+"""GPU tests of the drop-in Python layer: the reference's own call sequence
+(1DTFIM/TrainingRNN_1DTFIM.py:189-207) against the reference-named modules of this package."""
+import numpy as np
+import pytest
+
+from oracle import estimators as E
+from oracle import models as M
+from oracle import philox
+
+pytestmark = pytest.mark.gpu
+
+
+def test_1dtfim_loop_reads_like_the_reference():
+    from rnnwavefunctions_amd import compat as tf
+    from rnnwavefunctions_amd.TFIM1D.TrainingRNN_1DTFIM import Ising_local_energies, RNNwavefunction
+    N, numsamples, Bx = 20, 500, 1.0
+    Jz = +np.ones(N)
+    wf = RNNwavefunction(N, units=[20], cell=tf.CudnnCompatibleGRUCell, seed=111)
+    assert wf.num_params() == 1442                      # h=20 -> 1 442
+    sess = tf.Session(graph=wf.graph, config=tf.ConfigProto())
+    with wf.graph.as_default():
+        samples_ = wf.sample(numsamples=numsamples, inputdim=2)
+        samples_placeholder = tf.placeholder(dtype=tf.int32, shape=(None, N))
+        log_probs_tensor = wf.log_probability(samples_placeholder, inputdim=2)
+    queue_samples = np.zeros((N + 1, numsamples, N), dtype=np.int32)
+    log_probs = np.zeros((N + 1) * numsamples, dtype=np.float64)
+
+    samples = sess.run(samples_)
+    assert samples.dtype == np.int64 and samples.shape == (numsamples, N)
+    local_energies = Ising_local_energies(Jz, Bx, samples, queue_samples, log_probs_tensor, samples_placeholder,
+                                          log_probs, sess)
+    meanE, varE = np.mean(local_energies), np.var(local_energies)
+    assert np.isfinite(meanE) and varE > 0
+
+    prm = wf.get_params()
+    # same stream as the oracle: batch 0 of seed 111
+    s_ref, _ = M.prnn_sample(prm, N, philox.uniforms(111, 0, 0, numsamples, N))
+    assert (samples != s_ref).any(axis=1).sum() <= 1
+    e_ref, lp_ref = E.ising_local_energies(Jz, Bx, samples, lambda x: M.prnn_log_probability(prm, x),
+                                           return_log_probs=True)
+    assert np.allclose(local_energies, e_ref, rtol=2e-5)
+    assert np.allclose(log_probs, lp_ref.ravel(), atol=5e-5)          # the caller's scratch is filled
+    assert np.array_equal(queue_samples[0], samples)
+
+    # the reference formulation (host queue + chunked sess.run) through the same objects
+    log_probs2 = np.zeros_like(log_probs)
+    e2 = Ising_local_energies(Jz, Bx, samples, queue_samples, log_probs_tensor, samples_placeholder, log_probs2,
+                              sess, mode="reference")
+    assert np.allclose(e2, local_energies, rtol=1e-9)
+    assert np.array_equal(queue_samples[3][:, 2], 1 - samples[:, 2])
+
+    # a second sess.run draws the next batch
+    assert not np.array_equal(sess.run(samples_), samples)
+    # eager conveniences
+    assert np.allclose(wf.log_probability(samples[:7], 2), lp_ref[0, :7], atol=5e-5)
+
+    with pytest.raises(TypeError):
+        Ising_local_energies(Jz, Bx, samples, queue_samples, object(), samples_placeholder, log_probs, sess)
+    with pytest.raises(ValueError):
+        wf.sample(10, inputdim=3)
+
+
+def test_weights_roundtrip_through_npz(tmp_path):
+    from rnnwavefunctions_amd.TFIM1D.RNNwavefunction import RNNwavefunction
+    a = RNNwavefunction(12, units=[10], seed=1)
+    b = RNNwavefunction(12, units=[10], seed=2)
+    s = np.random.RandomState(0).randint(0, 2, (20, 12))
+    assert not np.allclose(a.log_probability(s, 2), b.log_probability(s, 2))
+    a.save(tmp_path / "wf.npz")
+    b.restore(tmp_path / "wf.npz")
+    assert np.array_equal(a.log_probability(s, 2), b.log_probability(s, 2))
+    assert a.num_params() == 422                        # Tutorial_1DTFIM.ipynb cell 15
+
+
+def test_2dtfim_1drnn_facade(golden_estimators):
+    from conftest import golden_params
+    from rnnwavefunctions_amd import compat as tf
+    from rnnwavefunctions_amd.TFIM2D_1DRNN.Training1DRNN_2DTFIM import Ising2D_local_energies, RNNwavefunction
+    g = golden_estimators
+    Nx, Ny = (int(v) for v in g["g4c_shape"])
+    wf = RNNwavefunction(Nx, Ny, units=[7], cell=tf.CudnnCompatibleGRUCell)
+    wf.set_params(golden_params(g, "g4c"))
+    ph = tf.placeholder(tf.int32, shape=(None, Nx * Ny))
+    t = wf.log_probability(ph, 2)
+    s = g["g4c_samples"]
+    e = Ising2D_local_energies(g["g4c_Jz"], float(g["g4c_Bx"]), Nx, Ny, s, None, t, ph, None, tf.Session())
+    assert np.allclose(e, g["g4c_eloc"], rtol=1e-10)

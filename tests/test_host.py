@@ -1,0 +1,131 @@
+"""CPU tests of the host side: the C-ABI library loads and exports everything include/rnnwf.h declares
+(no compute without a GPU), the host-only estimator helpers match the reference's golden vectors
+bit for bit, the TF stand-ins behave, and the C restatement agrees with the NumPy oracle."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from oracle import cport
+from oracle import estimators as E
+from oracle import models as M
+from oracle import philox
+from rnnwavefunctions_amd import compat
+from rnnwavefunctions_amd import params as P
+from rnnwavefunctions_amd.estimators import J1J2MatrixElements, J1J2Slices
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from rnnwavefunctions_amd import build
+    return build.build()
+
+
+def test_abi_library_exports_every_declared_symbol(built_lib):
+    from rnnwavefunctions_amd import _lib
+    header = open(os.path.join(ROOT, "include", "rnnwf.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(rnnwf_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    lib = ctypes.CDLL(built_lib)
+    for name in declared:
+        assert hasattr(lib, name), name
+    handle = _lib.load_library()
+    assert handle.rnnwf_backend_name() == b"hip-gfx950"
+    assert handle.rnnwf_abi_version() == _lib.ABI_VERSION
+
+
+def test_no_device_fails_loudly(built_lib):
+    from rnnwavefunctions_amd import _lib
+    lib = _lib.load_library()
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.RnnwfError, match="no HIP device"):
+        _lib.NativeWavefunction(_lib.MODEL_GRU1D, 10, 1, (10,))
+    assert b"no HIP device" in lib.rnnwf_last_error(None)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "rnnwavefunctions_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip")):
+                txt = open(os.path.join(d, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(d, f)
+
+
+def test_host_j1j2_matrix_elements_bit_exact(golden_j1j2):
+    g = golden_j1j2
+    for c in range(int(g["g1_ncases"])):
+        pre = "g1_%d_" % c
+        N, J2v, periodic, marshall = g[pre + "meta"]
+        N = int(N)
+        for k, sig in enumerate(g[pre + "sigma"]):
+            sh = np.zeros((2 * N + 2, N), dtype=np.int32)
+            me = np.zeros(2 * N + 2, dtype=np.float32)
+            num = J1J2MatrixElements(np.ones(N), J2v * np.ones(N), 0.1 * np.arange(N), sig, sh, me,
+                                     bool(periodic), bool(marshall))
+            assert num == g[pre + "num"][k]
+            assert np.array_equal(sh[:num], g[pre + "rows"][k, :num])
+            assert np.array_equal(me[:num], g[pre + "elems"][k, :num])
+
+
+def test_host_j1j2_slices_keep_the_reference_quirk(golden_j1j2):
+    g = golden_j1j2
+    N, ns = 8, 32
+    for flag in (0, 1):
+        pre = "g2_%d_" % flag
+        sig = np.zeros(((2 * N + 2) * ns, N), dtype=np.int32)
+        H = np.zeros((2 * N + 2) * ns, dtype=np.float32)
+        sl, tot = J1J2Slices(np.ones(N), 0.5 * np.ones(N), np.zeros(N), g[pre + "samples"], sig, H,
+                             np.zeros((2 * N + 2, N), dtype=np.int32), np.zeros(2 * N + 2, dtype=np.float32), bool(flag))
+        assert [s.start for s in sl] + [tot] == g[pre + "offsets"].tolist()
+        assert np.array_equal(sig[:tot], g[pre + "sigmas"])
+        assert np.array_equal(H[:tot], g[pre + "H"])
+
+
+def test_session_standins():
+    sess = compat.Session(graph=compat.Graph(), config=compat.ConfigProto())
+    with pytest.raises(TypeError):
+        sess.run("not an op")
+    ph = compat.placeholder(compat.int32, shape=(None, 5))
+    assert ph.shape == (None, 5)
+    assert compat.is_gru_cell(compat.CudnnCompatibleGRUCell) and compat.is_gru_cell(None)
+    assert not compat.is_gru_cell("LSTMCell")
+    with compat.Graph().as_default() as g:
+        assert isinstance(g, compat.Graph)
+
+
+def test_params_roundtrip(tmp_path):
+    prm = P.init_gru_params([7], seed=3, heads=("wf_dense_ampl", "wf_dense_phase"))
+    P.save_npz(tmp_path / "w.npz", prm)
+    back = P.load_npz(tmp_path / "w.npz")
+    assert list(back) == list(prm)
+    assert all(np.array_equal(back[k], prm[k]) and back[k].dtype == prm[k].dtype for k in prm)
+    assert np.all(prm["RNNwavefunction/multi_rnn_cell/cell_0/cudnn_compatible_gru_cell/gates/bias"] == 1)
+
+
+def test_c_restatement_matches_numpy_oracle():
+    prm = P.randomize_biases(P.scale_kernels(P.init_gru_params([23], seed=5), 2.0), 6)
+    s = np.random.RandomState(0).randint(0, 2, (70, 21)).astype(np.int32)
+    assert np.allclose(cport.prnn_log_probability(prm, s), M.prnn_log_probability(prm, s), atol=2e-5)
+    Jz = 1 + 0.1 * np.arange(21)
+    e_c, lp_c = cport.ising_local_energies(prm, Jz, 0.8, s, return_log_probs=True)
+    e_n, lp_n = E.ising_local_energies(Jz, 0.8, s, lambda x: M.prnn_log_probability(prm, x), return_log_probs=True)
+    assert np.allclose(lp_c, lp_n.ravel(), atol=2e-5)
+    assert np.allclose(e_c, e_n, rtol=2e-5)
+    u = philox.uniforms(9, 1, 0, 100, 21)
+    s_c, l_c = cport.prnn_sample(prm, 21, u)
+    s_n, l_n = M.prnn_sample(prm, 21, u)
+    assert (s_c != s_n).any(axis=1).sum() <= 1
+    assert cport.usable_cores() >= 1
+
+
+def test_bench_helpers():
+    import bench
+    assert bench.f_cell_gru(50) == 15800 and bench.f_cell_gru(100) == 61600
+    assert bench.WORKLOADS["cfg2"]["N"] == 80 and bench.WORKLOADS["cfg2"]["H"] == 50
