@@ -1,10 +1,304 @@
-// mdrnn.hip - 2D MDRNN wave function (2DTFIM_2DRNN/) - placeholder until the kernels land: every entry
-// point fails loudly.
+// mdrnn.hip - host side of the 2D MDRNN wave function (model MDRNN2D, float64):
+// sample / log_probability / fused 2D-TFIM local energies / fused VMC step.
+#include <algorithm>
+
+#include "mdrnn_kernels.h"
 #include "models.h"
+#include "pack.h"
+
 using namespace rnnwf;
-#define NI(h) return (h)->fail(RNNWF_ERR_INVALID, "%s: MDRNN kernels not built yet", __func__)
-int rnnwf::mdrnn_pack_image(rnnwf_handle* h, std::vector<char>&) { NI(h); }
-int rnnwf::mdrnn_sample(rnnwf_handle* h, int64_t, uint64_t, uint64_t, int64_t, int32_t*, double*) { NI(h); }
-int rnnwf::mdrnn_log_prob(rnnwf_handle* h, const int32_t*, int64_t, double*) { NI(h); }
-int rnnwf::mdrnn_tfim_eloc(rnnwf_handle* h, const int32_t*, int64_t, const double*, double, double*, double*) { NI(h); }
-int rnnwf::mdrnn_vmc_step(rnnwf_handle* h, int64_t, uint64_t, uint64_t, int64_t, const double*, int32_t*, double*, double*) { NI(h); }
+
+namespace {
+
+constexpr size_t kHsBudget = (size_t)24 << 30;   // bytes of per-site hidden states per pass
+
+template <int NFULL, int WAVES>
+struct MLaunch {
+    using L = MdLayout<NFULL>;
+    static int blocks_per_cu(rnnwf_handle* h, const void* fn, int* out) {
+        RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES));
+        int nb = 0;
+        RNNWF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, WAVES * 64, L::BYTES));
+        *out = std::max(nb, 1);
+        return 0;
+    }
+    static int base(rnnwf_handle* h, const MdArgs& a) {
+        static int bpc = 0;
+        const void* fn = (const void*)mdrnn_base_kernel<NFULL, WAVES>;
+        if (!bpc) if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
+        const int64_t need = (a.nsb + WAVES - 1) / WAVES;
+        const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
+        TimedLaunch tl(h, 0);
+        mdrnn_base_kernel<NFULL, WAVES><<<grid, WAVES * 64, L::BYTES, h->stream>>>(a);
+        RNNWF_HIP(h, hipGetLastError());
+        return 0;
+    }
+    static int flip_grid(rnnwf_handle* h, int64_t ntiles, unsigned* grid) {
+        static int bpc = 0;
+        const void* fn = (const void*)mdrnn_flip_kernel<NFULL, WAVES>;
+        if (!bpc) if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
+        const int64_t need = (ntiles + WAVES - 1) / WAVES;
+        *grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
+        return 0;
+    }
+    static int flip(rnnwf_handle* h, MdArgs a) {
+        unsigned grid = 0;
+        if (int rc = flip_grid(h, a.ntiles, &grid)) return rc;
+        const size_t ring_bytes = (size_t)grid * WAVES * 2 * a.Nx * L::KT * 64 * 8;
+        if (int rc = ensure(h, h->rowbuf, ring_bytes)) return rc;
+        a.ring = (double*)h->rowbuf.p;
+        TimedLaunch tl(h, 1);
+        mdrnn_flip_kernel<NFULL, WAVES><<<grid, WAVES * 64, L::BYTES, h->stream>>>(a);
+        RNNWF_HIP(h, hipGetLastError());
+        return 0;
+    }
+    static size_t hs_bytes_per_block() { return (size_t)L::KT * 64 * 8; }
+    static double mfma_flops_per_step() { return (double)L::NT * 2 * L::KT * 2048.0; }
+
+    static std::vector<char> pack(const rnnwf_handle* h) {
+        const int H = h->H;
+        std::vector<char> img(L::BYTES, 0);
+        const auto& Wh = pv(h, "Wh_rnn_0");   // [H, H]
+        const auto& Uh = pv(h, "Uh_rnn_0");   // [2, H]
+        const auto& Wv = pv(h, "Wv_rnn_0");
+        const auto& Uv = pv(h, "Uv_rnn_0");
+        const auto& b = pv(h, "b_rnn_0");
+        const auto& Wd = pv(h, "wf_dense/kernel");
+        const auto& bd = pv(h, "wf_dense/bias");
+        double* A = reinterpret_cast<double*>(img.data() + L::OFF_A);
+        for (int t = 0; t < L::NT; ++t)
+            for (int row = 0; row < 16; ++row) {
+                const int unit = 16 * t + row;
+                if (unit >= H || (t == NFULL && row >= 4)) continue;
+                for (int kq = 0; kq < 4; ++kq) {
+                    const int lane = (kq << 4) | row;
+                    for (int kk = 0; kk < 2 * L::KT; ++kk) {
+                        const int k = 4 * (kk < L::KT ? kk : kk - L::KT) + kq;
+                        if (k >= H) continue;
+                        const double w = kk < L::KT ? Wh[(size_t)k * H + unit] : Wv[(size_t)k * H + unit];
+                        A[(((size_t)t * L::KT + kk / 2) * 64 + lane) * 2 + (kk & 1)] = w;
+                    }
+                }
+            }
+        for (int v = 0; v < 3; ++v) {
+            double* BH = reinterpret_cast<double*>(img.data() + L::OFF_BH + v * L::SZ_B);
+            double* BV = reinterpret_cast<double*>(img.data() + L::OFF_BV + v * L::SZ_B);
+            for (int t = 0; t < L::NT; ++t)
+                for (int q = 0; q < 4; ++q)
+                    for (int r = 0; r < 4; ++r) {
+                        if (t == NFULL && r != 0) continue;
+                        const int unit = t < NFULL ? 16 * t + 4 * r + q : 16 * NFULL + q;
+                        if (unit >= H) continue;
+                        BH[t * 16 + q * 4 + r] = b[unit] + (v ? Uh[(size_t)(v - 1) * H + unit] : 0.0);
+                        BV[t * 16 + q * 4 + r] = v ? Uv[(size_t)(v - 1) * H + unit] : 0.0;
+                    }
+        }
+        double* WD = reinterpret_cast<double*>(img.data() + L::OFF_WD);
+        double* BD = reinterpret_cast<double*>(img.data() + L::OFF_BD);
+        for (int kt = 0; kt < L::KT; ++kt)
+            for (int q = 0; q < 4; ++q) {
+                const int unit = 4 * kt + q;
+                if (unit >= H) continue;
+                WD[(kt * 4 + q) * 2] = Wd[(size_t)unit * 2];
+                WD[(kt * 4 + q) * 2 + 1] = Wd[(size_t)unit * 2 + 1];
+            }
+        BD[0] = bd[0];
+        BD[1] = bd[1];
+        return img;
+    }
+};
+
+#define MD_DISPATCH(h, EXPR)                                    \
+    do {                                                        \
+        switch ((h)->NFULL) {                                   \
+            case 1: { using K = MLaunch<1, 4>; EXPR; }          \
+            case 2: { using K = MLaunch<2, 4>; EXPR; }          \
+            case 3: { using K = MLaunch<3, 4>; EXPR; }          \
+            case 4: { using K = MLaunch<4, 4>; EXPR; }          \
+        }                                                       \
+    } while (0)
+
+int launch_base(rnnwf_handle* h, const MdArgs& a) {
+    MD_DISPATCH(h, return K::base(h, a));
+    return h->fail(RNNWF_ERR_INVALID, "MDRNN: num_units > 68 is not implemented on gfx950 yet");
+}
+int launch_flip(rnnwf_handle* h, const MdArgs& a) {
+    MD_DISPATCH(h, return K::flip(h, a));
+    return h->fail(RNNWF_ERR_INVALID, "MDRNN: num_units > 68 is not implemented on gfx950 yet");
+}
+size_t hs_bytes_per_block(rnnwf_handle* h) {
+    MD_DISPATCH(h, return K::hs_bytes_per_block());
+    return 1;
+}
+double mfma_flops_per_step(rnnwf_handle* h) {
+    MD_DISPATCH(h, return K::mfma_flops_per_step());
+    return 0;
+}
+
+// device maps, 6 x N int32: col_of_pos | pos_of_site | row_of_pos | vert_pos | row_first | (spare)
+struct Maps {
+    const int32_t *col_of_pos, *pos_of_site, *row_of_pos, *vert_pos, *row_first;
+};
+
+int get_maps(rnnwf_handle* h, Maps* m) {
+    const int Nx = h->Nx, Ny = h->Ny, N = h->N;
+    if (!h->maps.p) {
+        std::vector<int32_t> v((size_t)5 * N);
+        auto pos_of = [&](int nx, int ny) { return ny * Nx + (ny % 2 == 0 ? nx : Nx - 1 - nx); };
+        for (int p = 0; p < N; ++p) {
+            const int ny = p / Nx, j = p % Nx;
+            const int nx = ny % 2 == 0 ? j : Nx - 1 - j;
+            const int k = nx * Ny + ny;                        // samples[b, nx, ny] in C order
+            v[p] = k;
+            v[(size_t)N + k] = p;
+            v[(size_t)2 * N + p] = k + 1;                      // queue row of the flip at (nx, ny): nx*Ny + ny + 1
+            v[(size_t)3 * N + p] = ny > 0 ? pos_of(nx, ny - 1) : -1;
+            v[(size_t)4 * N + p] = j == 0 ? 1 : 0;
+        }
+        if (int rc = ensure(h, h->maps, v.size() * 4)) return rc;
+        RNNWF_HIP(h, hipMemcpy(h->maps.p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    }
+    const int32_t* b = (const int32_t*)h->maps.p;
+    m->col_of_pos = b;
+    m->pos_of_site = b + N;
+    m->row_of_pos = b + 2 * (size_t)N;
+    m->vert_pos = b + 3 * (size_t)N;
+    m->row_first = b + 4 * (size_t)N;
+    return 0;
+}
+
+int64_t max_chains_per_pass(rnnwf_handle* h) {
+    const size_t per_block = (size_t)h->N * hs_bytes_per_block(h);
+    return std::max<int64_t>(1, (int64_t)(kHsBudget / per_block)) * kChains;
+}
+
+MdArgs base_args(rnnwf_handle* h, int64_t ns, const Maps& m) {
+    MdArgs a{};
+    a.wimg = h->wimg.p;
+    a.N = h->N;
+    a.Nx = h->Nx;
+    a.ns = ns;
+    a.nsb = (ns + kChains - 1) / kChains;
+    a.vert_pos = m.vert_pos;
+    a.row_first = m.row_first;
+    a.row_of_pos = m.row_of_pos;
+    return a;
+}
+
+int eloc_on_device(rnnwf_handle* h, int64_t ns, const Maps& m, bool sampling, uint64_t seed, uint64_t step,
+                   int64_t offset, const double* Jz_dev, double Bx) {
+    const int N = h->N;
+    const int64_t nsb = (ns + kChains - 1) / kChains;
+    if (int rc = ensure(h, h->hck, (size_t)N * nsb * hs_bytes_per_block(h))) return rc;
+    if (int rc = ensure(h, h->lpq, (size_t)(N + 1) * ns * 8)) return rc;
+    if (int rc = ensure(h, h->eloc, (size_t)ns * 8)) return rc;
+    MdArgs a = base_args(h, ns, m);
+    a.bits = (uint32_t*)h->bits.p;
+    a.hs = (double*)h->hck.p;
+    a.lpq = (double*)h->lpq.p;
+    a.sampling = sampling ? 1 : 0;
+    a.seed = seed; a.step = step; a.sample_offset = offset;
+    if (int rc = launch_base(h, a)) return rc;
+    if (Bx != 0.0 && N > 1) {
+        a.sampling = 0;
+        a.ntiles = (int64_t)(N - 1) * nsb;
+        if (int rc = launch_flip(h, a)) return rc;
+        h->work[0] += (double)ns * N * (N - 1) / 2.0;
+        h->work[1] += (double)nsb * N * (N - 1) / 2.0 * mfma_flops_per_step(h);
+    }
+    return run_tfim_eloc(h, (const uint32_t*)h->bits.p, (const double*)h->lpq.p, ns, h->Nx, h->Ny, m.pos_of_site, Jz_dev,
+                         Bx, (double*)h->eloc.p);
+}
+
+}  // namespace
+
+int rnnwf::mdrnn_pack_image(rnnwf_handle* h, std::vector<char>& img) {
+    if (h->N > 256) return h->fail(RNNWF_ERR_INVALID, "MDRNN: lattices above 256 sites are not implemented");
+    MD_DISPATCH(h, { img = K::pack(h); return 0; });
+    return h->fail(RNNWF_ERR_INVALID, "MDRNN: num_units > 68 is not implemented on gfx950 yet");
+}
+
+int rnnwf::mdrnn_log_prob(rnnwf_handle* h, const int32_t* samples, int64_t B, double* out) {
+    const int N = h->N;
+    Maps m;
+    if (int rc = get_maps(h, &m)) return rc;
+    const int64_t chunk = max_chains_per_pass(h);
+    for (int64_t off = 0; off < B; off += chunk) {
+        const int64_t nb = std::min(chunk, B - off);
+        const int64_t nsb = (nb + kChains - 1) / kChains;
+        if (int rc = upload_and_pack(h, samples + off * N, nb, h->bits, 0, m.col_of_pos)) return rc;
+        if (int rc = ensure(h, h->out_lp, (size_t)nb * 8)) return rc;
+        if (int rc = ensure(h, h->hck, (size_t)N * nsb * hs_bytes_per_block(h))) return rc;
+        MdArgs a = base_args(h, nb, m);
+        a.bits = (uint32_t*)h->bits.p;
+        a.hs = (double*)h->hck.p;
+        a.out_lp = (double*)h->out_lp.p;
+        if (int rc = launch_base(h, a)) return rc;
+        RNNWF_HIP(h, hipMemcpyAsync(out + off, h->out_lp.p, (size_t)nb * 8, hipMemcpyDeviceToHost, h->stream));
+        RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    return RNNWF_OK;
+}
+
+int rnnwf::mdrnn_sample(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t step, int64_t offset, int32_t* out,
+                        double* out_log) {
+    const int N = h->N;
+    const int W = (N + 31) / 32;
+    Maps m;
+    if (int rc = get_maps(h, &m)) return rc;
+    if (ns > max_chains_per_pass(h)) return h->fail(RNNWF_ERR_NOMEM, "rnnwf_sample: batch too large for one pass; split it");
+    const int64_t nsb = (ns + kChains - 1) / kChains;
+    if (int rc = ensure(h, h->bits, (size_t)W * ns * 4)) return rc;
+    if (int rc = ensure(h, h->out_lp, (size_t)ns * 8)) return rc;
+    if (int rc = ensure(h, h->hck, (size_t)N * nsb * hs_bytes_per_block(h))) return rc;
+    MdArgs a = base_args(h, ns, m);
+    a.bits = (uint32_t*)h->bits.p;
+    a.hs = (double*)h->hck.p;
+    a.out_lp = (double*)h->out_lp.p;
+    a.sampling = 1;
+    a.seed = seed; a.step = step; a.sample_offset = offset;
+    if (int rc = launch_base(h, a)) return rc;
+    if (int rc = unpack_and_download(h, h->bits, ns, out, m.pos_of_site)) return rc;
+    if (out_log) RNNWF_HIP(h, hipMemcpyAsync(out_log, h->out_lp.p, (size_t)ns * 8, hipMemcpyDeviceToHost, h->stream));
+    RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+    return RNNWF_OK;
+}
+
+int rnnwf::mdrnn_tfim_eloc(rnnwf_handle* h, const int32_t* samples, int64_t ns, const double* Jz, double Bx,
+                           double* eloc, double* log_probs) {
+    const int N = h->N;
+    Maps m;
+    if (int rc = get_maps(h, &m)) return rc;
+    if (int rc = ensure(h, h->coupl, (size_t)N * 8)) return rc;
+    RNNWF_HIP(h, hipMemcpyAsync(h->coupl.p, Jz, (size_t)N * 8, hipMemcpyHostToDevice, h->stream));
+    const int64_t chunk = max_chains_per_pass(h);
+    for (int64_t off = 0; off < ns; off += chunk) {
+        const int64_t nb = std::min(chunk, ns - off);
+        if (int rc = upload_and_pack(h, samples + off * N, nb, h->bits, 0, m.col_of_pos)) return rc;
+        if (int rc = eloc_on_device(h, nb, m, false, 0, 0, 0, (const double*)h->coupl.p, Bx)) return rc;
+        RNNWF_HIP(h, hipMemcpyAsync(eloc + off, h->eloc.p, (size_t)nb * 8, hipMemcpyDeviceToHost, h->stream));
+        if (log_probs)
+            RNNWF_HIP(h, hipMemcpy2DAsync(log_probs + off, (size_t)ns * 8, h->lpq.p, (size_t)nb * 8, (size_t)nb * 8,
+                                          (size_t)N + 1, hipMemcpyDeviceToHost, h->stream));
+        RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    return RNNWF_OK;
+}
+
+int rnnwf::mdrnn_vmc_step(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t step, int64_t offset,
+                          const double* couplings, int32_t* out_samples, double* out_eloc, double* moments) {
+    const int N = h->N;
+    const int W = (N + 31) / 32;
+    Maps m;
+    if (int rc = get_maps(h, &m)) return rc;
+    if (ns > max_chains_per_pass(h))
+        return h->fail(RNNWF_ERR_NOMEM, "rnnwf_vmc_step: %lld samples exceed the hidden-state budget; split the batch",
+                       (long long)ns);
+    if (int rc = ensure(h, h->bits, (size_t)W * ns * 4)) return rc;
+    if (int rc = ensure(h, h->coupl, (size_t)N * 8)) return rc;
+    RNNWF_HIP(h, hipMemcpyAsync(h->coupl.p, couplings, (size_t)N * 8, hipMemcpyHostToDevice, h->stream));
+    if (int rc = eloc_on_device(h, ns, m, true, seed, step, offset, (const double*)h->coupl.p, couplings[N])) return rc;
+    if (out_samples) if (int rc = unpack_and_download(h, h->bits, ns, out_samples, m.pos_of_site)) return rc;
+    if (out_eloc) RNNWF_HIP(h, hipMemcpyAsync(out_eloc, h->eloc.p, (size_t)ns * 8, hipMemcpyDeviceToHost, h->stream));
+    return run_moments(h, h->eloc.p, ns, false, moments);
+}
