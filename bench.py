@@ -27,15 +27,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (model, N or (Nx,Ny), num_units, numsamples per GPU, couplings builder, description)
     "cfg2": dict(kind="tfim1d", N=80, H=50, ns=10000, Bx=1.0,
                  desc="1DTFIM pRNN N=80 num_units=50 numsamples=10000 (BASELINE config 2)"),
     "cfg1": dict(kind="tfim1d", N=20, H=20, ns=500, Bx=1.0,
                  desc="1DTFIM pRNN N=20 num_units=20 numsamples=500 (BASELINE config 1)"),
+    "cfg3": dict(kind="j1j2", N=40, H=50, ns=10000, J2=0.5,
+                 desc="J1J2 cRNN N=40 J2=0.5 U(1) mask num_units=50 numsamples=10000 (BASELINE config 3)"),
+    "cfg4": dict(kind="tfim2d", Nx=12, Ny=12, N=144, H=50, ns=10000, Bx=3.0,
+                 desc="2DTFIM_2DRNN 12x12 MDRNNcell num_units=50 numsamples=10000, f64 (BASELINE config 4)"),
     "cfg5": dict(kind="tfim1d", N=200, H=100, ns=32768, Bx=1.0,
                  desc="1DTFIM pRNN N=200 num_units=100 numsamples=32768 per GPU (BASELINE config 5 shard)"),
 }
-PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 MFMA = vector peak
+# /opt/skills/guides/MI355X_MICROARCH.md: dense f32 MFMA = f32 vector peak; f64 matrix = f64 vector peak
+PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}
 
 
 def f_cell_gru(h):
@@ -43,12 +47,31 @@ def f_cell_gru(h):
     return 6 * h * h + 16 * h
 
 
+def f_cell(wl):
+    h = wl["H"]
+    if wl["kind"] == "j1j2":
+        return f_cell_gru(h) + 4 * h          # second Dense(2) head
+    if wl["kind"] == "tfim2d":
+        return 4 * h * h + 12 * h             # MDRNN: 4h^2 + 4dh + 4h
+    return f_cell_gru(h)
+
+
 def make_wavefunction(wl, device):
     from rnnwavefunctions_amd import _lib, params as P
-    prm = P.init_gru_params([wl["H"]], seed=111)
-    wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D, wl["N"], 1, (wl["H"],), device=device)
+    N, H = wl["N"], wl["H"]
+    if wl["kind"] == "j1j2":
+        prm = P.init_gru_params([H], seed=111, heads=("wf_dense_ampl", "wf_dense_phase"))
+        wf = _lib.NativeWavefunction(_lib.MODEL_CRNN_U1, N, 1, (H,), device=device)
+        couplings = np.concatenate([np.ones(N), wl["J2"] * np.ones(N), np.zeros(N), [0.0, 0.0]])
+    elif wl["kind"] == "tfim2d":
+        prm = P.init_mdrnn_params(H, seed=111)
+        wf = _lib.NativeWavefunction(_lib.MODEL_MDRNN2D, wl["Nx"], wl["Ny"], (H,), device=device)
+        couplings = np.append(np.ones(N), wl["Bx"])
+    else:
+        prm = P.init_gru_params([H], seed=111)
+        wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D, N, 1, (H,), device=device)
+        couplings = np.append(np.ones(N), wl["Bx"])
     wf.set_params(prm, scope="RNNwavefunction")
-    couplings = np.append(np.ones(wl["N"]), wl["Bx"])
     return wf, prm, couplings
 
 
@@ -104,14 +127,18 @@ def main():
     if args.numsamples:
         wl["ns"] = args.numsamples
 
+    # Load order matters: the product library (and RCCL, which it dlopens) come first so that the HIP runtime
+    # in this process is /opt/rocm's; torch (which bundles its own copies) is imported afterwards and only for
+    # the launcher's CPU-side rendezvous.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    wf, prm, couplings = make_wavefunction(wl, device=local_rank)
     dist = None
     if world > 1:
+        uid = wf.comm_unique_id()             # every rank: loads librccl now; only rank 0's id is used
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         import torch.distributed as dist      # launcher plumbing only: gloo rendezvous + barrier on CPU
         dist.init_process_group(backend="gloo")
-
-    wf, prm, couplings = make_wavefunction(wl, device=local_rank)
-    if world > 1:
-        box = [wf.comm_unique_id() if rank == 0 else None]
+        box = [uid if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         wf.comm_init(box[0], rank, world)
 
@@ -156,28 +183,32 @@ def main():
         mean_e = m[0] / m[2]
         var_e = m[1] / m[2] - mean_e ** 2
         launches = max(flip["launches"], 1)
-        alg_flops_per_launch = flip["cell_evals"] / launches * f_cell_gru(wl["H"])
+        alg_flops_per_launch = flip["cell_evals"] / launches * f_cell(wl)
         flip_ms = flip["total_ms"] / launches
         achieved = alg_flops_per_launch / (flip_ms * 1e-3) / 1e12 if flip_ms > 0 else 0.0
+        dtype = "f64" if wl["kind"] == "tfim2d" else "f32"
+        peak = PEAK_TFLOPS[dtype]
+        kernel = {"tfim1d": "prnn_flip_kernel", "j1j2": "crnn_swap_kernel", "tfim2d": "mdrnn_flip_kernel"}[wl["kind"]]
         rec = {
             "metric": "samples*sites/sec (autoregressive sample+local_energy), 1D TFIM N=80 nh=50"
-                      if args.workload == "cfg2" else "samples*sites/sec (autoregressive sample+local_energy)",
+                      if args.workload == "cfg2" else "samples*sites/sec (autoregressive sample+local_energy), " + args.workload,
             "value": value, "unit": "samples*sites/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": dtype, "data": "synthetic",
             "config": {"workload": wl["desc"], "numsamples_per_gpu": ns, "global_numsamples": ns * world,
                        "sites": N, "num_units": wl["H"], "parallelism": "dp%d (sample shards, 1 RCCL all-reduce/step)" % world,
                        "weights": "glorot-uniform RandomState(111), gate bias 1", "mean_E": mean_e, "var_E": var_e},
-            "roofline": {"bound": "mfma", "kernel": "prnn_flip_kernel", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": load_traffic(args.workload),
+            "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": (load_traffic(args.workload) or {}).get("hbm_bytes_per_launch"),
+                         "traffic_detail": load_traffic(args.workload),
                          "algorithmic_flops_per_launch": alg_flops_per_launch,
                          "mfma_flops_issued_per_launch": flip["mfma_flops"] / launches,
                          "avg_launch_ms": flip_ms,
                          "base_pass_ms": base["total_ms"] / max(base["launches"], 1),
                          "assembly_ms": asm["total_ms"] / max(asm["launches"], 1) * (asm["launches"] / launches)},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and wl["kind"] == "tfim1d":
             rec["cpu_baseline"] = cpu_baseline(wl, prm)
         else:
             rec["cpu_baseline"] = None

@@ -210,3 +210,18 @@ def test_headline_config_energy_per_site_within_north_star():
     # off-diagonal part is a sum of N positive terms times -Bx: E_loc <= diagonal energy
     diag = -(np.where(s[:, :-1] == s[:, 1:], 1.0, -1.0)).sum(axis=1)
     assert np.all(e < diag)
+
+
+def test_rccl_all_reduce_single_rank():
+    """The RCCL transport end to end with a one-rank communicator (the multi-rank case needs several GPUs
+    and is run by the driver's scaling bench; its host logic is covered by tests/test_distributed_cpu.py)."""
+    from rnnwavefunctions_amd import _lib
+    prm = trained_like(10, seed=1)
+    wf = make_wf(_lib.MODEL_GRU1D, 8, 10, prm)
+    uid = wf.comm_unique_id()
+    assert len(uid) == _lib.UNIQUE_ID_BYTES
+    wf.comm_init(uid, 0, 1)
+    m = np.array([1.5, -2.0, 64.0, 0.25])
+    assert np.array_equal(wf.allreduce_moments(m), m)
+    with pytest.raises(ValueError):
+        wf.comm_init(uid, 3, 2)
