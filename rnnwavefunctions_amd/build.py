@@ -16,7 +16,10 @@ LIB = os.path.join(LIBDIR, "librnnwf_hip.so")
 SOURCES = ["rnnwf_api.hip", "prnn.hip", "crnn.hip", "mdrnn.hip", "comm.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
-         "-ffp-contract=fast"]
+         "-ffp-contract=fast",
+         # keep MFMA accumulators in VGPRs: no v_accvgpr_read/write around the gate arithmetic and 4 waves/SIMD
+         # at num_units=50 (the option exists for every target of this clang, so the host pass accepts it too)
+         "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _newest_header():

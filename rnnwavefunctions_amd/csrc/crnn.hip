@@ -15,7 +15,7 @@ constexpr int64_t kChunk = (int64_t)1 << 20;
 
 template <int NFULL, int WAVES>
 struct CLaunch {
-    using L = GruLayout<float, NFULL, 4>;
+    using L = GruLayout<float, NFULL, 3>;
     static int blocks_per_cu(rnnwf_handle* h, const void* fn, int* out) {
         RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES));
         int nb = 0;
@@ -46,7 +46,7 @@ struct CLaunch {
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }
-    static std::vector<char> pack(const rnnwf_handle* h) { return pack_gru_image<float, NFULL, 4>(h); }
+    static std::vector<char> pack(const rnnwf_handle* h) { return pack_gru_image<float, NFULL, 3>(h); }
     static size_t hck_bytes_per_block() { return (size_t)L::KT * 64 * sizeof(float); }
 };
 

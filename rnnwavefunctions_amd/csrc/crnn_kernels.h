@@ -44,30 +44,36 @@ struct CrnnArgs {
     double2* contrib;          // [ns][2N]
 };
 
-// masked, renormalised sqrt-softmax amplitudes and phases of one site (ComplexRNNwavefunction.py:83-93,143-155)
-__device__ __forceinline__ void crnn_site(const float (&z)[4], int n, int N, int num_up, float& a0, float& a1,
-                                          float& ph0, float& ph1) {
-    const float m = fmaxf(z[0], z[1]);
-    const float e0 = expf(z[0] - m), e1 = expf(z[1] - m);
-    const float s = e0 + e1;
-    a0 = sqrtf(e0 / s);
-    a1 = sqrtf(e1 / s);
+// One site of the complex RNN (ComplexRNNwavefunction.py:83-93,143-157) from the head outputs
+// z = (amplitude logit difference, phase logit 0, phase logit 1):
+//   amplitudes a = sqrt(softmax)            -> log a_s = 1/2 log p_s
+//   for n >= N/2 the U(1) mask zeroes a spin value that would overshoot N/2 and l2-normalises: with both
+//   values allowed nothing changes (a0^2 + a1^2 = 1), with one allowed its amplitude becomes 1 (log 0) and the
+//   other 0 (log -inf)
+//   phase = pi * softsign(phase logit of the chosen spin)
+// la0/la1: log-amplitudes, w0: probability of spin 0 for the sampler, ph0/ph1: phases.
+__device__ __forceinline__ void crnn_site(const float (&z)[3], int n, int N, int num_up, float& la0, float& la1,
+                                          float& w0, float& ph0, float& ph1) {
+    float lp0, lp1;
+    log_softmax2(z[0], lp0, lp1);
+    la0 = 0.5f * lp0;
+    la1 = 0.5f * lp1;
+    w0 = prob0(z[0]);
     if (2 * n >= N) {                                    // n >= N/2: enforce zero magnetisation
         const int base = N / 2 - 1;
-        const int num_down = n - num_up;
-        a0 *= (base - num_down >= 0) ? 1.0f : 0.0f;      // [activations_down, activations_up]
-        a1 *= (base - num_up >= 0) ? 1.0f : 0.0f;
-        const float inv = 1.0f / sqrtf(fmaxf(a0 * a0 + a1 * a1, 1e-30f));   // tf.nn.l2_normalize(eps=1e-30)
-        a0 *= inv;
-        a1 *= inv;
+        const bool ok_down = base - (n - num_up) >= 0;   // [activations_down, activations_up]
+        const bool ok_up = base - num_up >= 0;
+        const float ninf = -__builtin_inff();
+        if (!ok_down) { la0 = ninf; w0 = 0.0f; if (ok_up) la1 = 0.0f; }
+        if (!ok_up) { la1 = ninf; if (ok_down) { la0 = 0.0f; w0 = 1.0f; } }
     }
-    ph0 = 3.14159265358979323846f * (z[2] / (1.0f + fabsf(z[2])));   // pi * softsign
-    ph1 = 3.14159265358979323846f * (z[3] / (1.0f + fabsf(z[3])));
+    ph0 = 3.14159265358979323846f * (z[1] / (1.0f + fabsf(z[1])));   // pi * softsign
+    ph1 = 3.14159265358979323846f * (z[2] / (1.0f + fabsf(z[2])));
 }
 
 template <int NFULL, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) crnn_base_kernel(CrnnArgs a) {
-    using C = GruCore<float, NFULL, 4>;
+    using C = GruCore<float, NFULL, 3>;
     constexpr int KT = C::KT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     C::stage(lds, a.wimg);
@@ -88,27 +94,25 @@ __global__ void __launch_bounds__(WAVES * 64) crnn_base_kernel(CrnnArgs a) {
         for (int n = 0; n < N; ++n) {
             if (!a.sampling && (n & 31) == 0) word = a.bits[(int64_t)(n >> 5) * a.ns + sc];
             C::step(lds, sig_in, h, lane);
-            float z[4];
+            float z[3];
             C::head(lds, h, lane, z);
-            float a0, a1, ph0, ph1;
-            crnn_site(z, n, N, num_up, a0, a1, ph0, ph1);
+            float la0, la1, w0, ph0, ph1;
+            crnn_site(z, n, N, num_up, la0, la1, w0, ph0, ph1);
             int sig;
             if (a.sampling) {
-                // tf.random.categorical(log(a^2)): class 0 iff u * (a0^2 + a1^2) < a0^2; a masked class has
-                // logit -inf and is skipped by TF's kernel - same outcome here since its a^2 is exactly 0
+                // tf.random.categorical(log(a^2)): class 0 iff u * total < a0^2; a masked class has logit -inf
+                // and is skipped by TF's kernel - same outcome here since its weight is exactly 0
                 const float u = philox_uniform(a.seed, a.step, (uint64_t)(a.sample_offset + sc), n);
-                const double w0 = (double)a0 * (double)a0, w1 = (double)a1 * (double)a1;
-                sig = ((double)u * (w0 + w1) < w0) ? 0 : 1;
+                sig = (u < w0) ? 0 : 1;
                 word |= (uint32_t)sig << (n & 31);
                 if (((n & 31) == 31 || n == N - 1) && valid && q == 0) a.bits[(int64_t)(n >> 5) * a.ns + s] = word;
                 if ((n & 31) == 31) word = 0;
             } else {
                 sig = (word >> (n & 31)) & 1;
             }
-            const float asel = sig ? a1 : a0, aoth = sig ? a0 : a1;
             if (a.cb && valid && q == 0)
-                a.cb[(int64_t)n * a.ns + s] = make_double2(re + (double)logf(aoth), im + (double)(sig ? ph0 : ph1));
-            re += (double)logf(asel);
+                a.cb[(int64_t)n * a.ns + s] = make_double2(re + (double)(sig ? la0 : la1), im + (double)(sig ? ph0 : ph1));
+            re += (double)(sig ? la1 : la0);
             im += (double)(sig ? ph1 : ph0);
             if (a.hck && n < N - 1) {
                 float* dst = reinterpret_cast<float*>(a.hck) + (((int64_t)n * a.nsb + sb) * KT) * 64 + lane;
@@ -214,7 +218,7 @@ __global__ void j1j2_tile_scan_kernel(const int32_t* cnt, int N, int32_t* tile_s
 
 template <int NFULL, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) crnn_swap_kernel(CrnnArgs a) {
-    using C = GruCore<float, NFULL, 4>;
+    using C = GruCore<float, NFULL, 3>;
     constexpr int KT = C::KT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     C::stage(lds, a.wimg);
@@ -254,12 +258,12 @@ __global__ void __launch_bounds__(WAVES * 64) crnn_swap_kernel(CrnnArgs a) {
         for (int n = lo + 1; n < N; ++n) {
             if ((n & 31) == 0) word = a.bits[(int64_t)(n >> 5) * a.ns + s];
             C::step(lds, sig_in, h, lane);
-            float z[4];
+            float z[3];
             C::head(lds, h, lane, z);
-            float a0, a1, ph0, ph1;
-            crnn_site(z, n, N, num_up, a0, a1, ph0, ph1);
+            float la0, la1, w0, ph0, ph1;
+            crnn_site(z, n, N, num_up, la0, la1, w0, ph0, ph1);
             const int sig = (int)((word >> (n & 31)) & 1) ^ (n == it.hi ? 1 : 0);
-            re += (double)logf(sig ? a1 : a0);
+            re += (double)(sig ? la1 : la0);
             im += (double)(sig ? ph1 : ph0);
             num_up += sig;
             sig_in = sig;

@@ -6,15 +6,60 @@
 //     c = tanh(x Wci + bci + r * (h Wch + bch));   h' = (1-u) c + u h
 // x is a one-hot (or the zero vector at the first site), so its matmuls are row selections that are
 // folded into the accumulator initialisation (tables BINIT / XC of layout.h).
+//
+// f32 activations run on v_exp_f32 (2^x): the packed image carries the gate rows pre-multiplied by
+// -log2(e) and the candidate rows by -2 log2(e) (pack.h, Act<float>), so that
+//     sigmoid(x) = 1 / (1 + 2^acc)          tanh(y) = 2 / (1 + 2^pre) - 1
+// need no multiply; h' = c + u (h - c).  f64 keeps unscaled rows and libm-grade exp/tanh.
 #pragma once
 #include "device.h"
 
 namespace rnnwf {
 
+template <typename T> struct Act;
+template <> struct Act<float> {
+    static constexpr double kGateScale = -1.44269504088896340736;      // acc = -x log2(e)
+    static constexpr double kCandScale = -2.88539008177792681472;      // pre = -2 y log2(e)
+    static __device__ __forceinline__ float sigmoid_scaled(float a) {
+        return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a));
+    }
+    static __device__ __forceinline__ float tanh_scaled(float p) {
+        return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(p)), -1.0f);
+    }
+};
+template <> struct Act<double> {
+    static constexpr double kGateScale = 1.0;
+    static constexpr double kCandScale = 1.0;
+    static __device__ __forceinline__ double sigmoid_scaled(double a) { return 1.0 / (1.0 + exp(-a)); }
+    static __device__ __forceinline__ double tanh_scaled(double p) { return tanh(p); }
+};
+
+// log-probabilities of a two-way softmax from the logit difference d = z1 - z0:
+//   log p1 = -log(1 + e^-d), log p0 = -log(1 + e^d); evaluated as  -[max(0, -+d)] - log(1 + e^-|d|)
+// (tf.nn.softmax's exp(z - max)/sum followed by log, 1DTFIM/RNNwavefunction.py:109,113-116, in one step).
+__device__ __forceinline__ void log_softmax2(float d, float& lp0, float& lp1) {
+    const float ad = fabsf(d);
+    const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * ad);
+    const float L = 0.693147180559945309f * __builtin_amdgcn_logf(1.0f + e);     // v_log_f32 = log2
+    lp0 = -L - fmaxf(d, 0.0f);
+    lp1 = -L - fmaxf(-d, 0.0f);
+}
+__device__ __forceinline__ void log_softmax2(double d, double& lp0, double& lp1) {
+    const double L = log1p(exp(-fabs(d)));
+    lp0 = -L - fmax(d, 0.0);
+    lp1 = -L - fmax(-d, 0.0);
+}
+// p0 = sigmoid(-d) for the sampler (tf.multinomial draws class 0 iff u * (p0 + p1) < p0)
+__device__ __forceinline__ float prob0(float d) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(1.44269504088896341f * d));
+}
+__device__ __forceinline__ double prob0(double d) { return 1.0 / (1.0 + exp(d)); }
+
 template <typename T, int NFULL, int NOUT>
 struct GruCore {
     using L = GruLayout<T, NFULL, NOUT>;
     using F = Frag<T>;
+    using A = Act<T>;
     using V4 = typename F::V4;
     using VA = typename F::VA;
     static constexpr int KT = L::KT, NT = L::NT, NG = L::NG, VW = L::VW;
@@ -67,24 +112,25 @@ struct GruCore {
             const V4 xc = *reinterpret_cast<const V4*>(x + (size_t)m * 16 * sizeof(T));
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const T rg = sigmoid_(acc[m][r]);
-                const T ug = sigmoid_(acc[NFULL + m][r]);
-                const T cc = tanh_(xc[r] + rg * acc[2 * NFULL + m][r]);
-                h[4 * m + r] = (T(1) - ug) * cc + ug * h[4 * m + r];
+                const T rg = A::sigmoid_scaled(acc[m][r]);
+                const T ug = A::sigmoid_scaled(acc[NFULL + m][r]);
+                const T cc = A::tanh_scaled(xc[r] + rg * acc[2 * NFULL + m][r]);
+                h[4 * m + r] = cc + ug * (h[4 * m + r] - cc);
             }
         }
         {
             const V4 xc = *reinterpret_cast<const V4*>(x + (size_t)NFULL * 16 * sizeof(T));
             const V4 a = acc[NT - 1];
-            const T rg = sigmoid_(a[0]);
-            const T ug = sigmoid_(a[1]);
-            const T cc = tanh_(xc[0] + rg * a[2]);
-            h[KT - 1] = (T(1) - ug) * cc + ug * h[KT - 1];
+            const T rg = A::sigmoid_scaled(a[0]);
+            const T ug = A::sigmoid_scaled(a[1]);
+            const T cc = A::tanh_scaled(xc[0] + rg * a[2]);
+            h[KT - 1] = cc + ug * (h[KT - 1] - cc);
         }
     }
 
-    // Dense(NOUT) on the new hidden state: z = h' Wd + bd, reduced over the four lane quarters.
-    // (tf.layers.Dense at 1DTFIM/RNNwavefunction.py:33,67,109; two heads for the cRNN, :42-43.)
+    // Output heads on the new hidden state, reduced over the four lane quarters.  Row 0 is the softmax
+    // logit DIFFERENCE d = z1 - z0 of tf.layers.Dense(2) (1DTFIM/RNNwavefunction.py:33,67,109) - a two-way
+    // softmax depends on nothing else; the cRNN adds the two phase logits (rows 1, 2; :42-43).
     static __device__ __forceinline__ void head(const char* lds, const T (&h)[KT], int lane, T (&z)[NOUT]) {
         const int q = lane >> 4;
         asm volatile("" ::: "memory");
@@ -102,15 +148,6 @@ struct GruCore {
             z[o] += __shfl_xor(z[o], 32);
             z[o] += bd[o];
         }
-    }
-
-    // softmax over two logits as tf.nn.softmax computes it: exp(z - max) / sum.
-    static __device__ __forceinline__ void softmax2(T z0, T z1, T& p0, T& p1) {
-        const T m = z0 > z1 ? z0 : z1;
-        const T e0 = exp_(z0 - m), e1 = exp_(z1 - m);
-        const T s = e0 + e1;
-        p0 = e0 / s;
-        p1 = e1 / s;
     }
 };
 

@@ -34,11 +34,10 @@ struct PrnnArgs {
     int64_t ntiles;              // flip pass: (N-1) * nsb
 };
 
-template <typename T> __device__ __forceinline__ double log_as_f64(T p) { return log((double)p); }
 
 template <typename T, int NFULL, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) prnn_base_kernel(PrnnArgs a) {
-    using C = GruCore<T, NFULL, 2>;
+    using C = GruCore<T, NFULL, 1>;
     constexpr int KT = C::KT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     C::stage(lds, a.wimg);
@@ -59,24 +58,24 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_base_kernel(PrnnArgs a) {
         for (int n = 0; n < N; ++n) {
             if (!a.sampling && (n & 31) == 0) word = a.bits[(int64_t)(n >> 5) * a.ns + sc];
             C::step(lds, sig_in, h, lane);
-            T z[2];
+            T z[1];
             C::head(lds, h, lane, z);
-            T p0, p1;
-            C::softmax2(z[0], z[1], p0, p1);
+            T lp0, lp1;
+            log_softmax2(z[0], lp0, lp1);
             int sig;
             if (a.sampling) {
-                // tf.multinomial(log p): first class whose running sum exceeds u * total
+                // tf.multinomial(log p): class 0 iff u * total < p0
                 const float u = philox_uniform(a.seed, a.step, (uint64_t)(a.sample_offset + sc), n);
-                sig = ((double)u * ((double)p0 + (double)p1) < (double)p0) ? 0 : 1;
+                sig = ((T)u < prob0(z[0])) ? 0 : 1;
                 word |= (uint32_t)sig << (n & 31);
                 if (((n & 31) == 31 || n == N - 1) && valid && q == 0) a.bits[(int64_t)(n >> 5) * a.ns + s] = word;
                 if ((n & 31) == 31) word = 0;
             } else {
                 sig = (word >> (n & 31)) & 1;
             }
-            const double lsel = log_as_f64(sig ? p1 : p0);
+            const double lsel = (double)(sig ? lp1 : lp0);
             if (a.lpq) {
-                const double loth = log_as_f64(sig ? p0 : p1);
+                const double loth = (double)(sig ? lp0 : lp1);
                 const int64_t row = a.row_of_pos ? a.row_of_pos[n] : n + 1;
                 if (valid && q == 0) a.lpq[row * a.ns + s] = cum + loth;
             }
@@ -97,7 +96,7 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_base_kernel(PrnnArgs a) {
 
 template <typename T, int NFULL, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) prnn_flip_kernel(PrnnArgs a) {
-    using C = GruCore<T, NFULL, 2>;
+    using C = GruCore<T, NFULL, 1>;
     constexpr int KT = C::KT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     C::stage(lds, a.wimg);
@@ -125,12 +124,12 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_flip_kernel(PrnnArgs a) {
         for (int n = i + 1; n < N; ++n) {
             if ((n & 31) == 0) word = a.bits[(int64_t)(n >> 5) * a.ns + sc];
             C::step(lds, sig_in, h, lane);
-            T z[2];
+            T z[1];
             C::head(lds, h, lane, z);
-            T p0, p1;
-            C::softmax2(z[0], z[1], p0, p1);
+            T lp0, lp1;
+            log_softmax2(z[0], lp0, lp1);
             const int sig = (word >> (n & 31)) & 1;
-            lp += log_as_f64(sig ? p1 : p0);
+            lp += (double)(sig ? lp1 : lp0);
             sig_in = sig;
         }
         if (valid && q == 0) {

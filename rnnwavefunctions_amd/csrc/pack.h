@@ -14,7 +14,18 @@ inline const std::vector<double>& pv(const rnnwf_handle* h, const std::string& n
     return h->params.at(name).value;
 }
 
+// Row scales that let the f32 kernels feed the accumulator straight into v_exp_f32 (see gru_core.h, Act<T>).
+template <typename T> struct PackScale;
+template <> struct PackScale<float> {
+    static constexpr double gate = -1.44269504088896340736, cand = -2.88539008177792681472;
+};
+template <> struct PackScale<double> {
+    static constexpr double gate = 1.0, cand = 1.0;
+};
+
 // Packs the single-layer cuDNN-compatible GRU + Dense head(s).
+// NOUT = 1: positive RNN (head row = softmax logit difference z1 - z0);
+// NOUT = 3: complex RNN (amplitude logit difference, phase logit 0, phase logit 1).
 template <typename T, int NFULL, int NOUT>
 std::vector<char> pack_gru_image(const rnnwf_handle* h) {
     using L = GruLayout<T, NFULL, NOUT>;
@@ -39,11 +50,12 @@ std::vector<char> pack_gru_image(const rnnwf_handle* h) {
         }
         return unit < H;
     };
-    auto wt = [&](int gate, int unit, int k) -> double {  // W^T[row(gate,unit)][k]
+    const double sg = PackScale<T>::gate, sc = PackScale<T>::cand;
+    auto wt = [&](int gate, int unit, int k) -> double {  // (scaled) W^T[row(gate,unit)][k]
         if (k >= H) return 0.0;
-        if (gate == 0) return Wg[(size_t)(2 + k) * 2 * H + unit];
-        if (gate == 1) return Wg[(size_t)(2 + k) * 2 * H + H + unit];
-        return Wch[(size_t)k * H + unit];
+        if (gate == 0) return sg * Wg[(size_t)(2 + k) * 2 * H + unit];
+        if (gate == 1) return sg * Wg[(size_t)(2 + k) * 2 * H + H + unit];
+        return sc * Wch[(size_t)k * H + unit];
     };
     T* avec = reinterpret_cast<T*>(img.data() + L::OFF_AVEC);
     T* arem = reinterpret_cast<T*>(img.data() + L::OFF_AREM);
@@ -70,9 +82,9 @@ std::vector<char> pack_gru_image(const rnnwf_handle* h) {
                     int gate, unit;
                     if (!decode(tile, q, r, gate, unit)) continue;
                     double b;
-                    if (gate == 0) b = bg[unit] + (v ? Wg[(size_t)(v - 1) * 2 * H + unit] : 0.0);
-                    else if (gate == 1) b = bg[H + unit] + (v ? Wg[(size_t)(v - 1) * 2 * H + H + unit] : 0.0);
-                    else b = bch[unit];
+                    if (gate == 0) b = sg * (bg[unit] + (v ? Wg[(size_t)(v - 1) * 2 * H + unit] : 0.0));
+                    else if (gate == 1) b = sg * (bg[H + unit] + (v ? Wg[(size_t)(v - 1) * 2 * H + H + unit] : 0.0));
+                    else b = sc * bch[unit];
                     binit[tile * 16 + q * 4 + r] = (T)b;
                 }
         for (int m = 0; m <= NFULL; ++m)
@@ -81,22 +93,29 @@ std::vector<char> pack_gru_image(const rnnwf_handle* h) {
                     if (m == NFULL && r != 0) continue;
                     const int unit = m < NFULL ? 16 * m + 4 * r + q : 16 * NFULL + q;
                     if (unit >= H) continue;
-                    xc[m * 16 + q * 4 + r] = (T)(bci[unit] + (v ? Wci[(size_t)(v - 1) * H + unit] : 0.0));
+                    xc[m * 16 + q * 4 + r] = (T)(sc * (bci[unit] + (v ? Wci[(size_t)(v - 1) * H + unit] : 0.0)));
                 }
     }
     T* wd = reinterpret_cast<T*>(img.data() + L::OFF_WD);
     T* bd = reinterpret_cast<T*>(img.data() + L::OFF_BD);
-    const char* heads[2] = {NOUT == 2 ? "wf_dense" : "wf_dense_ampl", "wf_dense_phase"};
-    for (int hd = 0; hd < NOUT / 2; ++hd) {
-        const auto& Wd = pv(h, std::string(heads[hd]) + "/kernel");  // [H, 2]
-        const auto& bdv = pv(h, std::string(heads[hd]) + "/bias");   // [2]
-        for (int kt = 0; kt < L::KT; ++kt)
-            for (int q = 0; q < 4; ++q) {
-                const int unit = 4 * kt + q;
-                if (unit >= H) continue;
-                for (int o = 0; o < 2; ++o) wd[(kt * 4 + q) * NOUT + hd * 2 + o] = (T)Wd[(size_t)unit * 2 + o];
+    const auto& Wd = pv(h, std::string(NOUT == 1 ? "wf_dense" : "wf_dense_ampl") + "/kernel");   // [H, 2]
+    const auto& bdv = pv(h, std::string(NOUT == 1 ? "wf_dense" : "wf_dense_ampl") + "/bias");    // [2]
+    for (int kt = 0; kt < L::KT; ++kt)
+        for (int q = 0; q < 4; ++q) {
+            const int unit = 4 * kt + q;
+            if (unit >= H) continue;
+            wd[(kt * 4 + q) * NOUT] = (T)(Wd[(size_t)unit * 2 + 1] - Wd[(size_t)unit * 2]);
+            if (NOUT == 3) {
+                const auto& Wp = pv(h, "wf_dense_phase/kernel");
+                wd[(kt * 4 + q) * NOUT + 1] = (T)Wp[(size_t)unit * 2];
+                wd[(kt * 4 + q) * NOUT + 2] = (T)Wp[(size_t)unit * 2 + 1];
             }
-        for (int o = 0; o < 2; ++o) bd[hd * 2 + o] = (T)bdv[o];
+        }
+    bd[0] = (T)(bdv[1] - bdv[0]);
+    if (NOUT == 3) {
+        const auto& bp = pv(h, "wf_dense_phase/bias");
+        bd[1] = (T)bp[0];
+        bd[2] = (T)bp[1];
     }
     return img;
 }

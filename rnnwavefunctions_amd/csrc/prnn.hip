@@ -15,7 +15,7 @@ constexpr int64_t kLogProbChunk = (int64_t)1 << 20;
 
 template <typename T, int NFULL, int WAVES>
 struct Launch {
-    using L = GruLayout<T, NFULL, 2>;
+    using L = GruLayout<T, NFULL, 1>;
     static int blocks_per_cu(rnnwf_handle* h, const void* fn, int* out) {
         RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES));
         int nb = 0;
@@ -45,7 +45,7 @@ struct Launch {
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }
-    static std::vector<char> pack(const rnnwf_handle* h) { return pack_gru_image<T, NFULL, 2>(h); }
+    static std::vector<char> pack(const rnnwf_handle* h) { return pack_gru_image<T, NFULL, 1>(h); }
     static size_t hck_bytes_per_block() { return (size_t)L::KT * 64 * sizeof(T); }
     static double mfma_flops_per_step() { return (double)L::NT * L::KT * 2048.0; }
 };
