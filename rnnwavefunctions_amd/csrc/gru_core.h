@@ -74,7 +74,9 @@ struct GruCore {
     }
 
     // h[kt] of lane (c, q) holds unit 4 kt + q of chain c.  sig: input spin of this step (-1: zero vector).
-    static __device__ __forceinline__ void step(const char* lds, int sig, T (&h)[KT], int lane) {
+    // `ablate` (diagnostics, RNNWF_ABLATE): 1 skips the MFMAs, 2 the gate arithmetic - used to measure that on
+    // gfx950 f32 MFMA time and VALU time ADD (no overlap across the waves of a SIMD): see DESIGN.md section 6.
+    static __device__ __forceinline__ void step(const char* lds, int sig, T (&h)[KT], int lane, int ablate = 0) {
         const int q = lane >> 4;
         // The weight image never changes, so the compiler would hoist all ~NT*KT fragment loads out of
         // the site loop and pin them in registers (1 wave/SIMD).  Re-read them from LDS every step.
@@ -86,6 +88,7 @@ struct GruCore {
             for (int t = 0; t < NT; ++t) acc[t] = *reinterpret_cast<const V4*>(b + (size_t)t * 16 * sizeof(T));
         }
         const VA* av = reinterpret_cast<const VA*>(lds + L::OFF_AVEC) + lane;
+        if (!(ablate & 1)) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
 #pragma unroll
@@ -105,6 +108,12 @@ struct GruCore {
             const T* ar = reinterpret_cast<const T*>(lds + L::OFF_AREM) + lane;
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = F::mfma(ar[t * 64], h[KT - 1], acc[t]);
+        }
+        }
+        if (ablate & 2) {      // keep the accumulators alive without the gate arithmetic
+#pragma unroll
+            for (int t = 0; t < NT; ++t) asm volatile("" :: "v"(acc[t]));
+            return;
         }
         const char* x = lds + L::OFF_XC + (size_t)(sig + 1) * L::SZ_XC_VARIANT + (size_t)q * 4 * sizeof(T);
 #pragma unroll
@@ -134,13 +143,13 @@ struct GruCore {
     static __device__ __forceinline__ void head(const char* lds, const T (&h)[KT], int lane, T (&z)[NOUT]) {
         const int q = lane >> 4;
         asm volatile("" ::: "memory");
-        const T* wd = reinterpret_cast<const T*>(lds + L::OFF_WD) + q * NOUT;
+        const T* wd = reinterpret_cast<const T*>(lds + L::OFF_WD) + q * L::WD_Q;
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) z[o] = T(0);
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-            for (int o = 0; o < NOUT; ++o) z[o] += h[kt] * wd[kt * 4 * NOUT + o];
+            for (int o = 0; o < NOUT; ++o) z[o] += h[kt] * wd[kt * NOUT + o];
         const T* bd = reinterpret_cast<const T*>(lds + L::OFF_BD);
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) {

@@ -32,6 +32,7 @@ struct PrnnArgs {
     int64_t sample_offset;
     int32_t sampling;            // 1: draw spins, 0: read them from bits
     int64_t ntiles;              // flip pass: (N-1) * nsb
+    int32_t ablate;              // diagnostics only (RNNWF_ABLATE): 1 skip MFMAs, 2 skip gate arithmetic, 4 skip head
 };
 
 
@@ -118,18 +119,21 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_flip_kernel(PrnnArgs a) {
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) h[kt] = src[kt * 64];
         }
-        uint32_t word = a.bits[(int64_t)(i >> 5) * a.ns + sc];
-        int sig_in = 1 - (int)((word >> (i & 31)) & 1);   // the flipped spin feeds site i+1
+        // Site n consumes spin n-1 and its head needs spin n: one coalesced 4-byte load per site, fetched a site
+        // ahead (branch-free loop body, so the scheduler can interleave MFMA and VALU work across the whole step).
+        auto spin = [&](int n) { return (int)((a.bits[(int64_t)(n >> 5) * a.ns + sc] >> (n & 31)) & 1); };
+        int sig_in = 1 - spin(i);                  // the flipped spin feeds site i+1
         double lp = 0.0;
         for (int n = i + 1; n < N; ++n) {
-            if ((n & 31) == 0) word = a.bits[(int64_t)(n >> 5) * a.ns + sc];
-            C::step(lds, sig_in, h, lane);
-            T z[1];
-            C::head(lds, h, lane, z);
-            T lp0, lp1;
-            log_softmax2(z[0], lp0, lp1);
-            const int sig = (word >> (n & 31)) & 1;
-            lp += (double)(sig ? lp1 : lp0);
+            const int sig = spin(n);
+            C::step(lds, sig_in, h, lane, a.ablate);
+            if (!(a.ablate & 4)) {
+                T z[1];
+                C::head(lds, h, lane, z);
+                T lp0, lp1;
+                log_softmax2(z[0], lp0, lp1);
+                lp += (double)(sig ? lp1 : lp0);
+            }
             sig_in = sig;
         }
         if (valid && q == 0) {

@@ -22,7 +22,7 @@ constexpr int kChains = 16;  // chains (spin configurations) per wave: the N dim
 template <typename T, int NFULL_, int NOUT_>
 struct GruLayout {
     static constexpr int NFULL = NFULL_;
-    static constexpr int NOUT = NOUT_;              // 2: positive RNN head; 4: amplitude + phase heads
+    static constexpr int NOUT = NOUT_;              // head rows: 1 (pRNN logit difference), 3 (cRNN: + 2 phase logits)
     static constexpr int HP = 16 * NFULL + 4;       // padded hidden size
     static constexpr int KT = 4 * NFULL + 1;        // k-steps of 4
     static constexpr int NT = 3 * NFULL + 1;        // 16-row output tiles
@@ -35,8 +35,9 @@ struct GruLayout {
     static constexpr size_t SZ_BINIT_VARIANT = ((size_t)NT * 16 + 4) * sizeof(T);    // +4 T pad: de-alias banks
     static constexpr size_t OFF_XC = OFF_BINIT + 3 * SZ_BINIT_VARIANT;               // [3][NFULL+1][4][4] T
     static constexpr size_t SZ_XC_VARIANT = ((size_t)(NFULL + 1) * 16 + 4) * sizeof(T);
-    static constexpr size_t OFF_WD = OFF_XC + 3 * SZ_XC_VARIANT;                     // [KT][4 q][NOUT] T
-    static constexpr size_t OFF_BD = OFF_WD + (size_t)KT * 4 * NOUT * sizeof(T);     // [NOUT] T (padded to 32 B)
+    static constexpr int WD_Q = ((NOUT * KT + 3) / 4) * 4;                           // head weights per lane quarter
+    static constexpr size_t OFF_WD = OFF_XC + 3 * SZ_XC_VARIANT;                     // [4 q][KT][NOUT] T, WD_Q per q
+    static constexpr size_t OFF_BD = OFF_WD + (size_t)4 * WD_Q * sizeof(T);          // [NOUT] T (padded to 32 B)
     static constexpr size_t BYTES = ((OFF_BD + 32 + 15) / 16) * 16;
 };
 

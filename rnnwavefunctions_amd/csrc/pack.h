@@ -104,11 +104,11 @@ std::vector<char> pack_gru_image(const rnnwf_handle* h) {
         for (int q = 0; q < 4; ++q) {
             const int unit = 4 * kt + q;
             if (unit >= H) continue;
-            wd[(kt * 4 + q) * NOUT] = (T)(Wd[(size_t)unit * 2 + 1] - Wd[(size_t)unit * 2]);
+            wd[q * L::WD_Q + kt * NOUT] = (T)(Wd[(size_t)unit * 2 + 1] - Wd[(size_t)unit * 2]);
             if (NOUT == 3) {
                 const auto& Wp = pv(h, "wf_dense_phase/kernel");
-                wd[(kt * 4 + q) * NOUT + 1] = (T)Wp[(size_t)unit * 2];
-                wd[(kt * 4 + q) * NOUT + 2] = (T)Wp[(size_t)unit * 2 + 1];
+                wd[q * L::WD_Q + kt * NOUT + 1] = (T)Wp[(size_t)unit * 2];
+                wd[q * L::WD_Q + kt * NOUT + 2] = (T)Wp[(size_t)unit * 2 + 1];
             }
         }
     bd[0] = (T)(bdv[1] - bdv[0]);

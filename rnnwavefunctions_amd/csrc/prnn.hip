@@ -1,6 +1,7 @@
 // prnn.hip - host side of the positive GRU RNN wave function (models GRU1D, GRU1D_PARITY, GRU1D_F64):
 // sample / log_probability / fused TFIM local energies / fused VMC step.
 #include <algorithm>
+#include <cstdlib>
 
 #include "gru_kernels.h"
 #include "models.h"
@@ -132,6 +133,7 @@ int eloc_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
     if (Bx != 0.0 && N > 1) {
         a.ntiles = (int64_t)(N - 1) * nsb;
         a.sampling = 0;
+        if (const char* e = getenv("RNNWF_ABLATE")) a.ablate = atoi(e);   // diagnostics only
         if (int rc = launch_flip(h, a)) return rc;
         h->work[0] += (double)ns * N * (N - 1) / 2.0;
         h->work[1] += (double)nsb * N * (N - 1) / 2.0 * mfma_flops_per_step(h);
