@@ -46,6 +46,9 @@ PROTOTYPES = {
     "rnnwf_tfim2d_eloc": (C.c_int, [_P, _I32P, _I64, _F64P, _F64, _F64P, _F64P]),
     "rnnwf_j1j2_eloc": (C.c_int, [_P, _I32P, _I64, _F64P, _F64P, _F64P, _I32, _I32, _F32P, C.POINTER(_I64)]),
     "rnnwf_vmc_step": (C.c_int, [_P, _I64, _U64, _U64, _I64, _F64P, _I64, _I32P, _P, _F64P]),
+    "rnnwf_vmc_gradient": (C.c_int, [_P, _F64, _F64]),
+    "rnnwf_get_grad": (C.c_int, [_P, C.c_char_p, _P, _I64, _I32]),
+    "rnnwf_allreduce_grads": (C.c_int, [_P]),
     "rnnwf_comm_unique_id": (C.c_int, [_P]),
     "rnnwf_comm_init": (C.c_int, [_P, _P, _I32, _I32]),
     "rnnwf_allreduce_moments": (C.c_int, [_P, _F64P, _I32]),
@@ -243,6 +246,20 @@ class NativeWavefunction:
             out["samples"] = smp
         if want_eloc:
             out["eloc"] = el.view(np.complex64)[:, 0] if self.model == MODEL_CRNN_U1 else el
+        return out
+
+    # -- gradient of the VMC cost -----------------------------------------------------------------
+    def vmc_gradient(self, mean_energy, norm, shapes, allreduce=False):
+        """Gradient of mean(logP*E) - mean(E)*mean(logP) on the batch of the last vmc_step.
+        shapes: {tf_name (without scope): shape}; returns {tf_name: float64 ndarray}."""
+        self._check(self.lib.rnnwf_vmc_gradient(self.h, float(mean_energy), float(norm)))
+        if allreduce:
+            self._check(self.lib.rnnwf_allreduce_grads(self.h))
+        out = {}
+        for name, shape in shapes.items():
+            g = np.empty(shape, dtype=np.float64)
+            self._check(self.lib.rnnwf_get_grad(self.h, name.encode(), g.ctypes.data_as(_P), g.size, F64))
+            out[name] = g
         return out
 
     # -- multi-GPU --------------------------------------------------------------------------------

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "librnnwf_hip.so")
-SOURCES = ["rnnwf_api.hip", "prnn.hip", "crnn.hip", "mdrnn.hip", "comm.hip"]
+SOURCES = ["rnnwf_api.hip", "prnn.hip", "crnn.hip", "mdrnn.hip", "grad.hip", "comm.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
          "-ffp-contract=fast",

@@ -2,7 +2,9 @@
 // librccl.so is loaded lazily with dlopen so that single-GPU use never pays for it.
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstring>
+#include <vector>
 
 #include "models.h"
 
@@ -83,6 +85,30 @@ extern "C" int rnnwf_allreduce_moments(rnnwf_handle* h, double* moments, int32_t
     RNNWF_HIP(h, hipMemcpyAsync(h->pinned, h->moments.p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     RNNWF_HIP(h, hipStreamSynchronize(h->stream));
     memcpy(moments, h->pinned, (size_t)count * sizeof(double));
+    return RNNWF_OK;
+}
+
+extern "C" int rnnwf_allreduce_grads(rnnwf_handle* h) {
+    if (!h) return RNNWF_ERR_INVALID;
+    if (h->grads.empty()) return h->fail(RNNWF_ERR_STATE, "rnnwf_allreduce_grads: no gradients (call rnnwf_vmc_gradient first)");
+    if (!h->comm) {
+        if (h->nranks == 1) return RNNWF_OK;
+        return h->fail(RNNWF_ERR_STATE, "rnnwf_allreduce_grads: communicator not initialised");
+    }
+    RNNWF_HIP(h, hipSetDevice(h->cfg.device));
+    size_t total = 0;
+    for (auto& kv : h->grads) total += kv.second.size();      // std::map: same order on every rank
+    std::vector<double> flat(total);
+    size_t off = 0;
+    for (auto& kv : h->grads) { std::copy(kv.second.begin(), kv.second.end(), flat.begin() + off); off += kv.second.size(); }
+    if (int rc = rnnwf::ensure(h, h->gradQ, total * sizeof(double))) return rc;   // scratch (P/Q are dead after the GEMM)
+    RNNWF_HIP(h, hipMemcpyAsync(h->gradQ.p, flat.data(), total * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    const int rc = g_rccl.all_reduce(h->gradQ.p, h->gradQ.p, total, kNcclFloat64, kNcclSum, h->comm, h->stream);
+    if (rc != 0) return h->fail(RNNWF_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.error_string ? g_rccl.error_string(rc) : "?");
+    RNNWF_HIP(h, hipMemcpyAsync(flat.data(), h->gradQ.p, total * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+    off = 0;
+    for (auto& kv : h->grads) { std::copy(flat.begin() + off, flat.begin() + off + kv.second.size(), kv.second.begin()); off += kv.second.size(); }
     return RNNWF_OK;
 }
 

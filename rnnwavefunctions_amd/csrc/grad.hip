@@ -1,0 +1,196 @@
+// grad.hip - host side of the VMC-cost gradient for the positive GRU RNN (f32, single layer):
+// rnnwf_vmc_gradient / rnnwf_get_grad / rnnwf_allreduce_grads.
+#include <algorithm>
+
+#include "grad_kernels.h"
+#include "models.h"
+#include "pack.h"
+
+using namespace rnnwf;
+
+namespace {
+
+template <int NFULL, int WAVES>
+struct GLaunch {
+    using L = GruLayout<float, NFULL, 1>;
+    using G = GradLayout<NFULL>;
+
+    static std::vector<char> pack_bwd(const rnnwf_handle* h) {
+        const int H = h->H;
+        std::vector<char> img(G::BWD_BYTES, 0);
+        const std::string pre = kGruPre;
+        const auto& Wg = pv(h, pre + "gates/kernel");                         // [2+H, 2H]
+        const auto& Wch = pv(h, pre + "candidate/hidden_projection/kernel");  // [H, H]
+        float* A = reinterpret_cast<float*>(img.data());
+        for (int t = 0; t < G::NTO; ++t)
+            for (int row = 0; row < 16; ++row) {
+                const int q = row >> 2, r = row & 3;
+                if (t == NFULL && r != 0) continue;
+                const int kout = t < NFULL ? 16 * t + 4 * r + q : 16 * NFULL + q;   // hidden unit receiving dL/dh
+                if (kout >= H) continue;
+                for (int kq = 0; kq < 4; ++kq) {
+                    const int lane = (kq << 4) | row;
+                    for (int kk = 0; kk < G::KB; ++kk) {
+                        const int g = kk / G::KT, kt = kk % G::KT, u = 4 * kt + kq;  // pre-activation (gate g, unit u)
+                        if (u >= H) continue;
+                        double w;
+                        if (g == 0) w = Wg[(size_t)(2 + kout) * 2 * H + u];
+                        else if (g == 1) w = Wg[(size_t)(2 + kout) * 2 * H + H + u];
+                        else w = Wch[(size_t)kout * H + u];
+                        A[(((size_t)t * G::KBG + kk / 4) * 64 + lane) * 4 + (kk & 3)] = (float)w;
+                    }
+                }
+            }
+        return img;
+    }
+
+    static int run(rnnwf_handle* h, GradArgs a, int64_t R, float* dW) {
+        static int bpc = 0;
+        const void* fn = (const void*)prnn_bwd_kernel<NFULL, WAVES>;
+        const size_t lds = L::BYTES + G::BWD_BYTES;
+        if (!bpc) {
+            RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            RNNWF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, WAVES * 64, lds));
+            bpc = std::max(bpc, 1);
+        }
+        const int64_t need = (a.nsb + WAVES - 1) / WAVES;
+        const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
+        prnn_bwd_kernel<NFULL, WAVES><<<grid, WAVES * 64, lds, h->stream>>>(a);
+        RNNWF_HIP(h, hipGetLastError());
+        int64_t rpb = (R + (int64_t)h->cu_count * 4 - 1) / ((int64_t)h->cu_count * 4);
+        rpb = std::max<int64_t>(64, ((rpb + 3) / 4) * 4);
+        const unsigned gblocks = (unsigned)((R + rpb - 1) / rpb);
+        tn_gemm_kernel<G::PCOLS / 16, G::QCOLS / 16><<<gblocks, 256, 0, h->stream>>>(a.P, a.Q, R, rpb, dW);
+        RNNWF_HIP(h, hipGetLastError());
+        return 0;
+    }
+
+    // dW image [PCOLS][QCOLS] + head gradients -> TF-named gradient arrays
+    static void unpack(rnnwf_handle* h, const float* dW, const float* hg) {
+        const int H = h->H;
+        const int NT = G::NT;
+        auto col_of_unit = [&](int k) { return k < 16 * NFULL ? 16 * (k / 16) + 4 * (k % 4) + (k % 16) / 4 : 16 * NFULL + 4 * (k - 16 * NFULL); };
+        const int xcol = 16 * NFULL + 1, onecol = 16 * NFULL + 3;
+        auto at = [&](int prow, int col) { return (double)dW[(size_t)prow * G::QCOLS + col]; };
+        const std::string pre = kGruPre;
+        auto& gWg = h->grads[pre + "gates/kernel"];
+        auto& gbg = h->grads[pre + "gates/bias"];
+        auto& gWci = h->grads[pre + "candidate/input_projection/kernel"];
+        auto& gbci = h->grads[pre + "candidate/input_projection/bias"];
+        auto& gWch = h->grads[pre + "candidate/hidden_projection/kernel"];
+        auto& gbch = h->grads[pre + "candidate/hidden_projection/bias"];
+        auto& gWd = h->grads["wf_dense/kernel"];
+        auto& gbd = h->grads["wf_dense/bias"];
+        gWg.assign((size_t)(2 + H) * 2 * H, 0.0); gbg.assign(2 * H, 0.0);
+        gWci.assign((size_t)2 * H, 0.0); gbci.assign(H, 0.0);
+        gWch.assign((size_t)H * H, 0.0); gbch.assign(H, 0.0);
+        gWd.assign((size_t)H * 2, 0.0); gbd.assign(2, 0.0);
+        for (int u = 0; u < H; ++u) {
+            const int m = u / 16, r = (u % 16) / 4, q = u % 4;
+            const bool full = u < 16 * NFULL;
+            const int uq = u - 16 * NFULL;                       // remainder units: lane quarter = uq
+            int prow[3];
+            for (int g = 0; g < 3; ++g) prow[g] = full ? (g * NFULL + m) * 16 + 4 * q + r : (NT - 1) * 16 + 4 * uq + g;
+            const int prow_y = full ? (NT + m) * 16 + 4 * q + r : (NT + NFULL) * 16 + 4 * uq;
+            for (int k = 0; k < H; ++k) {
+                const int col = col_of_unit(k);
+                gWg[(size_t)(2 + k) * 2 * H + u] = at(prow[0], col);
+                gWg[(size_t)(2 + k) * 2 * H + H + u] = at(prow[1], col);
+                gWch[(size_t)k * H + u] = at(prow[2], col);
+            }
+            for (int sgm = 0; sgm < 2; ++sgm) {
+                gWg[(size_t)sgm * 2 * H + u] = at(prow[0], xcol + sgm);
+                gWg[(size_t)sgm * 2 * H + H + u] = at(prow[1], xcol + sgm);
+                gWci[(size_t)sgm * H + u] = at(prow_y, xcol + sgm);
+            }
+            gbg[u] = at(prow[0], onecol);
+            gbg[H + u] = at(prow[1], onecol);
+            gbch[u] = at(prow[2], onecol);
+            gbci[u] = at(prow_y, onecol);
+            // head: the image holds the logit difference z1 - z0, so d/dWd[:,1] = +v and d/dWd[:,0] = -v
+            const double v = hg[u];          // slot 4 kt + q == unit index
+            gWd[(size_t)u * 2 + 1] = v;
+            gWd[(size_t)u * 2] = -v;
+        }
+        gbd[1] = hg[4 * G::KT];
+        gbd[0] = -hg[4 * G::KT];
+    }
+};
+
+#define GRAD_DISPATCH(h, EXPR)                                  \
+    do {                                                        \
+        switch ((h)->NFULL) {                                   \
+            case 1: { using K = GLaunch<1, 4>; EXPR; }          \
+            case 2: { using K = GLaunch<2, 4>; EXPR; }          \
+            case 3: { using K = GLaunch<3, 4>; EXPR; }          \
+            case 4: { using K = GLaunch<4, 4>; EXPR; }          \
+        }                                                       \
+    } while (0)
+
+}  // namespace
+
+extern "C" int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double norm) {
+    if (!h) return RNNWF_ERR_INVALID;
+    if (!h->committed) return h->fail(RNNWF_ERR_STATE, "parameters not committed");
+    if (h->model != RNNWF_MODEL_GRU1D)
+        return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: implemented for the 1D positive GRU RNN (f32) only so far");
+    if (h->NFULL > 4) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: num_units > 68 not implemented yet");
+    if (h->last_ns <= 0 || !h->last_has_ckpt)
+        return h->fail(RNNWF_ERR_STATE, "rnnwf_vmc_gradient: call rnnwf_vmc_step first (its samples, states and E_loc are reused)");
+    if (!(norm > 0)) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: norm must be positive");
+    RNNWF_HIP(h, hipSetDevice(h->cfg.device));
+    const int N = h->N;
+    const int64_t ns = h->last_ns, R = ns * N;
+    int pcols = 0, qcols = 0, hgn = 0;
+    GRAD_DISPATCH(h, { pcols = K::G::PCOLS; qcols = K::G::QCOLS; hgn = K::G::HEAD_GRADS; break; });
+    if (!h->wbwd.p) {
+        std::vector<char> img;
+        GRAD_DISPATCH(h, { img = K::pack_bwd(h); break; });
+        if (int rc = ensure(h, h->wbwd, img.size())) return rc;
+        RNNWF_HIP(h, hipMemcpyAsync(h->wbwd.p, img.data(), img.size(), hipMemcpyHostToDevice, h->stream));
+        RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    if (int rc = ensure(h, h->gradP, (size_t)R * pcols * 4)) return rc;
+    if (int rc = ensure(h, h->gradQ, (size_t)R * qcols * 4)) return rc;
+    const size_t dw_floats = (size_t)pcols * qcols + hgn;
+    if (int rc = ensure(h, h->gradW, dw_floats * 4)) return rc;
+    RNNWF_HIP(h, hipMemsetAsync(h->gradW.p, 0, dw_floats * 4, h->stream));
+    GradArgs a{};
+    a.wimg = h->wimg.p;
+    a.wbwd = h->wbwd.p;
+    a.N = N;
+    a.ns = ns;
+    a.nsb = (ns + kChains - 1) / kChains;
+    a.bits = (const uint32_t*)h->bits.p;
+    a.hck = (const float*)h->hck.p;
+    a.eloc = (const double*)h->eloc.p;
+    a.mean_e = mean_energy;
+    a.inv_norm = 1.0 / norm;
+    a.P = (float*)h->gradP.p;
+    a.Q = (float*)h->gradQ.p;
+    a.head_grad = (float*)h->gradW.p + (size_t)pcols * qcols;
+    GRAD_DISPATCH(h, { if (int rc = K::run(h, a, R, (float*)h->gradW.p)) return rc; break; });
+    std::vector<float> host(dw_floats);
+    RNNWF_HIP(h, hipMemcpyAsync(host.data(), h->gradW.p, dw_floats * 4, hipMemcpyDeviceToHost, h->stream));
+    RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+    GRAD_DISPATCH(h, { K::unpack(h, host.data(), host.data() + (size_t)pcols * qcols); break; });
+    return RNNWF_OK;
+}
+
+extern "C" int rnnwf_get_grad(rnnwf_handle* h, const char* name, void* data, int64_t count, int32_t dtype) {
+    if (!h || !name || !data) return RNNWF_ERR_INVALID;
+    auto it = h->grads.find(name);
+    if (it == h->grads.end()) return h->fail(RNNWF_ERR_STATE, "no gradient for '%s' (call rnnwf_vmc_gradient first)", name);
+    if ((int64_t)it->second.size() != count)
+        return h->fail(RNNWF_ERR_INVALID, "gradient '%s' has %lld elements, caller passed %lld", name,
+                       (long long)it->second.size(), (long long)count);
+    if (dtype == RNNWF_F32) for (int64_t i = 0; i < count; ++i) ((float*)data)[i] = (float)it->second[i];
+    else if (dtype == RNNWF_F64) for (int64_t i = 0; i < count; ++i) ((double*)data)[i] = it->second[i];
+    else return h->fail(RNNWF_ERR_INVALID, "unknown dtype %d", dtype);
+    return RNNWF_OK;
+}
+
+// the weight image changed: the backward image must be rebuilt on the next gradient call
+void rnnwf::grad_invalidate(rnnwf_handle* h) {
+    if (h->wbwd.p) { hipFree(h->wbwd.p); h->wbwd.p = nullptr; h->wbwd.cap = 0; }
+}

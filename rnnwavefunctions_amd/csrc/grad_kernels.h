@@ -1,0 +1,221 @@
+// grad_kernels.h - gradient of the VMC cost for the positive GRU RNN.
+//
+// Reference: cost = mean(log P * E_loc) - mean(E_loc) * mean(log P), differentiated by TensorFlow
+// (1DTFIM/TrainingRNN_1DTFIM.py:151-166), i.e.  grad = sum_s w_s dlog P(s)/dtheta,  w_s = (E_s - mean E) / ns.
+//
+//   prnn_bwd_kernel : back-propagation through time for 16 chains per wave, site N-1 down to 0.  Each site
+//                     re-computes its gates from the stored input state (hck, written by the base pass), forms
+//                     the pre-activation gradients (VALU) and propagates dL/dh through the transposed weights
+//                     on the f32 MFMA (same lane layout trick as the forward: the C/D fragment is the next B
+//                     operand).  It writes, per (site, chain), the row  P = [d a_r | d a_u | d q | d y]  and the
+//                     row  Q = [h_in | x one-hot | 1]; head gradients are reduced in registers.
+//   tn_gemm_kernel  : dW = P^T Q over all R = N*ns rows (tall-skinny TN GEMM on the f32 MFMA; operands are read
+//                     straight from the row-major arrays, which already have the A/B fragment shape), partial
+//                     sums combined with float atomics.
+#pragma once
+#include "gru_core.h"
+
+namespace rnnwf {
+
+template <int NFULL>
+struct GradLayout {
+    static constexpr int KT = 4 * NFULL + 1;
+    static constexpr int NT = 3 * NFULL + 1;
+    static constexpr int NTO = NFULL + 1;                 // 16-row tiles covering the hidden units
+    static constexpr int PCOLS = 16 * (NT + NTO);         // [gate rows in image order | dy in unit-fragment order]
+    static constexpr int QCOLS = 16 * NTO;                // [h_in in unit-fragment order ; x0, x1, 1 in the spare slots]
+    static constexpr int KB = 3 * KT;                     // k-steps of the backward product (gate g, kt)
+    static constexpr int KBG = (KB + 3) / 4;              // groups of 4 k-steps (b128 LDS reads)
+    static constexpr size_t BWD_BYTES = (size_t)NTO * KBG * 64 * 16;   // [NTO][KBG][64] float4
+    static constexpr int HEAD_GRADS = 4 * KT + 4;         // wd-difference gradient per unit slot + bias
+};
+
+struct GradArgs {
+    const void* wimg;          // forward image (GruLayout<float, NFULL, 1>)
+    const void* wbwd;          // backward A fragments (GradLayout::BWD_BYTES)
+    int32_t N;
+    int64_t ns, nsb;
+    const uint32_t* bits;
+    const float* hck;          // [N-1][nsb][KT][64] state after each site
+    const double* eloc;        // [ns]
+    double mean_e, inv_norm;   // w_s = (E_s - mean_e) * inv_norm
+    float* P;                  // [N*ns][PCOLS]
+    float* Q;                  // [N*ns][QCOLS]
+    float* head_grad;          // [HEAD_GRADS], zeroed before the launch
+};
+
+template <int NFULL, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) prnn_bwd_kernel(GradArgs a) {
+    using C = GruCore<float, NFULL, 1>;
+    using G = GradLayout<NFULL>;
+    using V4 = typename C::V4;
+    constexpr int KT = C::KT, NT = C::NT;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    C::stage(lds, a.wimg);
+    {
+        char* lb = lds + C::L::BYTES;
+        const uint4* src = reinterpret_cast<const uint4*>(a.wbwd);
+        uint4* dst = reinterpret_cast<uint4*>(lb);
+        for (int i = threadIdx.x; i < (int)(G::BWD_BYTES / 16); i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+    }
+    const char* lbwd = lds + C::L::BYTES;
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int64_t gw = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * WAVES;
+    const int N = a.N;
+    const float* wd = reinterpret_cast<const float*>(lds + C::L::OFF_WD) + q * C::L::WD_Q;
+    for (int64_t sb = gw; sb < a.nsb; sb += nw) {
+        const int64_t s = sb * kChains + c;
+        const bool valid = s < a.ns;
+        const int64_t sc = valid ? s : a.ns - 1;
+        const float w = valid ? (float)((a.eloc[sc] - a.mean_e) * a.inv_norm) : 0.0f;
+        auto spin = [&](int n) { return (int)((a.bits[(int64_t)(n >> 5) * a.ns + sc] >> (n & 31)) & 1); };
+        float dh[KT], hg[KT];
+        float gb = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) { dh[k] = 0.0f; hg[k] = 0.0f; }
+        for (int n = N - 1; n >= 0; --n) {
+            float h[KT], hn[KT], rg[KT], ug[KT], cc[KT], qv[KT];
+            if (n > 0) {
+                const float* src = a.hck + (((int64_t)(n - 1) * a.nsb + sb) * KT) * 64 + lane;
+#pragma unroll
+                for (int k = 0; k < KT; ++k) h[k] = src[k * 64];
+            } else {
+#pragma unroll
+                for (int k = 0; k < KT; ++k) h[k] = 0.0f;
+            }
+            const int sig_in = n > 0 ? spin(n - 1) : -1;
+            const int sig = spin(n);
+            C::step_keep(lds, sig_in, h, hn, rg, ug, cc, qv, lane);
+            float z[1];
+            C::head(lds, hn, lane, z);
+            // d log p(sig) / d(z1 - z0) = sig - p1
+            const float p1 = 1.0f - prob0(z[0]);
+            const float g = w * ((float)sig - p1);
+            gb += g;
+            float dp[4 * G::KBG];
+            float dy[KT];
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                hg[k] = fmaf(g, hn[k], hg[k]);
+                const float d = fmaf(g, wd[k], dh[k]);                  // total dL/dh_n of this lane's unit
+                const float du = d * (h[k] - cc[k]);
+                const float dc = d * (1.0f - ug[k]);
+                dh[k] = d * ug[k];                                      // direct path to h_{n-1}
+                dy[k] = dc * (1.0f - cc[k] * cc[k]);
+                dp[2 * KT + k] = dy[k] * rg[k];                         // d q
+                dp[k] = dy[k] * qv[k] * rg[k] * (1.0f - rg[k]);         // d a_r
+                dp[KT + k] = du * ug[k] * (1.0f - ug[k]);               // d a_u
+            }
+#pragma unroll
+            for (int k = G::KB; k < 4 * G::KBG; ++k) dp[k] = 0.0f;
+            if (valid) {
+                float* prow = a.P + ((int64_t)n * a.ns + s) * G::PCOLS + 4 * q;
+#pragma unroll
+                for (int m = 0; m < NFULL; ++m) {
+#pragma unroll
+                    for (int gt = 0; gt < 3; ++gt) {
+                        V4 v = {dp[gt * KT + 4 * m], dp[gt * KT + 4 * m + 1], dp[gt * KT + 4 * m + 2], dp[gt * KT + 4 * m + 3]};
+                        *reinterpret_cast<V4*>(prow + (gt * NFULL + m) * 16) = v;
+                    }
+                    V4 vy = {dy[4 * m], dy[4 * m + 1], dy[4 * m + 2], dy[4 * m + 3]};
+                    *reinterpret_cast<V4*>(prow + (NT + m) * 16) = vy;
+                }
+                V4 vm = {dp[KT - 1], dp[2 * KT - 1], dp[3 * KT - 1], 0.0f};    // mixed tile: row 4q + gate
+                *reinterpret_cast<V4*>(prow + (NT - 1) * 16) = vm;
+                V4 vym = {dy[KT - 1], 0.0f, 0.0f, 0.0f};
+                *reinterpret_cast<V4*>(prow + (NT + NFULL) * 16) = vym;
+                float* qrow = a.Q + ((int64_t)n * a.ns + s) * G::QCOLS + 4 * q;
+#pragma unroll
+                for (int m = 0; m < NFULL; ++m) {
+                    V4 v = {h[4 * m], h[4 * m + 1], h[4 * m + 2], h[4 * m + 3]};
+                    *reinterpret_cast<V4*>(qrow + m * 16) = v;
+                }
+                const float first = q == 0 ? 1.0f : 0.0f;
+                V4 vq = {h[KT - 1], first * (sig_in == 0 ? 1.0f : 0.0f), first * (sig_in == 1 ? 1.0f : 0.0f), first};
+                *reinterpret_cast<V4*>(qrow + NFULL * 16) = vq;
+            }
+            // dL/dh_{n-1} += W_r d a_r + W_u d a_u + Wch d q   (A = transposed weights, B = dp fragments)
+            V4 accb[G::NTO];
+#pragma unroll
+            for (int t = 0; t < G::NTO; ++t) accb[t] = V4{0.f, 0.f, 0.f, 0.f};
+            asm volatile("" ::: "memory");
+            const V4* ab = reinterpret_cast<const V4*>(lbwd) + lane;
+#pragma unroll
+            for (int kg = 0; kg < G::KBG; ++kg) {
+                V4 af[G::NTO];
+#pragma unroll
+                for (int t = 0; t < G::NTO; ++t) af[t] = ab[(t * G::KBG + kg) * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < G::NTO; ++t)
+                        accb[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][j], dp[4 * kg + j], accb[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int m = 0; m < NFULL; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dh[4 * m + r] += accb[m][r];
+            dh[KT - 1] += accb[NFULL][0];
+        }
+        // head gradients: reduce over the 16 chains of each lane quarter, one atomic per (unit slot)
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            float v = hg[k];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            if (c == 0) atomicAdd(&a.head_grad[4 * k + q], v);
+        }
+        {
+            float v = gb;
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            if (c == 0 && q == 0) atomicAdd(&a.head_grad[4 * KT], v);
+        }
+    }
+}
+
+// dW[PCOLS][QCOLS] += sum over rows of P[row][:]^T Q[row][:]; one block = 4 waves = one contiguous chunk of rows.
+// Wave w owns the 16-row output tiles mt = w, w+4, ... and all QCOLS/16 column tiles.
+template <int PT, int QT>
+__global__ void __launch_bounds__(256) tn_gemm_kernel(const float* __restrict__ P, const float* __restrict__ Q, int64_t R,
+                                                      int64_t rows_per_block, float* __restrict__ dW) {
+    typedef float V4 __attribute__((ext_vector_type(4)));
+    constexpr int MW = (PT + 3) / 4;                       // output row tiles per wave
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+    V4 acc[MW][QT];
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int j = 0; j < QT; ++j) acc[i][j] = V4{0.f, 0.f, 0.f, 0.f};
+    for (int64_t r = r0; r < r1; r += 4) {
+        const int64_t row = r + lk;
+        const bool ok = row < r1;
+        float af[MW], bf[QT];
+#pragma unroll
+        for (int i = 0; i < MW; ++i) {
+            const int mt = wave + 4 * i;
+            af[i] = (ok && mt < PT) ? P[row * (PT * 16) + mt * 16 + li] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < QT; ++j) bf[j] = ok ? Q[row * (QT * 16) + j * 16 + li] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int j = 0; j < QT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+        const int mt = wave + 4 * i;
+        if (mt >= PT) continue;
+#pragma unroll
+        for (int j = 0; j < QT; ++j)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                atomicAdd(&dW[(size_t)(mt * 16 + 4 * lk + rr) * (QT * 16) + j * 16 + li], acc[i][j][rr]);
+    }
+}
+
+}  // namespace rnnwf

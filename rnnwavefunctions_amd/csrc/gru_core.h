@@ -137,6 +137,65 @@ struct GruCore {
         }
     }
 
+    // Forward step that also returns the gate values of this lane's units (index kt <-> unit 4 kt + q), for the
+    // backward pass: r, u, c and the candidate's hidden projection q = h Wch + bch (un-scaled).
+    static __device__ __forceinline__ void step_keep(const char* lds, int sig, const T (&h)[KT], T (&hn)[KT], T (&rg)[KT],
+                                                     T (&ug)[KT], T (&cc)[KT], T (&qv)[KT], int lane) {
+        const int q = lane >> 4;
+        asm volatile("" ::: "memory");
+        V4 acc[NT];
+        {
+            const char* b = lds + L::OFF_BINIT + (size_t)(sig + 1) * L::SZ_BINIT_VARIANT + (size_t)q * 4 * sizeof(T);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = *reinterpret_cast<const V4*>(b + (size_t)t * 16 * sizeof(T));
+        }
+        const VA* av = reinterpret_cast<const VA*>(lds + L::OFF_AVEC) + lane;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int t0 = 0; t0 < NT; t0 += TC) {
+                VA a[TC];
+#pragma unroll
+                for (int t = 0; t < TC; ++t)
+                    if (t0 + t < NT) a[t] = av[((t0 + t) * NG + g) * 64];
+#pragma unroll
+                for (int j = 0; j < VW; ++j)
+#pragma unroll
+                    for (int t = 0; t < TC; ++t)
+                        if (t0 + t < NT) acc[t0 + t] = F::mfma(a[t][j], h[g * VW + j], acc[t0 + t]);
+            }
+        }
+        {
+            const T* ar = reinterpret_cast<const T*>(lds + L::OFF_AREM) + lane;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = F::mfma(ar[t * 64], h[KT - 1], acc[t]);
+        }
+        const char* x = lds + L::OFF_XC + (size_t)(sig + 1) * L::SZ_XC_VARIANT + (size_t)q * 4 * sizeof(T);
+        const T inv_cs = T(1.0 / A::kCandScale);
+#pragma unroll
+        for (int m = 0; m < NFULL; ++m) {
+            const V4 xc = *reinterpret_cast<const V4*>(x + (size_t)m * 16 * sizeof(T));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 4 * m + r;
+                rg[k] = A::sigmoid_scaled(acc[m][r]);
+                ug[k] = A::sigmoid_scaled(acc[NFULL + m][r]);
+                qv[k] = acc[2 * NFULL + m][r] * inv_cs;
+                cc[k] = A::tanh_scaled(xc[r] + rg[k] * acc[2 * NFULL + m][r]);
+                hn[k] = cc[k] + ug[k] * (h[k] - cc[k]);
+            }
+        }
+        {
+            const V4 xc = *reinterpret_cast<const V4*>(x + (size_t)NFULL * 16 * sizeof(T));
+            const V4 a = acc[NT - 1];
+            rg[KT - 1] = A::sigmoid_scaled(a[0]);
+            ug[KT - 1] = A::sigmoid_scaled(a[1]);
+            qv[KT - 1] = a[2] * inv_cs;
+            cc[KT - 1] = A::tanh_scaled(xc[0] + rg[KT - 1] * a[2]);
+            hn[KT - 1] = cc[KT - 1] + ug[KT - 1] * (h[KT - 1] - cc[KT - 1]);
+        }
+    }
+
     // Output heads on the new hidden state, reduced over the four lane quarters.  Row 0 is the softmax
     // logit DIFFERENCE d = z1 - z0 of tf.layers.Dense(2) (1DTFIM/RNNwavefunction.py:33,67,109) - a two-way
     // softmax depends on nothing else; the cRNN adds the two phase logits (rows 1, 2; :42-43).

@@ -53,6 +53,11 @@ struct rnnwf_handle {
     rnnwf::DevBuf camp, tiles, tile_count, cbase, cout;
     // MDRNN
     rnnwf::DevBuf rowbuf;
+    // gradient (grad.hip)
+    rnnwf::DevBuf wbwd, gradP, gradQ, gradW;
+    std::map<std::string, std::vector<double>> grads;
+    int64_t last_ns = 0;          // batch of the last rnnwf_vmc_step still resident (bits, hck, eloc)
+    bool last_has_ckpt = false;
     void* pinned = nullptr;  // small pinned staging (moments)
 
     bool timing_on = false;

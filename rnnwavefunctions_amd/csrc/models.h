@@ -49,6 +49,9 @@ int mdrnn_tfim_eloc(rnnwf_handle* h, const int32_t* samples, int64_t ns, const d
 int mdrnn_vmc_step(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t step, int64_t offset, const double* couplings,
                    int32_t* out_samples, double* out_eloc, double* moments);
 
+// ---- gradient (grad.hip) ---------------------------------------------------------------------------
+void grad_invalidate(rnnwf_handle* h);
+
 }  // namespace rnnwf
 
 extern "C" int rnnwf_comm_destroy(rnnwf_handle* h);

@@ -121,11 +121,11 @@ int eloc_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
     const size_t hck_bytes = (size_t)std::max(N - 1, 1) * nsb * hck_bytes_per_block(h);
     if (int rc = ensure(h, h->lpq, (size_t)(N + 1) * ns * 8)) return rc;
     if (int rc = ensure(h, h->eloc, (size_t)ns * 8)) return rc;
-    if (Bx != 0.0) if (int rc = ensure(h, h->hck, hck_bytes)) return rc;
+    if (int rc = ensure(h, h->hck, hck_bytes)) return rc;    // always: the gradient pass reuses the states
 
     PrnnArgs a = base_args(h, ns);
     a.bits = (uint32_t*)h->bits.p;
-    a.hck = Bx != 0.0 ? h->hck.p : nullptr;
+    a.hck = h->hck.p;
     a.lpq = (double*)h->lpq.p;
     a.sampling = sampling ? 1 : 0;
     a.seed = seed; a.step = step; a.sample_offset = offset;
@@ -180,6 +180,7 @@ int rnnwf::prnn_pack_image(rnnwf_handle* h, std::vector<char>& img) {
 
 int rnnwf::prnn_log_prob(rnnwf_handle* h, const int32_t* samples, int64_t B, double* out) {
     const int N = h->N;
+    h->last_ns = 0;
     const bool parity = h->model == RNNWF_MODEL_GRU1D_PARITY;
     for (int64_t off = 0; off < B; off += kLogProbChunk) {
         const int64_t nb = std::min(kLogProbChunk, B - off);
@@ -208,6 +209,7 @@ int rnnwf::prnn_sample(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t step
                        double* out_log) {
     const int N = h->N;
     const int W = (N + 31) / 32;
+    h->last_ns = 0;
     if (int rc = ensure(h, h->bits, (size_t)W * ns * 4)) return rc;
     if (int rc = ensure(h, h->out_lp, (size_t)ns * 8)) return rc;
     PrnnArgs a = base_args(h, ns);
@@ -237,6 +239,7 @@ int rnnwf::prnn_sample(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t step
 int rnnwf::prnn_tfim_eloc(rnnwf_handle* h, const int32_t* samples, int64_t ns, int Nx, int Ny, const double* Jz,
                           double Bx, double* eloc, double* log_probs) {
     const int N = h->N;
+    h->last_ns = 0;
     if (int rc = ensure(h, h->coupl, (size_t)N * 8)) return rc;
     RNNWF_HIP(h, hipMemcpyAsync(h->coupl.p, Jz, (size_t)N * 8, hipMemcpyHostToDevice, h->stream));
     const int64_t chunk = max_chains_per_pass(h);
@@ -271,5 +274,7 @@ int rnnwf::prnn_vmc_step(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t st
     if (int rc = eloc_on_device(h, ns, true, seed, step, offset, Nx, Ny, (const double*)h->coupl.p, Bx)) return rc;
     if (out_samples) if (int rc = unpack_and_download(h, h->bits, ns, out_samples, nullptr)) return rc;
     if (out_eloc) RNNWF_HIP(h, hipMemcpyAsync(out_eloc, h->eloc.p, (size_t)ns * 8, hipMemcpyDeviceToHost, h->stream));
+    h->last_ns = ns;              // bits, hck and eloc stay resident for rnnwf_vmc_gradient
+    h->last_has_ckpt = true;
     return run_moments(h, h->eloc.p, ns, false, moments);
 }

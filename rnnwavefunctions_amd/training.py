@@ -1,0 +1,90 @@
+"""VMC training drivers with the reference's call signatures.
+
+    run_1DTFIM  <- 1DTFIM/TrainingRNN_1DTFIM.py:79-229
+
+One iteration of the reference loop (:199-227) is: draw samples, local energies, mean/var, print every 10 steps,
+Adam step on  cost = mean(log_probs * Eloc) - mean(Eloc) * mean(log_probs)  (:156).  Here the whole iteration but
+the 8 102-parameter Adam update runs on the GPU: `vmc_step` (sample + fused local energies + moments) and
+`vmc_gradient` (back-propagation through time + weight-gradient GEMM) keep samples, hidden states and local
+energies resident in HBM; the host only sees the four moments and the gradient arrays.
+"""
+import os
+
+import numpy as np
+
+from . import _lib
+from . import params as P
+
+
+class Adam:
+    """tf.train.AdamOptimizer(learning_rate) with TF-1 defaults (beta1 0.9, beta2 0.999, epsilon 1e-8):
+    lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t);  theta -= lr_t m / (sqrt(v) + epsilon)."""
+
+    def __init__(self, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        self.b1, self.b2, self.eps = beta1, beta2, epsilon
+        self.t = 0
+        self.m, self.v = {}, {}
+
+    def step(self, params, grads, lr):
+        self.t += 1
+        lr_t = lr * np.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        for k, g in grads.items():
+            g = np.asarray(g, dtype=np.float64)
+            if k not in self.m:
+                self.m[k] = np.zeros_like(g)
+                self.v[k] = np.zeros_like(g)
+            self.m[k] = self.b1 * self.m[k] + (1.0 - self.b1) * g
+            self.v[k] = self.b2 * self.v[k] + (1.0 - self.b2) * g * g
+            params[k] = (params[k].astype(np.float64) - lr_t * self.m[k] / (np.sqrt(self.v[k]) + self.eps)).astype(params[k].dtype)
+        return params
+
+
+def cost_gradient(native, params, scope, mean_energy, norm, allreduce=False):
+    """{scoped tf name: gradient} of the reference cost on the batch of the last vmc_step."""
+    shapes = {k[len(scope) + 1:]: v.shape for k, v in params.items()}
+    g = native.vmc_gradient(mean_energy, norm, shapes, allreduce=allreduce)
+    return {scope + "/" + k: v for k, v in g.items()}
+
+
+def run_1DTFIM(numsteps=10 ** 4, systemsize=20, num_units=50, Bx=1, num_layers=1, numsamples=500, learningrate=5e-3,
+               seed=111, save_dir=None, device=0, verbose=True):
+    """Train the 1D pRNN wave function on the open transverse-field Ising chain; returns (meanEnergy, varEnergy)
+    lists with one entry per iteration, as the reference's run_1DTFIM."""
+    if num_layers != 1:
+        raise ValueError("only num_layers = 1 is implemented on gfx950 (the reference's run scripts use 1)")
+    N = systemsize
+    scope = "RNNwavefunction"
+    Jz = +np.ones(N)
+    lr = np.float64(learningrate)
+    units = [num_units] * num_layers
+    params = P.init_gru_params(units, seed=seed, scope=scope)
+    wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D, N, 1, tuple(units), device=device)
+    wf.set_params(params, scope=scope)
+    if verbose:
+        for k, v in params.items():
+            print(k, (v.size,))
+        print("The number of params is {0}".format(P.count_params(params)))
+    couplings = np.append(Jz, float(Bx))
+    opt = Adam()
+    ending = "_units" + "".join("_{0}".format(u) for u in units)
+    meanEnergy, varEnergy = [], []
+    for it in range(numsteps + 1):
+        out = wf.vmc_step(numsamples, seed=seed, step=it, couplings=couplings)
+        s1, s2, n, _ = out["moments"]
+        meanE = s1 / n
+        varE = s2 / n - meanE * meanE
+        meanEnergy.append(meanE)
+        varEnergy.append(varE)
+        if verbose and it % 10 == 0:
+            print("mean(E): {0}, var(E): {1}, #samples {2}, #Step {3} \n\n".format(meanE, varE, numsamples, it))
+        grads = cost_gradient(wf, params, scope, meanE, numsamples)
+        params = opt.step(params, grads, lr)
+        wf.set_params(params, scope=scope)
+        if save_dir is not None and it % 10 == 0:
+            tag = "_N" + str(N) + "_samp" + str(numsamples) + "_Jz" + str(Jz[0]) + "_Bx" + str(Bx) + "_GRURNN_OBC_TFIM" + ending
+            np.save(os.path.join(save_dir, "meanEnergy" + tag + ".npy"), meanEnergy)
+            np.save(os.path.join(save_dir, "varEnergy" + tag + ".npy"), varEnergy)
+            if it % 500 == 0:
+                P.save_npz(os.path.join(save_dir, "RNNwavefunction" + tag + ".npz"), params)
+    run_1DTFIM.last_params = params
+    return meanEnergy, varEnergy

@@ -1,0 +1,71 @@
+"""GPU tests of the gradient / training row: the HIP back-propagation against finite
+differences of the float64 oracle, and the end-to-end acceptance test the reference's notebook records
+(Tutorial_1DTFIM.ipynb cells 8, 18: ED -12.38148999965476, trained pRNN -12.3808 for N=10, 10 units, 200 samples)."""
+import numpy as np
+import pytest
+
+from oracle import models as M
+from rnnwavefunctions_amd import params as P
+
+pytestmark = pytest.mark.gpu
+SCOPE = "RNNwavefunction"
+
+
+def oracle_cost(prm64, samples, eloc):
+    lp = M.prnn_log_probability(prm64, samples, dtype=np.float64)
+    return np.mean(lp * eloc) - np.mean(eloc) * np.mean(lp)          # TrainingRNN_1DTFIM.py:156
+
+
+@pytest.mark.parametrize("N,H,ns", [(6, 6, 64), (9, 20, 48), (7, 50, 32)])
+def test_gradient_matches_finite_differences_of_the_oracle(N, H, ns):
+    from rnnwavefunctions_amd import _lib
+    from rnnwavefunctions_amd.training import cost_gradient
+    prm = P.randomize_biases(P.scale_kernels(P.init_gru_params([H], seed=H), 1.5), H + 1)
+    wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D, N, 1, (H,))
+    wf.set_params(prm, scope=SCOPE)
+    out = wf.vmc_step(ns, seed=3, step=0, couplings=np.append(np.ones(N), 1.0), want_samples=True, want_eloc=True)
+    s, e = out["samples"], out["eloc"]
+    grads = cost_gradient(wf, prm, SCOPE, e.mean(), ns)
+    prm64 = {k: v.astype(np.float64) for k, v in prm.items()}
+    rng = np.random.RandomState(0)
+    worst = 0.0
+    scale = max(np.abs(g).max() for g in grads.values())
+    for name, g in grads.items():
+        assert g.shape == prm[name].shape
+        flat = prm64[name].ravel()
+        for idx in rng.choice(flat.size, size=min(flat.size, 12), replace=False):
+            old = flat[idx]
+            eps = 1e-5
+            flat[idx] = old + eps
+            cp = oracle_cost(prm64, s, e)
+            flat[idx] = old - eps
+            cm = oracle_cost(prm64, s, e)
+            flat[idx] = old
+            fd = (cp - cm) / (2 * eps)
+            worst = max(worst, abs(fd - g.ravel()[idx]) / scale)
+    print("N=%d H=%d: max |grad - FD| / max|grad| = %.2e" % (N, H, worst))
+    assert worst < 2e-3
+
+
+def test_gradient_needs_a_resident_batch():
+    from rnnwavefunctions_amd import _lib
+    prm = P.init_gru_params([10], seed=1)
+    wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D, 8, 1, (10,))
+    wf.set_params(prm, scope=SCOPE)
+    with pytest.raises(_lib.RnnwfError, match="rnnwf_vmc_step"):
+        wf.vmc_gradient(0.0, 10, {"wf_dense/bias": (2,)})
+
+
+def test_run_1dtfim_reaches_the_exact_ground_state_energy():
+    from rnnwavefunctions_amd.TFIM1D.TrainingRNN_1DTFIM import run_1DTFIM
+    meanE, varE = run_1DTFIM(numsteps=600, systemsize=10, num_units=10, Bx=1, num_layers=1, numsamples=200,
+                             learningrate=5e-3, seed=111, verbose=False)
+    assert len(meanE) == 601 and len(varE) == 601
+    ed = -12.38148999965476
+    final = np.mean(meanE[-50:])
+    print("run_1DTFIM N=10: E(first)=%.4f  mean of last 50 steps = %.5f  (ED %.5f)  var(last) = %.4f" %
+          (meanE[0], final, ed, np.mean(varE[-50:])))
+    assert meanE[0] > -11.5                     # random initial state is far from the ground state
+    assert final > ed - 0.02                    # variational (up to the Monte-Carlo error of the mean)
+    assert abs(final - ed) < 0.03               # the notebook reaches -12.3808 after 1000 steps
+    assert np.mean(varE[-50:]) < 0.5 * varE[0]  # zero-variance principle: variance collapses near an eigenstate
