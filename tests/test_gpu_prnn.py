@@ -227,3 +227,21 @@ def test_rccl_all_reduce_single_rank():
     assert np.array_equal(wf.allreduce_moments(m), m)
     with pytest.raises(ValueError):
         wf.comm_init(uid, 3, 2)
+
+
+@pytest.mark.parametrize("N,H,ns", [(1, 10, 5), (2, 10, 1), (32, 20, 17), (33, 20, 16), (64, 36, 31), (200, 100, 19)])
+def test_edge_sizes(N, H, ns):
+    """Ragged batches (ns not a multiple of the 16-chain tile, down to one sample), chain lengths around the 32-bit
+    word boundaries of the packed spins, the largest BASELINE chain (N=200, num_units=100)."""
+    from rnnwavefunctions_amd import _lib
+    prm = trained_like(H, seed=N + H)
+    wf = make_wf(_lib.MODEL_GRU1D, N, H, prm)
+    out = wf.vmc_step(ns, seed=1, step=0, couplings=np.append(np.ones(N), 0.7), want_samples=True, want_eloc=True)
+    s, e = out["samples"], out["eloc"]
+    assert s.shape == (ns, N)
+    e_ref = E.ising_local_energies(np.ones(N), 0.7, s, lambda x: M.prnn_log_probability(prm, x))
+    assert np.allclose(e, e_ref, rtol=3e-5, atol=3e-5)
+    assert np.allclose(wf.log_prob(s), M.prnn_log_probability(prm, s), atol=2e-6 * N + 2e-6)
+    u = philox.uniforms(1, 0, 0, ns, N)
+    s_ref, _ = M.prnn_sample(prm, N, u)
+    assert (s != s_ref).any(axis=1).sum() <= 1
