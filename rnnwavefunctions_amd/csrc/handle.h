@@ -55,6 +55,9 @@ struct rnnwf_handle {
     rnnwf::DevBuf rowbuf;
     // gradient (grad.hip)
     rnnwf::DevBuf wbwd, gradP, gradQ, gradW;
+    // bf16x3 engine (split_core.h): second weight image; engine_split = use it for the flip pass
+    rnnwf::DevBuf wsplit;
+    bool engine_split = false;
     std::map<std::string, std::vector<double>> grads;
     int64_t last_ns = 0;          // batch of the last rnnwf_vmc_step still resident (bits, hck, eloc)
     bool last_has_ckpt = false;

@@ -1,0 +1,96 @@
+// pack_split.h - host-side packing of the GRU parameters into the bf16x3 image of split_core.h.
+#pragma once
+#include <cmath>
+#include <cstring>
+
+#include "pack.h"
+#include "split_core.h"
+
+namespace rnnwf {
+
+inline uint16_t bf16_rne(float x) {
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline float bf16_to_float(uint16_t b) {
+    const uint32_t u = (uint32_t)b << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+// w -> three bf16 numbers whose sum is exactly (float)w
+inline void split3(double w, uint16_t (&p)[3]) {
+    float r = (float)w;
+    for (int i = 0; i < 3; ++i) {
+        p[i] = bf16_rne(r);
+        r -= bf16_to_float(p[i]);
+    }
+}
+
+template <int NF32, int RJ>
+std::vector<char> pack_split_image(const rnnwf_handle* h) {
+    using L = SplitLayout<NF32, RJ>;
+    const int H = h->H;
+    std::vector<char> img(L::BYTES, 0);
+    const std::string pre = kGruPre;
+    const auto& Wg = pv(h, pre + "gates/kernel");
+    const auto& bg = pv(h, pre + "gates/bias");
+    const auto& Wci = pv(h, pre + "candidate/input_projection/kernel");
+    const auto& bci = pv(h, pre + "candidate/input_projection/bias");
+    const auto& Wch = pv(h, pre + "candidate/hidden_projection/kernel");
+    const auto& bch = pv(h, pre + "candidate/hidden_projection/bias");
+    const auto& Wd = pv(h, "wf_dense/kernel");
+    const auto& bd = pv(h, "wf_dense/bias");
+    const double sg = PackScale<float>::gate, sc = PackScale<float>::cand;
+    uint16_t* A = reinterpret_cast<uint16_t*>(img.data() + L::OFF_A);
+    for (int T = 0; T < L::NT; ++T)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int r32 = lane & 31, hhk = lane >> 5;
+            const int hh_row = (r32 >> 2) & 1, rho = (r32 & 3) + 4 * (r32 >> 3);
+            int g = -1, uo = -1;
+            if (T < 3 * NF32) {
+                g = T % 3;
+                uo = L::unit_of(16 * (T / 3) + rho, hh_row);
+            } else {
+                const int s = 16 * (T - 3 * NF32) + rho;
+                if (s < 3 * RJ) { g = s / RJ; uo = 32 * NF32 + hh_row * RJ + s % RJ; }
+            }
+            if (g < 0 || uo >= H) continue;
+            for (int x = 0; x < L::NQ; ++x)
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int e = 8 * x + jj;
+                    double w = 0.0;
+                    if (e < L::NU) {
+                        const int ui = L::unit_of(e, hhk);
+                        if (ui < H) w = g == 0 ? sg * Wg[(size_t)(2 + ui) * 2 * H + uo]
+                                      : g == 1 ? sg * Wg[(size_t)(2 + ui) * 2 * H + H + uo]
+                                               : sc * Wch[(size_t)ui * H + uo];
+                    } else if (e == L::NU && hhk == 0) {                    // bias (+ input row of spin 0)
+                        w = g == 0 ? sg * (bg[uo] + Wg[uo]) : g == 1 ? sg * (bg[H + uo] + Wg[H + uo]) : sc * bch[uo];
+                    } else if (e == L::NU + 1 && hhk == 0) {                // input row difference, times sigma
+                        w = g == 0 ? sg * (Wg[(size_t)2 * H + uo] - Wg[uo])
+                          : g == 1 ? sg * (Wg[(size_t)2 * H + H + uo] - Wg[H + uo]) : 0.0;
+                    }
+                    uint16_t p[3];
+                    split3(w, p);
+                    for (int a = 0; a < 3; ++a) A[((((size_t)T * 3 + a) * L::NQ + x) * 64 + lane) * 8 + jj] = p[a];
+                }
+        }
+    float* XC = reinterpret_cast<float*>(img.data() + L::OFF_XC);
+    float* WD = reinterpret_cast<float*>(img.data() + L::OFF_WD);
+    float* BD = reinterpret_cast<float*>(img.data() + L::OFF_BD);
+    for (int hh = 0; hh < 2; ++hh)
+        for (int e = 0; e < L::NU; ++e) {
+            const int u = L::unit_of(e, hh);
+            if (u >= H) continue;
+            for (int sgm = 0; sgm < 2; ++sgm)
+                XC[(size_t)(sgm * 2 + hh) * L::NUP + e] = (float)(sc * (bci[u] + Wci[(size_t)sgm * H + u]));
+            WD[(size_t)hh * L::NUP + e] = (float)(Wd[(size_t)u * 2 + 1] - Wd[(size_t)u * 2]);
+        }
+    BD[0] = (float)(bd[1] - bd[0]);
+    return img;
+}
+
+}  // namespace rnnwf

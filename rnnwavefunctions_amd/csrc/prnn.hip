@@ -6,6 +6,8 @@
 #include "gru_kernels.h"
 #include "models.h"
 #include "pack.h"
+#include "pack_split.h"
+#include "split_kernels.h"
 
 using namespace rnnwf;
 
@@ -72,6 +74,50 @@ struct Launch {
         }                                                                                   \
     } while (0)
 
+// ---- bf16x3 engine for the flip pass (f32 models, num_units <= 68) ---------------------------------------
+template <int NF32, int RJ, int WAVES>
+struct SLaunch {
+    using L = SplitLayout<NF32, RJ>;
+    static int flip(rnnwf_handle* h, const PrnnArgs& a, int kt16) {
+        static int bpc = 0;
+        const void* fn = (const void*)prnn_flip_split_kernel<NF32, RJ, WAVES>;
+        if (!bpc) {
+            RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES));
+            RNNWF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, WAVES * 64, L::BYTES));
+            bpc = std::max(bpc, 1);
+        }
+        const int64_t ntiles = (int64_t)(a.N - 1) * ((a.ns + 31) / 32);
+        const int64_t need = (ntiles + WAVES - 1) / WAVES;
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
+        TimedLaunch tl(h, 1);
+        prnn_flip_split_kernel<NF32, RJ, WAVES><<<grid, WAVES * 64, L::BYTES, h->stream>>>(a, h->wsplit.p, kt16);
+        RNNWF_HIP(h, hipGetLastError());
+        return 0;
+    }
+    static std::vector<char> pack(const rnnwf_handle* h) { return pack_split_image<NF32, RJ>(h); }
+    static double mfma_flops_per_step() { return (double)L::NT * 6 * L::NQ * 32768.0; }   // per 32-chain wave-step
+};
+
+#define SPLIT_DISPATCH(h, EXPR)                                      \
+    do {                                                             \
+        switch ((h)->NFULL) {                                        \
+            case 1: { using K = SLaunch<0, 10, 4>; EXPR; }           \
+            case 2: { using K = SLaunch<1, 2, 4>; EXPR; }            \
+            case 3: { using K = SLaunch<1, 10, 4>; EXPR; }           \
+            case 4: { using K = SLaunch<2, 2, 4>; EXPR; }            \
+        }                                                            \
+    } while (0)
+
+int launch_flip_split(rnnwf_handle* h, const PrnnArgs& a) {
+    const int kt16 = 4 * h->NFULL + 1;
+    SPLIT_DISPATCH(h, return K::flip(h, a, kt16));
+    return h->fail(RNNWF_ERR_INVALID, "no bf16x3 kernel for NFULL=%d", h->NFULL);
+}
+double split_mfma_flops_per_step(rnnwf_handle* h) {
+    SPLIT_DISPATCH(h, return K::mfma_flops_per_step());
+    return 0;
+}
+
 int launch_base(rnnwf_handle* h, const PrnnArgs& a) {
     PRNN_DISPATCH(h, return K::base(h, a));
     return h->fail(RNNWF_ERR_INVALID, "no pRNN kernel for NFULL=%d f64=%d", h->NFULL, (int)h->f64);
@@ -134,9 +180,14 @@ int eloc_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
         a.ntiles = (int64_t)(N - 1) * nsb;
         a.sampling = 0;
         if (const char* e = getenv("RNNWF_ABLATE")) a.ablate = atoi(e);   // diagnostics only
-        if (int rc = launch_flip(h, a)) return rc;
+        if (h->engine_split) {
+            if (int rc = launch_flip_split(h, a)) return rc;
+            h->work[1] += (double)((ns + 31) / 32) * N * (N - 1) / 2.0 * split_mfma_flops_per_step(h);
+        } else {
+            if (int rc = launch_flip(h, a)) return rc;
+            h->work[1] += (double)nsb * N * (N - 1) / 2.0 * mfma_flops_per_step(h);
+        }
         h->work[0] += (double)ns * N * (N - 1) / 2.0;
-        h->work[1] += (double)nsb * N * (N - 1) / 2.0 * mfma_flops_per_step(h);
     }
     if (parity) {
         // second direction on the reversed chains, then log(0.5 (e^a + e^b)) row by row
@@ -154,9 +205,14 @@ int eloc_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
         if (int rc = launch_base(h, b)) return rc;
         if (Bx != 0.0 && N > 1) {
             b.ntiles = (int64_t)(N - 1) * nsb;
-            if (int rc = launch_flip(h, b)) return rc;
+            if (h->engine_split) {
+                if (int rc = launch_flip_split(h, b)) return rc;
+                h->work[1] += (double)((ns + 31) / 32) * N * (N - 1) / 2.0 * split_mfma_flops_per_step(h);
+            } else {
+                if (int rc = launch_flip(h, b)) return rc;
+                h->work[1] += (double)nsb * N * (N - 1) / 2.0 * mfma_flops_per_step(h);
+            }
             h->work[0] += (double)ns * N * (N - 1) / 2.0;
-            h->work[1] += (double)nsb * N * (N - 1) / 2.0 * mfma_flops_per_step(h);
         }
         if (int rc = run_parity_combine(h, (const double*)h->lpq.p, (const double*)h->lpq2.p, (int64_t)(N + 1) * ns,
                                         (double*)h->lpq.p)) return rc;
@@ -174,6 +230,17 @@ int64_t max_chains_per_pass(rnnwf_handle* h) {
 }  // namespace
 
 int rnnwf::prnn_pack_image(rnnwf_handle* h, std::vector<char>& img) {
+    // flip-pass engine: bf16x3 on the matrix core for the f32 models up to 68 units (RNNWF_ENGINE=f32 keeps the
+    // f32-input MFMA everywhere); the base pass, sampling and log_probability always run the f32-MFMA kernels
+    const char* eng = getenv("RNNWF_ENGINE");
+    h->engine_split = !h->f64 && h->NFULL <= 4 && !(eng && std::string(eng) == "f32");
+    if (h->engine_split) {
+        std::vector<char> simg;
+        SPLIT_DISPATCH(h, { simg = K::pack(h); break; });
+        if (int rc = ensure(h, h->wsplit, simg.size())) return rc;
+        RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+        RNNWF_HIP(h, hipMemcpy(h->wsplit.p, simg.data(), simg.size(), hipMemcpyHostToDevice));
+    }
     PRNN_DISPATCH(h, { img = K::pack(h); return 0; });
     return h->fail(RNNWF_ERR_INVALID, "no pRNN kernel for NFULL=%d f64=%d", h->NFULL, (int)h->f64);
 }

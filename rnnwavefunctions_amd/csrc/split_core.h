@@ -1,0 +1,166 @@
+// split_core.h - "bf16x3" engine of the GRU step: f32-accurate matrix products on the bf16 matrix core.
+//
+// Why: on gfx950 the f32-input MFMA runs at the f32 vector rate and its time ADDS to the VALU time of the gate
+// arithmetic (profiles/r01_c_*), while the bf16 MFMA is 16x faster.  Every f32 operand is represented EXACTLY as
+// the sum of three bf16 numbers (8 + 8 + 8 significand bits = the 24 of an f32):
+//        w = w1 + w2 + w3,   h = h1 + h2 + h3                      (w split once on the host, h every site)
+// and the product is taken as the six bf16 MFMA products whose magnitude is >= 2^-16 of the leading one,
+//        w h ~ w1 h1 + (w2 h1 + w1 h2) + (w3 h1 + w2 h2 + w1 h3),
+// accumulated in f32, smallest terms first.  bf16 x bf16 products are exact in f32; the dropped terms
+// (w2 h3, w3 h2, w3 h3) are below 2^-24 of |w h| each - the size of one f32 rounding.  So the result has f32
+// accuracy (tests: same tolerances as the f32-MFMA engine, both compared with the float64 oracle).
+//
+// Shapes: v_mfma_f32_32x32x16_bf16, 32 chains per wave (columns = lane & 31), 32-row tiles.  Lane (c, hh = lane>>5),
+// accumulator register rho of a tile holds row (rho & 3) + 8 (rho >> 2) + 4 hh.  The lane therefore owns, for its
+// chain, the units
+//      entry e < 16 NF32           : unit 32 (e/16) + row(e % 16, hh)            (full 32-unit blocks)
+//      entry 16 NF32 + j, j < RJ   : unit 32 NF32 + hh RJ + j                    (remainder units)
+// and, as for the f32 engine, that is also the K-ownership of the B operand (lane half hh supplies the 8
+// consecutive K entries 8x .. 8x+7 of quad x), so the new state is re-split in registers and fed straight back.
+// Gate rows: full block t -> tiles 3t + {r, u, c}; remainder units -> NMIX "mixed" tiles, slot g RJ + j.
+// Two extra K entries per part carry the bias (entry NU, value 1) and the one-hot input (entry NU+1, value sigma).
+#pragma once
+#include "gru_core.h"
+
+namespace rnnwf {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NF32_, int RJ_>
+struct SplitLayout {
+    static constexpr int NF32 = NF32_, RJ = RJ_;
+    static constexpr int NMIX = (3 * RJ + 15) / 16;
+    static constexpr int NT = 3 * NF32 + NMIX;          // 32-row output tiles
+    static constexpr int NU = 16 * NF32 + RJ;           // hidden units owned by one lane
+    static constexpr int NE = NU + 2;                   // + bias entry + input entry
+    static constexpr int NQ = (NE + 7) / 8;             // bf16x8 quads per part
+    static constexpr int NR = 4 * NQ;                   // packed 32-bit registers per part
+    static constexpr int NUP = ((NU + 3) / 4) * 4;
+    static constexpr int HP = 32 * NF32 + 2 * RJ;       // padded hidden size
+    static constexpr size_t OFF_A = 0;                                         // [NT][3][NQ][64] x 16 B
+    static constexpr size_t OFF_XC = OFF_A + (size_t)NT * 3 * NQ * 64 * 16;    // [2 sigma][2 hh][NUP] f32 (scaled)
+    static constexpr size_t OFF_WD = OFF_XC + (size_t)2 * 2 * NUP * 4;         // [2 hh][NUP] f32 head difference weights
+    static constexpr size_t OFF_BD = OFF_WD + (size_t)2 * NUP * 4;             // [4] f32 (bd difference, pad)
+    static constexpr size_t BYTES = OFF_BD + 16;
+    // unit owned by entry e of lane half hh
+    static constexpr int unit_of(int e, int hh) {
+        return e < 16 * NF32 ? 32 * (e / 16) + ((e % 16) & 3) + 8 * ((e % 16) >> 2) + 4 * hh : 32 * NF32 + hh * RJ + (e - 16 * NF32);
+    }
+};
+
+// x -> packed (bf16(x0), bf16(x1)) with round-to-nearest-even, as one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+template <int NF32, int RJ>
+struct SplitCore {
+    using L = SplitLayout<NF32, RJ>;
+    static constexpr int NT = L::NT, NU = L::NU, NQ = L::NQ, NR = L::NR;
+
+    static __device__ __forceinline__ void stage(char* lds, const void* wimg) {
+        const uint4* src = reinterpret_cast<const uint4*>(wimg);
+        uint4* dst = reinterpret_cast<uint4*>(lds);
+        for (int i = threadIdx.x; i < (int)(L::BYTES / 16); i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+    }
+
+    // h (this lane's NU units) -> three bf16 parts packed two per register; entries NU (bias, 1.0) and NU+1 (input
+    // spin) are appended to part 1.  Every step of the split is exact: r = x - bf16(x) is representable.
+    static __device__ __forceinline__ void split(const float (&h)[NU], int sig, unsigned (&R)[3][NR]) {
+        float v[2 * NR];
+#pragma unroll
+        for (int e = 0; e < 2 * NR; ++e) v[e] = e < NU ? h[e] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const unsigned p1 = cvt_pk_bf16(v[2 * i], v[2 * i + 1]);
+            const float r0 = v[2 * i] - __uint_as_float(p1 << 16);
+            const float r1 = v[2 * i + 1] - __uint_as_float(p1 & 0xffff0000u);
+            const unsigned p2 = cvt_pk_bf16(r0, r1);
+            const float s0 = r0 - __uint_as_float(p2 << 16);
+            const float s1 = r1 - __uint_as_float(p2 & 0xffff0000u);
+            R[0][i] = p1;
+            R[1][i] = p2;
+            R[2][i] = cvt_pk_bf16(s0, s1);
+        }
+        // bias / input entries (bf16 1.0 = 0x3F80)
+        constexpr int eb = NU, es = NU + 1;
+        const unsigned one = 0x3F80u, sg = sig ? 0x3F80u : 0u;
+        R[0][eb / 2] |= (eb & 1) ? (one << 16) : one;
+        R[0][es / 2] |= (es & 1) ? (sg << 16) : sg;
+    }
+
+    // One GRU step for 32 chains: R (split old state + bias/input entries) and hold (old state) in, new state out.
+    static __device__ __forceinline__ void step(const char* lds, int sig, const unsigned (&R)[3][NR], float (&h)[NU], int lane) {
+        const int hh = lane >> 5;
+        asm volatile("" ::: "memory");
+        f32x16 acc[NT];
+        f32x16 zero;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) zero[k] = 0.0f;       // folds into the MFMA's inline-constant C operand
+        const u32x4* av = reinterpret_cast<const u32x4*>(lds + L::OFF_A) + lane;
+        // (weight part, state part), smallest products first.  The A fragments of k-step k+1 are read from LDS while
+        // k-step k's MFMAs run (two register sets); the compiler barrier keeps later reads from being hoisted too
+        // (120 fragment quads in flight would cost all the occupancy).
+        constexpr int ORD[6][2] = {{2, 0}, {1, 1}, {0, 2}, {1, 0}, {0, 1}, {0, 0}};
+        constexpr int NK = 6 * NQ;
+        u32x4 cur[NT], nxt[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) cur[t] = av[((t * 3 + ORD[0][0]) * NQ + 0) * 64];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int o = k / NQ, x = k % NQ;
+            const int p = ORD[o][1];
+            if (k + 1 < NK) {
+                const int o2 = (k + 1) / NQ, x2 = (k + 1) % NQ, a2 = ORD[o2][0];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) nxt[t] = av[((t * 3 + a2) * NQ + x2) * 64];
+            }
+            const u32x4 bq = {R[p][4 * x], R[p][4 * x + 1], R[p][4 * x + 2], R[p][4 * x + 3]};
+            const bf16x8 b = __builtin_bit_cast(bf16x8, bq);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur[t]), b, k == 0 ? zero : acc[t], 0, 0, 0);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int t = 0; t < NT; ++t) cur[t] = nxt[t];
+        }
+        const float* xc = reinterpret_cast<const float*>(lds + L::OFF_XC) + (size_t)((sig * 2 + hh) * L::NUP);
+#pragma unroll
+        for (int e = 0; e < NU; ++e) {
+            float ar, au, ac;
+            if (e < 16 * NF32) {
+                ar = acc[3 * (e / 16)][e % 16];
+                au = acc[3 * (e / 16) + 1][e % 16];
+                ac = acc[3 * (e / 16) + 2][e % 16];
+            } else {
+                const int j = e - 16 * NF32;
+                ar = acc[3 * NF32 + (j) / 16][(j) % 16];
+                au = acc[3 * NF32 + (RJ + j) / 16][(RJ + j) % 16];
+                ac = acc[3 * NF32 + (2 * RJ + j) / 16][(2 * RJ + j) % 16];
+            }
+            const float rg = Act<float>::sigmoid_scaled(ar);
+            const float ug = Act<float>::sigmoid_scaled(au);
+            const float cc = Act<float>::tanh_scaled(xc[e] + rg * ac);
+            h[e] = cc + ug * (h[e] - cc);
+        }
+    }
+
+    // logit difference of the output head, reduced over the two lane halves
+    static __device__ __forceinline__ float head(const char* lds, const float (&h)[NU], int lane) {
+        const int hh = lane >> 5;
+        asm volatile("" ::: "memory");
+        const float* wd = reinterpret_cast<const float*>(lds + L::OFF_WD) + hh * L::NUP;
+        float z = 0.0f;
+#pragma unroll
+        for (int e = 0; e < NU; ++e) z = fmaf(h[e], wd[e], z);
+        z += __shfl_xor(z, 32);
+        return z + reinterpret_cast<const float*>(lds + L::OFF_BD)[0];
+    }
+};
+
+}  // namespace rnnwf
