@@ -189,6 +189,13 @@ int rnnwf_comm_destroy(rnnwf_handle* h);
 int rnnwf_timing_enable(rnnwf_handle* h, int32_t on);
 int rnnwf_timing_reset(rnnwf_handle* h);
 int rnnwf_timing_get(rnnwf_handle* h, int32_t kernel_id, double* total_ms, int64_t* launches, double* work);
+/* Which matrix engine the dominant (flip / swap) pass of this handle uses, decided at rnnwf_commit_params:
+ *   "bf16x3"  - both operands held exactly as three bf16 parts, six bf16 MFMA products, f32 accumulate
+ *               (f32 models up to 68 units; f32 accuracy, see csrc/split_core.h);
+ *   "f32mfma" - f32-input MFMA (forced with RNNWF_ENGINE=f32; always used above 68 units, for the base pass,
+ *               sampling and log_probability);
+ *   "f64mfma" - the float64 models.                                                                     */
+const char* rnnwf_engine_name(const rnnwf_handle* h);
 /* hipDeviceSynchronize on the handle's device (bench.py brackets its timed region with it). */
 int rnnwf_synchronize(rnnwf_handle* h);
 /* Device properties for reports: cu_count, clock_mhz, hbm_bytes. */

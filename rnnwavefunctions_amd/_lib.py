@@ -56,6 +56,7 @@ PROTOTYPES = {
     "rnnwf_timing_enable": (C.c_int, [_P, _I32]),
     "rnnwf_timing_reset": (C.c_int, [_P]),
     "rnnwf_timing_get": (C.c_int, [_P, _I32, _F64P, C.POINTER(_I64), _F64P]),
+    "rnnwf_engine_name": (C.c_char_p, [_P]),
     "rnnwf_synchronize": (C.c_int, [_P]),
     "rnnwf_device_info": (C.c_int, [_P, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I64), C.c_char_p]),
 }
@@ -290,6 +291,9 @@ class NativeWavefunction:
         work = (C.c_double * 2)()
         self._check(self.lib.rnnwf_timing_get(self.h, kernel_id, C.byref(ms), C.byref(n), work))
         return {"total_ms": ms.value, "launches": n.value, "cell_evals": work[0], "mfma_flops": work[1]}
+
+    def engine_name(self):
+        return self.lib.rnnwf_engine_name(self.h).decode()
 
     def synchronize(self):
         self._check(self.lib.rnnwf_synchronize(self.h))

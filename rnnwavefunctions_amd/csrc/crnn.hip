@@ -2,9 +2,13 @@
 // sample / log_amplitude / fused J1-J2 local energies / fused VMC step.
 #include <algorithm>
 
+#include <cstdlib>
+
 #include "crnn_kernels.h"
 #include "models.h"
 #include "pack.h"
+#include "pack_split.h"
+#include "crnn_split_kernels.h"
 
 using namespace rnnwf;
 
@@ -60,6 +64,49 @@ struct CLaunch {
             case 6: { using K = CLaunch<6, 12>; EXPR; }         \
         }                                                       \
     } while (0)
+
+// ---- bf16x3 engine for the swap pass (num_units <= 68) ---------------------------------------------------
+template <int NF32, int RJ, int WAVES>
+struct CSLaunch {
+    using L = SplitLayout<NF32, RJ, 3>;
+    static int swap(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles, int kt16) {
+        static int bpc = 0;
+        const void* fn = (const void*)crnn_swap_split_kernel<NF32, RJ, WAVES>;
+        if (!bpc) {
+            RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES));
+            RNNWF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, WAVES * 64, L::BYTES));
+            bpc = std::max(bpc, 1);
+        }
+        const int64_t need = (max_tiles + WAVES - 1) / WAVES;
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
+        TimedLaunch tl(h, 1);
+        crnn_swap_split_kernel<NF32, RJ, WAVES><<<grid, WAVES * 64, L::BYTES, h->stream>>>(a, h->wsplit.p, kt16);
+        RNNWF_HIP(h, hipGetLastError());
+        return 0;
+    }
+    static std::vector<char> pack(const rnnwf_handle* h) { return pack_split_image<NF32, RJ, 3>(h); }
+    static double mfma_flops_per_step() { return (double)L::NT * 6 * L::NQ * 32768.0; }
+};
+
+#define CSPLIT_DISPATCH(h, EXPR)                                     \
+    do {                                                             \
+        switch ((h)->NFULL) {                                        \
+            case 1: { using K = CSLaunch<0, 10, 4>; EXPR; }          \
+            case 2: { using K = CSLaunch<1, 2, 4>; EXPR; }           \
+            case 3: { using K = CSLaunch<1, 10, 4>; EXPR; }          \
+            case 4: { using K = CSLaunch<2, 2, 4>; EXPR; }           \
+        }                                                            \
+    } while (0)
+
+int launch_swap_split(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles) {
+    const int kt16 = 4 * h->NFULL + 1;
+    CSPLIT_DISPATCH(h, return K::swap(h, a, max_tiles, kt16));
+    return h->fail(RNNWF_ERR_INVALID, "no bf16x3 cRNN kernel for NFULL=%d", h->NFULL);
+}
+double csplit_mfma_flops_per_step(rnnwf_handle* h) {
+    CSPLIT_DISPATCH(h, return K::mfma_flops_per_step());
+    return 0;
+}
 
 int launch_base(rnnwf_handle* h, const CrnnArgs& a) {
     CRNN_DISPATCH(h, return K::base(h, a));
@@ -132,7 +179,7 @@ int j1j2_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
         dim3 grid((unsigned)((ns + 255) / 256), (unsigned)(2 * N));
         j1j2_enumerate_kernel<<<grid, 256, 0, h->stream>>>(e);
         RNNWF_HIP(h, hipGetLastError());
-        j1j2_tile_scan_kernel<<<1, 64, 0, h->stream>>>(cnt, N, tile_start, total_items);
+        j1j2_tile_scan_kernel<<<1, 64, 0, h->stream>>>(cnt, N, tile_start, total_items, h->engine_split ? 32 : kChains);
         RNNWF_HIP(h, hipGetLastError());
         // lands in pinned[64..88) at the caller's next stream sync (see collect_totals)
         RNNWF_HIP(h, hipMemcpyAsync((char*)h->pinned + 64, total_items, 24, hipMemcpyDeviceToHost, h->stream));
@@ -144,7 +191,11 @@ int j1j2_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
     a.cap = cap;
     a.contrib = (double2*)h->lpq.p;
     const int64_t max_tiles = (int64_t)N * ((2 * ns + kChains - 1) / kChains + 2);
-    if (int rc = launch_swap(h, a, max_tiles)) return rc;
+    if (h->engine_split) {
+        if (int rc = launch_swap_split(h, a, max_tiles)) return rc;
+    } else {
+        if (int rc = launch_swap(h, a, max_tiles)) return rc;
+    }
     {
         TimedLaunch tl(h, 2);
         j1j2_eloc_kernel<<<(unsigned)((ns + 255) / 256), 256, 0, h->stream>>>((const double2*)h->lpq.p, diag, ns, N,
@@ -158,13 +209,24 @@ int j1j2_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
 int64_t collect_totals(rnnwf_handle* h, int64_t ns) {
     const int64_t* t = (const int64_t*)((char*)h->pinned + 64);
     h->work[0] += (double)t[1];
-    h->work[1] += (double)t[2] * (double)(3 * h->NFULL + 1) * (4 * h->NFULL + 1) * 2048.0;
+    h->work[1] += (double)t[2] * (h->engine_split ? csplit_mfma_flops_per_step(h)
+                                                  : (double)(3 * h->NFULL + 1) * (4 * h->NFULL + 1) * 2048.0);
     return t[0] + ns;   // + one diagonal configuration per sample
 }
 
 }  // namespace
 
 int rnnwf::crnn_pack_image(rnnwf_handle* h, std::vector<char>& img) {
+    // swap-pass engine: bf16x3 on the matrix core up to 68 units (RNNWF_ENGINE=f32: f32-input MFMA everywhere)
+    const char* eng = getenv("RNNWF_ENGINE");
+    h->engine_split = h->NFULL <= 4 && !(eng && std::string(eng) == "f32");
+    if (h->engine_split) {
+        std::vector<char> simg;
+        CSPLIT_DISPATCH(h, { simg = K::pack(h); break; });
+        if (int rc = ensure(h, h->wsplit, simg.size())) return rc;
+        RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+        RNNWF_HIP(h, hipMemcpy(h->wsplit.p, simg.data(), simg.size(), hipMemcpyHostToDevice));
+    }
     CRNN_DISPATCH(h, { img = K::pack(h); return 0; });
     return h->fail(RNNWF_ERR_INVALID, "no cRNN kernel for NFULL=%d", h->NFULL);
 }

@@ -200,13 +200,13 @@ __global__ void __launch_bounds__(256) j1j2_enumerate_kernel(J1J2Args a) {
 // tile_start[lo] = sum_{l < lo} ceil(cnt[l] / 16); tile_start[N] = total;
 // totals[0] = sum cnt (off-diagonal configurations), totals[1] = sum cnt[lo] (N-1-lo) (cell evaluations),
 // totals[2] = sum tiles[lo] (N-1-lo) (wave-steps actually issued)
-__global__ void j1j2_tile_scan_kernel(const int32_t* cnt, int N, int32_t* tile_start, int64_t* totals) {
+__global__ void j1j2_tile_scan_kernel(const int32_t* cnt, int N, int32_t* tile_start, int64_t* totals, int tile_items) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     int32_t acc = 0;
     int64_t items = 0, evals = 0, wsteps = 0;
     for (int lo = 0; lo < N; ++lo) {
         tile_start[lo] = acc;
-        const int t = (cnt[lo] + kChains - 1) / kChains;
+        const int t = (cnt[lo] + tile_items - 1) / tile_items;
         acc += t;
         items += cnt[lo];
         evals += (int64_t)cnt[lo] * (N - 1 - lo);

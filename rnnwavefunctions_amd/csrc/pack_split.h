@@ -29,9 +29,9 @@ inline void split3(double w, uint16_t (&p)[3]) {
     }
 }
 
-template <int NF32, int RJ>
+template <int NF32, int RJ, int NOUT = 1>
 std::vector<char> pack_split_image(const rnnwf_handle* h) {
-    using L = SplitLayout<NF32, RJ>;
+    using L = SplitLayout<NF32, RJ, NOUT>;
     const int H = h->H;
     std::vector<char> img(L::BYTES, 0);
     const std::string pre = kGruPre;
@@ -41,8 +41,8 @@ std::vector<char> pack_split_image(const rnnwf_handle* h) {
     const auto& bci = pv(h, pre + "candidate/input_projection/bias");
     const auto& Wch = pv(h, pre + "candidate/hidden_projection/kernel");
     const auto& bch = pv(h, pre + "candidate/hidden_projection/bias");
-    const auto& Wd = pv(h, "wf_dense/kernel");
-    const auto& bd = pv(h, "wf_dense/bias");
+    const auto& Wd = pv(h, NOUT == 1 ? "wf_dense/kernel" : "wf_dense_ampl/kernel");
+    const auto& bd = pv(h, NOUT == 1 ? "wf_dense/bias" : "wf_dense_ampl/bias");
     const double sg = PackScale<float>::gate, sc = PackScale<float>::cand;
     uint16_t* A = reinterpret_cast<uint16_t*>(img.data() + L::OFF_A);
     for (int T = 0; T < L::NT; ++T)
@@ -87,9 +87,19 @@ std::vector<char> pack_split_image(const rnnwf_handle* h) {
             if (u >= H) continue;
             for (int sgm = 0; sgm < 2; ++sgm)
                 XC[(size_t)(sgm * 2 + hh) * L::NUP + e] = (float)(sc * (bci[u] + Wci[(size_t)sgm * H + u]));
-            WD[(size_t)hh * L::NUP + e] = (float)(Wd[(size_t)u * 2 + 1] - Wd[(size_t)u * 2]);
+            WD[((size_t)hh * L::NUP + e) * NOUT] = (float)(Wd[(size_t)u * 2 + 1] - Wd[(size_t)u * 2]);
+            if (NOUT == 3) {
+                const auto& Wp = pv(h, "wf_dense_phase/kernel");
+                WD[((size_t)hh * L::NUP + e) * NOUT + 1] = (float)Wp[(size_t)u * 2];
+                WD[((size_t)hh * L::NUP + e) * NOUT + 2] = (float)Wp[(size_t)u * 2 + 1];
+            }
         }
     BD[0] = (float)(bd[1] - bd[0]);
+    if (NOUT == 3) {
+        const auto& bp = pv(h, "wf_dense_phase/bias");
+        BD[1] = (float)bp[0];
+        BD[2] = (float)bp[1];
+    }
     return img;
 }
 

@@ -419,6 +419,12 @@ extern "C" int rnnwf_timing_get(rnnwf_handle* h, int32_t id, double* total_ms, i
     return RNNWF_OK;
 }
 
+extern "C" const char* rnnwf_engine_name(const rnnwf_handle* h) {
+    if (!h) return "";
+    if (h->f64) return "f64mfma";
+    return h->engine_split ? "bf16x3" : "f32mfma";
+}
+
 extern "C" int rnnwf_synchronize(rnnwf_handle* h) {
     if (!h) return RNNWF_ERR_INVALID;
     RNNWF_HIP(h, hipSetDevice(h->cfg.device));

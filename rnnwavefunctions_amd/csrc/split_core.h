@@ -20,6 +20,8 @@
 // Gate rows: full block t -> tiles 3t + {r, u, c}; remainder units -> NMIX "mixed" tiles, slot g RJ + j.
 // Two extra K entries per part carry the bias (entry NU, value 1) and the one-hot input (entry NU+1, value sigma).
 #pragma once
+#include <type_traits>
+
 #include "gru_core.h"
 
 namespace rnnwf {
@@ -28,8 +30,9 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int NF32_, int RJ_>
+template <int NF32_, int RJ_, int NOUT_ = 1>
 struct SplitLayout {
+    static constexpr int NOUT = NOUT_;                  // head rows: 1 (pRNN logit difference), 3 (cRNN: + 2 phase logits)
     static constexpr int NF32 = NF32_, RJ = RJ_;
     static constexpr int NMIX = (3 * RJ + 15) / 16;
     static constexpr int NT = 3 * NF32 + NMIX;          // 32-row output tiles
@@ -41,8 +44,8 @@ struct SplitLayout {
     static constexpr int HP = 32 * NF32 + 2 * RJ;       // padded hidden size
     static constexpr size_t OFF_A = 0;                                         // [NT][3][NQ][64] x 16 B
     static constexpr size_t OFF_XC = OFF_A + (size_t)NT * 3 * NQ * 64 * 16;    // [2 sigma][2 hh][NUP] f32 (scaled)
-    static constexpr size_t OFF_WD = OFF_XC + (size_t)2 * 2 * NUP * 4;         // [2 hh][NUP] f32 head difference weights
-    static constexpr size_t OFF_BD = OFF_WD + (size_t)2 * NUP * 4;             // [4] f32 (bd difference, pad)
+    static constexpr size_t OFF_WD = OFF_XC + (size_t)2 * 2 * NUP * 4;         // [2 hh][NUP][NOUT] f32 head weights
+    static constexpr size_t OFF_BD = OFF_WD + (size_t)2 * NUP * NOUT * 4;      // [4] f32 head biases (padded)
     static constexpr size_t BYTES = OFF_BD + 16;
     // unit owned by entry e of lane half hh
     static constexpr int unit_of(int e, int hh) {
@@ -57,9 +60,9 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
     return r;
 }
 
-template <int NF32, int RJ>
+template <int NF32, int RJ, int NOUT = 1>
 struct SplitCore {
-    using L = SplitLayout<NF32, RJ>;
+    using L = SplitLayout<NF32, RJ, NOUT>;
     static constexpr int NT = L::NT, NU = L::NU, NQ = L::NQ, NR = L::NR;
 
     static __device__ __forceinline__ void stage(char* lds, const void* wimg) {
@@ -103,35 +106,9 @@ struct SplitCore {
 #pragma unroll
         for (int k = 0; k < 16; ++k) zero[k] = 0.0f;       // folds into the MFMA's inline-constant C operand
         const u32x4* av = reinterpret_cast<const u32x4*>(lds + L::OFF_A) + lane;
-        // (weight part, state part), smallest products first.  The A fragments of k-step k+1 are read from LDS while
-        // k-step k's MFMAs run (two register sets); the compiler barrier keeps later reads from being hoisted too
-        // (120 fragment quads in flight would cost all the occupancy).
-        constexpr int ORD[6][2] = {{2, 0}, {1, 1}, {0, 2}, {1, 0}, {0, 1}, {0, 0}};
-        constexpr int NK = 6 * NQ;
-        u32x4 cur[NT], nxt[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) cur[t] = av[((t * 3 + ORD[0][0]) * NQ + 0) * 64];
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const int o = k / NQ, x = k % NQ;
-            const int p = ORD[o][1];
-            if (k + 1 < NK) {
-                const int o2 = (k + 1) / NQ, x2 = (k + 1) % NQ, a2 = ORD[o2][0];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) nxt[t] = av[((t * 3 + a2) * NQ + x2) * 64];
-            }
-            const u32x4 bq = {R[p][4 * x], R[p][4 * x + 1], R[p][4 * x + 2], R[p][4 * x + 3]};
-            const bf16x8 b = __builtin_bit_cast(bf16x8, bq);
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur[t]), b, k == 0 ? zero : acc[t], 0, 0, 0);
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int t = 0; t < NT; ++t) cur[t] = nxt[t];
-        }
         const float* xc = reinterpret_cast<const float*>(lds + L::OFF_XC) + (size_t)((sig * 2 + hh) * L::NUP);
-#pragma unroll
-        for (int e = 0; e < NU; ++e) {
+        // gate arithmetic of one owned unit (entry e) from its three accumulator slots
+        auto gate = [&](int e) {
             float ar, au, ac;
             if (e < 16 * NF32) {
                 ar = acc[3 * (e / 16)][e % 16];
@@ -147,19 +124,76 @@ struct SplitCore {
             const float ug = Act<float>::sigmoid_scaled(au);
             const float cc = Act<float>::tanh_scaled(xc[e] + rg * ac);
             h[e] = cc + ug * (h[e] - cc);
+        };
+        // (weight part, state part), smallest products first.  The A fragments of k-step k+1 are read from LDS while
+        // k-step k's MFMAs run (two register sets); the compiler barrier keeps later reads from being hoisted too
+        // (120 fragment quads in flight would cost all the occupancy).  Two passes over the k-steps: first the mixed
+        // tiles (remainder units), then the full tiles - so that the remainder units' gate arithmetic (VALU) can sit
+        // between the second pass's MFMAs: the bf16 matrix pipe lets ~2 VALU ops per MFMA issue for free (measured,
+        // profiles/r01_c_microbench_*), unlike the f32-input MFMA.
+        constexpr int ORD[6][2] = {{2, 0}, {1, 1}, {0, 2}, {1, 0}, {0, 1}, {0, 0}};
+        constexpr int NK = 6 * NQ;
+        constexpr int TF = 3 * NF32;                       // full tiles [0, TF), mixed tiles [TF, NT)
+        auto pass = [&](auto lo_c, auto hi_c, auto fill) {
+            constexpr int T0 = decltype(lo_c)::value, T1 = decltype(hi_c)::value;
+            if constexpr (T1 > T0) {
+                u32x4 cur[T1 - T0], nxt[T1 - T0];
+#pragma unroll
+                for (int t = T0; t < T1; ++t) cur[t - T0] = av[((t * 3 + ORD[0][0]) * NQ + 0) * 64];
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const int o = k / NQ, x = k % NQ;
+                    const int p = ORD[o][1];
+                    if (k + 1 < NK) {
+                        const int o2 = (k + 1) / NQ, x2 = (k + 1) % NQ, a2 = ORD[o2][0];
+#pragma unroll
+                        for (int t = T0; t < T1; ++t) nxt[t - T0] = av[((t * 3 + a2) * NQ + x2) * 64];
+                    }
+                    const u32x4 bq = {R[p][4 * x], R[p][4 * x + 1], R[p][4 * x + 2], R[p][4 * x + 3]};
+                    const bf16x8 b = __builtin_bit_cast(bf16x8, bq);
+#pragma unroll
+                    for (int t = T0; t < T1; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur[t - T0]), b,
+                                                                         k == 0 ? zero : acc[t], 0, 0, 0);
+                    fill(k);
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int t = T0; t < T1; ++t) cur[t - T0] = nxt[t - T0];
+                }
+            }
+        };
+        pass(std::integral_constant<int, TF>{}, std::integral_constant<int, NT>{}, [](int) {});
+        pass(std::integral_constant<int, 0>{}, std::integral_constant<int, TF>{}, [&](int k) {
+            // remainder unit j after k-step 2j+1 of the full-tile pass
+            if constexpr (TF > 0 && NT > TF) {
+                if ((k & 1) && (k >> 1) < RJ) gate(16 * NF32 + (k >> 1));
+            }
+        });
+        if constexpr (TF > 0 && NT > TF) {
+#pragma unroll
+            for (int j = NK / 2; j < RJ; ++j) gate(16 * NF32 + j);       // (only if RJ exceeds the k-steps available)
+#pragma unroll
+            for (int e = 0; e < 16 * NF32; ++e) gate(e);
+        } else {
+#pragma unroll
+            for (int e = 0; e < NU; ++e) gate(e);
         }
     }
 
-    // logit difference of the output head, reduced over the two lane halves
-    static __device__ __forceinline__ float head(const char* lds, const float (&h)[NU], int lane) {
+    // output head rows (row 0: softmax logit difference), reduced over the two lane halves
+    static __device__ __forceinline__ void head(const char* lds, const float (&h)[NU], int lane, float (&z)[NOUT]) {
         const int hh = lane >> 5;
         asm volatile("" ::: "memory");
-        const float* wd = reinterpret_cast<const float*>(lds + L::OFF_WD) + hh * L::NUP;
-        float z = 0.0f;
+        const float* wd = reinterpret_cast<const float*>(lds + L::OFF_WD) + hh * L::NUP * NOUT;
 #pragma unroll
-        for (int e = 0; e < NU; ++e) z = fmaf(h[e], wd[e], z);
-        z += __shfl_xor(z, 32);
-        return z + reinterpret_cast<const float*>(lds + L::OFF_BD)[0];
+        for (int o = 0; o < NOUT; ++o) z[o] = 0.0f;
+#pragma unroll
+        for (int e = 0; e < NU; ++e)
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) z[o] = fmaf(h[e], wd[e * NOUT + o], z[o]);
+        const float* bd = reinterpret_cast<const float*>(lds + L::OFF_BD);
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) z[o] += __shfl_xor(z[o], 32) + bd[o];
     }
 };
 

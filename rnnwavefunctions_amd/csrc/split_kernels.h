@@ -46,9 +46,10 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_flip_split_kernel(PrnnArgs a,
             const int sig = spin(n);
             C::split(h, sig_in, R);
             C::step(lds, sig_in, R, h, lane);
-            const float d = C::head(lds, h, lane);
+            float z[1];
+            C::head(lds, h, lane, z);
             float lp0, lp1;
-            log_softmax2(d, lp0, lp1);
+            log_softmax2(z[0], lp0, lp1);
             lp += (double)(sig ? lp1 : lp0);
             sig_in = sig;
         }

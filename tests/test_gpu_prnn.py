@@ -245,3 +245,31 @@ def test_edge_sizes(N, H, ns):
     u = philox.uniforms(1, 0, 0, ns, N)
     s_ref, _ = M.prnn_sample(prm, N, u)
     assert (s != s_ref).any(axis=1).sum() <= 1
+
+
+@pytest.mark.parametrize("N,H,ns", [(20, 10, 100), (33, 20, 50), (40, 36, 64), (65, 50, 37), (30, 64, 33)])
+def test_both_flip_engines_agree_with_the_f64_oracle(N, H, ns, monkeypatch):
+    """The flip pass runs on the bf16x3 engine by default (three-way exact bf16 split of both operands, f32
+    accumulate; csrc/split_core.h) and on the f32-input MFMA with RNNWF_ENGINE=f32.  Both must match the float64
+    oracle to the same f32-level tolerance, and each other."""
+    from rnnwavefunctions_amd import _lib
+    prm = trained_like(H, seed=2 * N + H)
+    prm64 = {k: v.astype(np.float64) for k, v in prm.items()}
+    rng = np.random.RandomState(7)
+    s = rng.randint(0, 2, (ns, N)).astype(np.int32)
+    Jz = 1.0 + 0.1 * rng.standard_normal(N)
+    e64, lp64 = E.ising_local_energies(Jz, 1.1, s, lambda x: M.prnn_log_probability(prm64, x, dtype=np.float64),
+                                       return_log_probs=True)
+    got = {}
+    for engine in ("f32", "bf16x3"):
+        monkeypatch.setenv("RNNWF_ENGINE", engine)
+        wf = make_wf(_lib.MODEL_GRU1D, N, H, prm)            # the engine is chosen when the parameters are committed
+        lp = np.zeros((N + 1) * ns)
+        e = wf.tfim_eloc(s, Jz, 1.1, log_probs=lp)
+        got[engine] = (e, lp)
+        err_lp = np.abs(lp - lp64.ravel()).max()
+        err_e = np.abs(e / e64 - 1).max()
+        print("N=%d H=%d %-6s: max|lp - f64| = %.2e   max rel E err = %.2e" % (N, H, engine, err_lp, err_e))
+        assert err_lp <= 2e-6 * N + 2e-6
+        assert err_e <= 2e-5
+    assert np.allclose(got["f32"][0], got["bf16x3"][0], rtol=2e-5)
