@@ -98,6 +98,32 @@ def cpu_baseline(wl, prm, target_seconds=15.0):
                       "<=25000-row chunks), C/OpenMP restatement oracle/c/rnnwf_oracle.c, %.1f s" % (ns_cpu, ns_full, dt)}
 
 
+def alt_engine_run(wl, couplings, warmup, steps):
+    """The same workload with the flip/swap pass forced onto the f32-input MFMA (RNNWF_ENGINE=f32), so that the
+    line carries both engines; reported beside `value`, never instead of it."""
+    os.environ["RNNWF_ENGINE"] = "f32"
+    try:
+        wf, _, _ = make_wavefunction(wl, device=int(os.environ.get("LOCAL_RANK", "0")))
+    finally:
+        del os.environ["RNNWF_ENGINE"]
+    ns, N = wl["ns"], wl["N"]
+    for it in range(warmup):
+        wf.vmc_step(ns, seed=111, step=it, couplings=couplings)
+    wf.timing_enable(True)
+    wf.timing_reset()
+    wf.synchronize()
+    t0 = time.perf_counter()
+    for it in range(steps):
+        m = wf.vmc_step(ns, seed=111, step=warmup + it, couplings=couplings)["moments"]
+    wf.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    k = wf.timing_get(1)
+    launches = max(k["launches"], 1)
+    ach = k["cell_evals"] / launches * f_cell(wl) / (k["total_ms"] / launches * 1e-3) / 1e12
+    return {"engine": wf.engine_name(), "value": ns * N / dt, "ms_per_step": dt * 1e3, "steps": steps,
+            "roofline_frac": ach / PEAK_TFLOPS["f32"], "avg_launch_ms": k["total_ms"] / launches, "mean_E": m[0] / m[2]}
+
+
 def load_traffic(workload):
     """HBM bytes per flip-kernel launch measured with rocprofv3 --pmc (separate pass), if recorded."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -116,6 +142,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--numsamples", type=int, default=0, help="per-GPU batch override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-engine", action="store_true", help="skip the extra f32-input-MFMA timing")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -216,6 +243,8 @@ def main():
                          "base_pass_ms": base["total_ms"] / max(base["launches"], 1),
                          "assembly_ms": asm["total_ms"] / max(asm["launches"], 1) * (asm["launches"] / launches)},
         }
+        if engine == "bf16x3" and world == 1 and not args.no_alt_engine:
+            rec["f32mfma_engine"] = alt_engine_run(wl, couplings, args.warmup, max(args.steps // 2, 3))
         if not args.no_cpu_baseline and world == 1 and wl["kind"] == "tfim1d":
             rec["cpu_baseline"] = cpu_baseline(wl, prm)
         else:
