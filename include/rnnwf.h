@@ -154,16 +154,19 @@ int rnnwf_vmc_step(rnnwf_handle* h, int64_t numsamples, uint64_t seed, uint64_t 
                    const double* couplings, int64_t n_couplings, int32_t* out_samples, void* out_eloc,
                    double* moments);
 
-/* ---- gradient of the VMC cost (1D positive GRU RNN, f32) ------------------
+/* ---- gradient of the VMC cost (1D positive and complex GRU RNNs, f32) ------
  * rnnwf_vmc_gradient <- optimizer.compute_gradients(cost) with
  *   cost = mean(log_probs * Eloc) - mean(Eloc) * mean(log_probs)      (1DTFIM/TrainingRNN_1DTFIM.py:151-162)
  *   evaluated on the batch of the LAST rnnwf_vmc_step (its samples, per-site hidden states and E_loc are still
  *   resident):  grad = sum_s (E_s - mean_energy) / norm * d log P(s) / d theta.  Single device: mean_energy =
  *   moments[0]/moments[2], norm = numsamples; sharded: the all-reduced mean and the global sample count, then
  *   rnnwf_allreduce_grads.  Back-propagation through time on the MFMA + a TN GEMM for the weight gradients.
+ *   Complex RNN: cost = 2 Re(mean(conj(log_amplitudes) Eloc) - conj(mean(log_amplitudes)) mean(Eloc))
+ *   (J1J2/TrainingRNN_J1J2.py:197), i.e. grad = 2/norm sum_s [(Re E_s - mean_energy) d Re log psi +
+ *   (Im E_s - mean_energy_im) d Im log psi]; mean_energy_im is ignored for the positive RNN.
  * rnnwf_get_grad     <- the gradient of one TF variable (same names and shapes as rnnwf_set_param).
  * rnnwf_allreduce_grads: one RCCL all-reduce (sum) over all gradient arrays of the handle.             */
-int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double norm);
+int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double mean_energy_im, double norm);
 int rnnwf_get_grad(rnnwf_handle* h, const char* tf_name, void* data, int64_t count, int32_t dtype);
 int rnnwf_allreduce_grads(rnnwf_handle* h);
 

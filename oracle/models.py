@@ -157,20 +157,20 @@ def prnn_sample(params, N, u, scope="RNNwavefunction", dtype=np.float32):
 
 def _heavyside(x):
     """J1J2/ComplexRNNwavefunction.py:11-13 : 1 where x >= 0 else 0."""
-    return (0.5 * (np.sign(np.sign(x) + np.float32(0.1)) + 1.0)).astype(np.float32)
+    return (0.5 * (np.sign(np.sign(x) + x.dtype.type(0.1)) + 1.0)).astype(x.dtype)
 
 
 def _l2_normalize(x, eps=1e-30):
     """tf.nn.l2_normalize(axis=1): x * rsqrt(max(sum x^2, eps))."""
-    ss = np.maximum((x * x).sum(axis=1, keepdims=True), np.float32(eps))
-    return (x / np.sqrt(ss)).astype(np.float32)
+    ss = np.maximum((x * x).sum(axis=1, keepdims=True), x.dtype.type(eps))
+    return (x / np.sqrt(ss)).astype(x.dtype)
 
 
 def _crnn_masked_ampl(out, Wa, ba, n, N, num_up):
     ampl = np.sqrt(softmax(out @ Wa + ba))                  # :5-6, :83 / :143
     if n >= N / 2:                                          # :85 / :147
-        baseline = np.float32(N // 2 - 1)
-        num_down = np.float32(n) - num_up
+        baseline = num_up.dtype.type(N // 2 - 1)
+        num_down = num_up.dtype.type(n) - num_up
         act_up = _heavyside(baseline - num_up)              # :89 / :151
         act_down = _heavyside(baseline - num_down)
         ampl = ampl * np.stack([act_down, act_up], axis=1)  # :92 / :154
@@ -199,9 +199,10 @@ def crnn_sample(params, N, u, scope="RNNwavefunction"):
     return samples
 
 
-def crnn_log_amplitude(params, samples, scope="RNNwavefunction"):
-    """J1J2/ComplexRNNwavefunction.py:126-167 -> complex64 (B,)."""
-    dtype = np.float32
+def crnn_log_amplitude(params, samples, scope="RNNwavefunction", dtype=np.float32):
+    """J1J2/ComplexRNNwavefunction.py:126-167 -> complex64 (B,)  (dtype=float64 -> complex128: used only to take
+    finite differences of the cost in the gradient tests)."""
+    ctype = np.complex64 if dtype == np.float32 else np.complex128
     samples = np.asarray(samples)
     B, N = samples.shape
     Wa = _p(params, scope, "wf_dense_ampl/kernel")
@@ -210,19 +211,19 @@ def crnn_log_amplitude(params, samples, scope="RNNwavefunction"):
     bp = _p(params, scope, "wf_dense_phase/bias")
     x = np.zeros((B, 2), dtype=dtype)
     states = _zero_states(params, scope, B, dtype)
-    sel = np.empty((B, N), dtype=np.complex64)
+    sel = np.empty((B, N), dtype=ctype)
     rows = np.arange(B)
     for n in range(N):
         out, states = multi_gru(x, states, params, scope)
-        num_up = samples[:, :n].sum(axis=1).astype(np.float32)          # :148
+        num_up = samples[:, :n].sum(axis=1).astype(dtype)               # :148
         ampl = _crnn_masked_ampl(out, Wa, ba, n, N, num_up)
         z = out @ Wp + bp
-        phase = (np.float32(np.pi) * (z / (np.float32(1) + np.abs(z)))).astype(np.float32)   # :8-9, :145
-        amp_c = ampl.astype(np.complex64) * np.exp(1j * phase.astype(np.complex64)).astype(np.complex64)  # :157
+        phase = (dtype(np.pi) * (z / (dtype(1) + np.abs(z)))).astype(dtype)   # :8-9, :145
+        amp_c = ampl.astype(ctype) * np.exp(1j * phase.astype(ctype)).astype(ctype)  # :157
         sel[:, n] = amp_c[rows, samples[:, n]]                            # :165-167 one-hot select
         x = _one_hot(samples[:, n], dtype)                                # :161
     with np.errstate(divide="ignore"):
-        return np.log(sel).sum(axis=1).astype(np.complex64)               # :167
+        return np.log(sel).sum(axis=1).astype(ctype)                      # :167
 
 
 # ----------------------------------------------------------------------------------------------

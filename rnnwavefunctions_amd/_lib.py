@@ -46,7 +46,7 @@ PROTOTYPES = {
     "rnnwf_tfim2d_eloc": (C.c_int, [_P, _I32P, _I64, _F64P, _F64, _F64P, _F64P]),
     "rnnwf_j1j2_eloc": (C.c_int, [_P, _I32P, _I64, _F64P, _F64P, _F64P, _I32, _I32, _F32P, C.POINTER(_I64)]),
     "rnnwf_vmc_step": (C.c_int, [_P, _I64, _U64, _U64, _I64, _F64P, _I64, _I32P, _P, _F64P]),
-    "rnnwf_vmc_gradient": (C.c_int, [_P, _F64, _F64]),
+    "rnnwf_vmc_gradient": (C.c_int, [_P, _F64, _F64, _F64]),
     "rnnwf_get_grad": (C.c_int, [_P, C.c_char_p, _P, _I64, _I32]),
     "rnnwf_allreduce_grads": (C.c_int, [_P]),
     "rnnwf_comm_unique_id": (C.c_int, [_P]),
@@ -251,9 +251,10 @@ class NativeWavefunction:
 
     # -- gradient of the VMC cost -----------------------------------------------------------------
     def vmc_gradient(self, mean_energy, norm, shapes, allreduce=False):
-        """Gradient of mean(logP*E) - mean(E)*mean(logP) on the batch of the last vmc_step.
-        shapes: {tf_name (without scope): shape}; returns {tf_name: float64 ndarray}."""
-        self._check(self.lib.rnnwf_vmc_gradient(self.h, float(mean_energy), float(norm)))
+        """Gradient of the reference's cost on the batch of the last vmc_step (mean_energy may be complex for
+        the complex RNN).  shapes: {tf_name (without scope): shape}; returns {tf_name: float64 ndarray}."""
+        me = complex(mean_energy)
+        self._check(self.lib.rnnwf_vmc_gradient(self.h, me.real, me.imag, float(norm)))
         if allreduce:
             self._check(self.lib.rnnwf_allreduce_grads(self.h))
         out = {}

@@ -234,6 +234,7 @@ int rnnwf::crnn_pack_image(rnnwf_handle* h, std::vector<char>& img) {
 int rnnwf::crnn_sample(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t step, int64_t offset, int32_t* out,
                        double* out_log) {
     const int W = (h->N + 31) / 32;
+    h->last_ns = 0;
     if (int rc = ensure(h, h->bits, (size_t)W * ns * 4)) return rc;
     if (int rc = ensure(h, h->out_lp, (size_t)ns * 8)) return rc;
     CrnnArgs a = base_args(h, ns);
@@ -250,6 +251,7 @@ int rnnwf::crnn_sample(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t step
 
 int rnnwf::crnn_log_amp(rnnwf_handle* h, const int32_t* samples, int64_t B, float* out_re_im, double* out_logp) {
     const int N = h->N;
+    h->last_ns = 0;
     for (int64_t off = 0; off < B; off += kChunk) {
         const int64_t nb = std::min(kChunk, B - off);
         if (int rc = upload_and_pack(h, samples + off * N, nb, h->bits, 0, nullptr)) return rc;
@@ -272,6 +274,7 @@ int rnnwf::crnn_log_amp(rnnwf_handle* h, const int32_t* samples, int64_t B, floa
 int rnnwf::crnn_j1j2_eloc(rnnwf_handle* h, const int32_t* samples, int64_t ns, const double* J1, const double* J2,
                           const double* Bz, int periodic, int marshall, float* eloc, int64_t* ncon) {
     const int N = h->N;
+    h->last_ns = 0;
     if (int rc = ensure(h, h->coupl, (size_t)3 * N * 8)) return rc;
     RNNWF_HIP(h, hipMemcpyAsync(h->coupl.p, J1, (size_t)N * 8, hipMemcpyHostToDevice, h->stream));
     RNNWF_HIP(h, hipMemcpyAsync((double*)h->coupl.p + N, J2, (size_t)N * 8, hipMemcpyHostToDevice, h->stream));
@@ -304,6 +307,8 @@ int rnnwf::crnn_vmc_step(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t st
     if (int rc = j1j2_on_device(h, ns, true, seed, step, offset, (const double*)h->coupl.p, periodic, marshall)) return rc;
     if (out_samples) if (int rc = unpack_and_download(h, h->bits, ns, out_samples, nullptr)) return rc;
     if (out_eloc) RNNWF_HIP(h, hipMemcpyAsync(out_eloc, h->eloc.p, (size_t)ns * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
+    h->last_ns = ns;                  // bits, hck and eloc stay resident for rnnwf_vmc_gradient
+    h->last_has_ckpt = true;
     if (int rc = run_moments(h, h->eloc.p, ns, true, moments)) return rc;   // syncs the stream
     collect_totals(h, ns);
     return RNNWF_OK;

@@ -10,9 +10,9 @@ using namespace rnnwf;
 
 namespace {
 
-template <int NFULL, int WAVES>
+template <int NFULL, int WAVES, int NOUT>
 struct GLaunch {
-    using L = GruLayout<float, NFULL, 1>;
+    using L = GruLayout<float, NFULL, NOUT>;
     using G = GradLayout<NFULL>;
 
     static std::vector<char> pack_bwd(const rnnwf_handle* h) {
@@ -46,7 +46,7 @@ struct GLaunch {
 
     static int run(rnnwf_handle* h, GradArgs a, int64_t R, float* dW) {
         static int bpc = 0;
-        const void* fn = (const void*)prnn_bwd_kernel<NFULL, WAVES>;
+        const void* fn = (const void*)gru_bwd_kernel<NFULL, WAVES, NOUT>;
         const size_t lds = L::BYTES + G::BWD_BYTES;
         if (!bpc) {
             RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -55,7 +55,7 @@ struct GLaunch {
         }
         const int64_t need = (a.nsb + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
-        prnn_bwd_kernel<NFULL, WAVES><<<grid, WAVES * 64, lds, h->stream>>>(a);
+        gru_bwd_kernel<NFULL, WAVES, NOUT><<<grid, WAVES * 64, lds, h->stream>>>(a);
         RNNWF_HIP(h, hipGetLastError());
         int64_t rpb = (R + (int64_t)h->cu_count * 4 - 1) / ((int64_t)h->cu_count * 4);
         rpb = std::max<int64_t>(64, ((rpb + 3) / 4) * 4);
@@ -79,12 +79,21 @@ struct GLaunch {
         auto& gbci = h->grads[pre + "candidate/input_projection/bias"];
         auto& gWch = h->grads[pre + "candidate/hidden_projection/kernel"];
         auto& gbch = h->grads[pre + "candidate/hidden_projection/bias"];
-        auto& gWd = h->grads["wf_dense/kernel"];
-        auto& gbd = h->grads["wf_dense/bias"];
+        const char* amp = NOUT == 1 ? "wf_dense" : "wf_dense_ampl";
+        auto& gWd = h->grads[std::string(amp) + "/kernel"];
+        auto& gbd = h->grads[std::string(amp) + "/bias"];
         gWg.assign((size_t)(2 + H) * 2 * H, 0.0); gbg.assign(2 * H, 0.0);
         gWci.assign((size_t)2 * H, 0.0); gbci.assign(H, 0.0);
         gWch.assign((size_t)H * H, 0.0); gbch.assign(H, 0.0);
         gWd.assign((size_t)H * 2, 0.0); gbd.assign(2, 0.0);
+        std::vector<double>* gWp = nullptr;
+        std::vector<double>* gbp = nullptr;
+        if (NOUT == 3) {
+            gWp = &h->grads["wf_dense_phase/kernel"];
+            gbp = &h->grads["wf_dense_phase/bias"];
+            gWp->assign((size_t)H * 2, 0.0);
+            gbp->assign(2, 0.0);
+        }
         for (int u = 0; u < H; ++u) {
             const int m = u / 16, r = (u % 16) / 4, q = u % 4;
             const bool full = u < 16 * NFULL;
@@ -111,29 +120,47 @@ struct GLaunch {
             const double v = hg[u];          // slot 4 kt + q == unit index
             gWd[(size_t)u * 2 + 1] = v;
             gWd[(size_t)u * 2] = -v;
+            if (NOUT == 3) {
+                (*gWp)[(size_t)u * 2] = hg[G::HEAD_ROW + u];
+                (*gWp)[(size_t)u * 2 + 1] = hg[2 * G::HEAD_ROW + u];
+            }
         }
         gbd[1] = hg[4 * G::KT];
         gbd[0] = -hg[4 * G::KT];
+        if (NOUT == 3) {
+            (*gbp)[0] = hg[G::HEAD_ROW + 4 * G::KT];
+            (*gbp)[1] = hg[2 * G::HEAD_ROW + 4 * G::KT];
+        }
     }
 };
 
-#define GRAD_DISPATCH(h, EXPR)                                  \
-    do {                                                        \
-        switch ((h)->NFULL) {                                   \
-            case 1: { using K = GLaunch<1, 4>; EXPR; }          \
-            case 2: { using K = GLaunch<2, 4>; EXPR; }          \
-            case 3: { using K = GLaunch<3, 4>; EXPR; }          \
-            case 4: { using K = GLaunch<4, 4>; EXPR; }          \
-        }                                                       \
+#define GRAD_DISPATCH(h, EXPR)                                          \
+    do {                                                                \
+        if ((h)->model == RNNWF_MODEL_CRNN_U1) {                        \
+            switch ((h)->NFULL) {                                       \
+                case 1: { using K = GLaunch<1, 4, 3>; EXPR; }           \
+                case 2: { using K = GLaunch<2, 4, 3>; EXPR; }           \
+                case 3: { using K = GLaunch<3, 4, 3>; EXPR; }           \
+                case 4: { using K = GLaunch<4, 4, 3>; EXPR; }           \
+            }                                                           \
+        } else {                                                        \
+            switch ((h)->NFULL) {                                       \
+                case 1: { using K = GLaunch<1, 4, 1>; EXPR; }           \
+                case 2: { using K = GLaunch<2, 4, 1>; EXPR; }           \
+                case 3: { using K = GLaunch<3, 4, 1>; EXPR; }           \
+                case 4: { using K = GLaunch<4, 4, 1>; EXPR; }           \
+            }                                                           \
+        }                                                               \
     } while (0)
 
 }  // namespace
 
-extern "C" int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double norm) {
+extern "C" int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double mean_energy_im, double norm) {
     if (!h) return RNNWF_ERR_INVALID;
     if (!h->committed) return h->fail(RNNWF_ERR_STATE, "parameters not committed");
-    if (h->model != RNNWF_MODEL_GRU1D)
-        return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: implemented for the 1D positive GRU RNN (f32) only so far");
+    if (h->model != RNNWF_MODEL_GRU1D && h->model != RNNWF_MODEL_CRNN_U1)
+        return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: implemented for the 1D positive and complex GRU RNNs (f32) so far");
+    const bool cplx = h->model == RNNWF_MODEL_CRNN_U1;
     if (h->NFULL > 4) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: num_units > 68 not implemented yet");
     if (h->last_ns <= 0 || !h->last_has_ckpt)
         return h->fail(RNNWF_ERR_STATE, "rnnwf_vmc_gradient: call rnnwf_vmc_step first (its samples, states and E_loc are reused)");
@@ -142,7 +169,7 @@ extern "C" int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double no
     const int N = h->N;
     const int64_t ns = h->last_ns, R = ns * N;
     int pcols = 0, qcols = 0, hgn = 0;
-    GRAD_DISPATCH(h, { pcols = K::G::PCOLS; qcols = K::G::QCOLS; hgn = K::G::HEAD_GRADS; break; });
+    GRAD_DISPATCH(h, { pcols = K::G::PCOLS; qcols = K::G::QCOLS; hgn = K::G::HEAD_ROW * (cplx ? 3 : 1); break; });
     if (!h->wbwd.p) {
         std::vector<char> img;
         GRAD_DISPATCH(h, { img = K::pack_bwd(h); break; });
@@ -164,8 +191,10 @@ extern "C" int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double no
     a.bits = (const uint32_t*)h->bits.p;
     a.hck = (const float*)h->hck.p;
     a.eloc = (const double*)h->eloc.p;
+    a.eloc_c = (const float2*)h->eloc.p;
     a.mean_e = mean_energy;
-    a.inv_norm = 1.0 / norm;
+    a.mean_im = mean_energy_im;
+    a.inv_norm = (cplx ? 2.0 : 1.0) / norm;      // the complex cost carries a factor 2 (TrainingRNN_J1J2.py:197)
     a.P = (float*)h->gradP.p;
     a.Q = (float*)h->gradQ.p;
     a.head_grad = (float*)h->gradW.p + (size_t)pcols * qcols;

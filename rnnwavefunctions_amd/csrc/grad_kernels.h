@@ -3,7 +3,7 @@
 // Reference: cost = mean(log P * E_loc) - mean(E_loc) * mean(log P), differentiated by TensorFlow
 // (1DTFIM/TrainingRNN_1DTFIM.py:151-166), i.e.  grad = sum_s w_s dlog P(s)/dtheta,  w_s = (E_s - mean E) / ns.
 //
-//   prnn_bwd_kernel : back-propagation through time for 16 chains per wave, site N-1 down to 0.  Each site
+//   gru_bwd_kernel  : back-propagation through time for 16 chains per wave, site N-1 down to 0.  Each site
 //                     re-computes its gates from the stored input state (hck, written by the base pass), forms
 //                     the pre-activation gradients (VALU) and propagates dL/dh through the transposed weights
 //                     on the f32 MFMA (same lane layout trick as the forward: the C/D fragment is the next B
@@ -27,7 +27,7 @@ struct GradLayout {
     static constexpr int KB = 3 * KT;                     // k-steps of the backward product (gate g, kt)
     static constexpr int KBG = (KB + 3) / 4;              // groups of 4 k-steps (b128 LDS reads)
     static constexpr size_t BWD_BYTES = (size_t)NTO * KBG * 64 * 16;   // [NTO][KBG][64] float4
-    static constexpr int HEAD_GRADS = 4 * KT + 4;         // wd-difference gradient per unit slot + bias
+    static constexpr int HEAD_ROW = 4 * KT + 4;           // per head row: gradient per unit slot (4 KT) + bias (+ pad)
 };
 
 struct GradArgs {
@@ -37,16 +37,20 @@ struct GradArgs {
     int64_t ns, nsb;
     const uint32_t* bits;
     const float* hck;          // [N-1][nsb][KT][64] state after each site
-    const double* eloc;        // [ns]
-    double mean_e, inv_norm;   // w_s = (E_s - mean_e) * inv_norm
+    const double* eloc;        // [ns] f64 (positive RNN) ...
+    const float2* eloc_c;      // ... or [ns] complex64 (complex RNN)
+    double mean_e, mean_im, inv_norm;   // w_s = (E_s - mean) * inv_norm  (real and imaginary part separately)
     float* P;                  // [N*ns][PCOLS]
     float* Q;                  // [N*ns][QCOLS]
-    float* head_grad;          // [HEAD_GRADS], zeroed before the launch
+    float* head_grad;          // [NOUT][HEAD_ROW], zeroed before the launch
 };
 
-template <int NFULL, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64) prnn_bwd_kernel(GradArgs a) {
-    using C = GruCore<float, NFULL, 1>;
+// NOUT = 1: positive RNN, L = sum_s w_s log P(s).
+// NOUT = 3: complex RNN, L = sum_s [w_re Re log psi(s) + w_im Im log psi(s)]  (J1J2/TrainingRNN_J1J2.py:197:
+//           cost = 2 Re(mean(conj(log psi) E) - conj(mean log psi) mean E); the factor 2 is in inv_norm).
+template <int NFULL, int WAVES, int NOUT>
+__global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
+    using C = GruCore<float, NFULL, NOUT>;
     using G = GradLayout<NFULL>;
     using V4 = typename C::V4;
     constexpr int KT = C::KT, NT = C::NT;
@@ -69,12 +73,30 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_bwd_kernel(GradArgs a) {
         const int64_t s = sb * kChains + c;
         const bool valid = s < a.ns;
         const int64_t sc = valid ? s : a.ns - 1;
-        const float w = valid ? (float)((a.eloc[sc] - a.mean_e) * a.inv_norm) : 0.0f;
+        float w = 0.0f, w_im = 0.0f;
+        if (valid) {
+            if constexpr (NOUT == 1) {
+                w = (float)((a.eloc[sc] - a.mean_e) * a.inv_norm);
+            } else {
+                const float2 e = a.eloc_c[sc];
+                w = (float)(((double)e.x - a.mean_e) * a.inv_norm);
+                w_im = (float)(((double)e.y - a.mean_im) * a.inv_norm);
+            }
+        }
         auto spin = [&](int n) { return (int)((a.bits[(int64_t)(n >> 5) * a.ns + sc] >> (n & 31)) & 1); };
-        float dh[KT], hg[KT];
-        float gb = 0.0f;
+        float dh[KT], hg[NOUT][KT];
+        float gb[NOUT];
 #pragma unroll
-        for (int k = 0; k < KT; ++k) { dh[k] = 0.0f; hg[k] = 0.0f; }
+        for (int k = 0; k < KT; ++k) dh[k] = 0.0f;
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            gb[o] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < KT; ++k) hg[o][k] = 0.0f;
+        }
+        int num_up = 0;                                   // complex RNN: up spins among sites < n (for the U(1) mask)
+        if constexpr (NOUT == 3)
+            for (int m = 0; m < N; ++m) num_up += spin(m);
         for (int n = N - 1; n >= 0; --n) {
             float h[KT], hn[KT], rg[KT], ug[KT], cc[KT], qv[KT];
             if (n > 0) {
@@ -88,18 +110,39 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_bwd_kernel(GradArgs a) {
             const int sig_in = n > 0 ? spin(n - 1) : -1;
             const int sig = spin(n);
             C::step_keep(lds, sig_in, h, hn, rg, ug, cc, qv, lane);
-            float z[1];
+            float z[NOUT];
             C::head(lds, hn, lane, z);
-            // d log p(sig) / d(z1 - z0) = sig - p1
+            // gradient of this site's term w.r.t. the head rows
+            float g[NOUT];
             const float p1 = 1.0f - prob0(z[0]);
-            const float g = w * ((float)sig - p1);
-            gb += g;
+            if constexpr (NOUT == 1) {
+                g[0] = w * ((float)sig - p1);                           // d log p(sig) / d(z1 - z0) = sig - p1
+            } else {
+                num_up -= sig;                                          // ups among sites < n
+                bool both = true;                                       // mask: a value that is forced has amplitude 1
+                if (2 * n >= N) {
+                    const int base = N / 2 - 1;
+                    both = (base - (n - num_up) >= 0) && (base - num_up >= 0);
+                }
+                g[0] = both ? 0.5f * w * ((float)sig - p1) : 0.0f;      // d log a(sig) = 1/2 d log p(sig)
+                const float zs = sig ? z[2] : z[1];
+                const float den = 1.0f + fabsf(zs);
+                const float gp = w_im * 3.14159265358979323846f / (den * den);   // d (pi softsign(z)) / dz
+                g[1] = sig ? 0.0f : gp;
+                g[2] = sig ? gp : 0.0f;
+            }
             float dp[4 * G::KBG];
             float dy[KT];
 #pragma unroll
+            for (int o = 0; o < NOUT; ++o) gb[o] += g[o];
+#pragma unroll
             for (int k = 0; k < KT; ++k) {
-                hg[k] = fmaf(g, hn[k], hg[k]);
-                const float d = fmaf(g, wd[k], dh[k]);                  // total dL/dh_n of this lane's unit
+                float d = dh[k];                                        // total dL/dh_n of this lane's unit
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) {
+                    hg[o][k] = fmaf(g[o], hn[k], hg[o][k]);
+                    d = fmaf(g[o], wd[k * NOUT + o], d);
+                }
                 const float du = d * (h[k] - cc[k]);
                 const float dc = d * (1.0f - ug[k]);
                 dh[k] = d * ug[k];                                      // direct path to h_{n-1}
@@ -159,17 +202,18 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_bwd_kernel(GradArgs a) {
                 for (int r = 0; r < 4; ++r) dh[4 * m + r] += accb[m][r];
             dh[KT - 1] += accb[NFULL][0];
         }
-        // head gradients: reduce over the 16 chains of each lane quarter, one atomic per (unit slot)
+        // head gradients: reduce over the 16 chains of each lane quarter, one atomic per (row, unit slot)
 #pragma unroll
-        for (int k = 0; k < KT; ++k) {
-            float v = hg[k];
+        for (int o = 0; o < NOUT; ++o) {
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                float v = hg[o][k];
+                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                if (c == 0) atomicAdd(&a.head_grad[o * G::HEAD_ROW + 4 * k + q], v);
+            }
+            float v = gb[o];
             v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-            if (c == 0) atomicAdd(&a.head_grad[4 * k + q], v);
-        }
-        {
-            float v = gb;
-            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-            if (c == 0 && q == 0) atomicAdd(&a.head_grad[4 * KT], v);
+            if (c == 0 && q == 0) atomicAdd(&a.head_grad[o * G::HEAD_ROW + 4 * KT], v);
         }
     }
 }

@@ -1,6 +1,7 @@
 """VMC training drivers with the reference's call signatures.
 
     run_1DTFIM  <- 1DTFIM/TrainingRNN_1DTFIM.py:79-229
+    run_J1J2    <- J1J2/TrainingRNN_J1J2.py:131-308
 
 One iteration of the reference loop (:199-227) is: draw samples, local energies, mean/var, print every 10 steps,
 Adam step on  cost = mean(log_probs * Eloc) - mean(Eloc) * mean(log_probs)  (:156).  Here the whole iteration but
@@ -87,4 +88,49 @@ def run_1DTFIM(numsteps=10 ** 4, systemsize=20, num_units=50, Bx=1, num_layers=1
             if it % 500 == 0:
                 P.save_npz(os.path.join(save_dir, "RNNwavefunction" + tag + ".npz"), params)
     run_1DTFIM.last_params = params
+    return meanEnergy, varEnergy
+
+
+def run_J1J2(numsteps=10 ** 5, systemsize=20, J1_=1.0, J2_=0.0, Marshall_sign=False, num_units=50, num_layers=1,
+             numsamples=500, learningrate=2.5 * 1e-4, seed=111, save_dir=None, device=0, verbose=True):
+    """Train the complex RNN wave function (U(1) zero magnetisation) on the open J1-J2 chain; returns
+    (meanEnergy, varEnergy) as the reference's run_J1J2 (meanEnergy complex, varEnergy = var of the real part).
+
+    As in the reference, `Marshall_sign` reaches J1J2MatrixElements through J1J2Slices' `periodic` slot
+    (J1J2/TrainingRNN_J1J2.py:118): Marshall_sign=True therefore selects the PERIODIC chain
+    without a Marshall sign - reproduced here on purpose so that runs compare with the reference's."""
+    if num_layers != 1:
+        raise ValueError("only num_layers = 1 is implemented on gfx950 (the reference's run scripts use 1)")
+    N = systemsize
+    scope = "RNNwavefunction"
+    lr = np.float64(learningrate)
+    units = [num_units] * num_layers
+    params = P.init_gru_params(units, seed=seed, scope=scope, heads=("wf_dense_ampl", "wf_dense_phase"))
+    wf = _lib.NativeWavefunction(_lib.MODEL_CRNN_U1, N, 1, tuple(units), device=device)
+    wf.set_params(params, scope=scope)
+    if verbose:
+        print("The number of params is {0}".format(P.count_params(params)))
+    periodic = 1.0 if Marshall_sign else 0.0          # the reference's quirk, see the docstring
+    couplings = np.concatenate([J1_ * np.ones(N), J2_ * np.ones(N), np.zeros(N), [periodic, 0.0]])
+    opt = Adam(beta1=0.9, beta2=0.999, epsilon=1e-8)
+    ending = "_units" + "".join("_{0}".format(u) for u in units)
+    meanEnergy, varEnergy = [], []
+    for it in range(numsteps + 1):
+        s1, s2, n, si = wf.vmc_step(numsamples, seed=seed, step=it, couplings=couplings)["moments"]
+        meanE = np.complex64(complex(s1 / n, si / n))
+        varE = s2 / n - (s1 / n) ** 2
+        meanEnergy.append(meanE)
+        varEnergy.append(varE)
+        if verbose and it % 10 == 0:
+            print("mean(E): {0}, var(E): {1}, #samples {2}, #Step {3} \n\n".format(meanE, varE, numsamples, it))
+        grads = cost_gradient(wf, params, scope, complex(s1 / n, si / n), numsamples)
+        params = opt.step(params, grads, lr)
+        wf.set_params(params, scope=scope)
+        if save_dir is not None and it % 10 == 0:
+            tag = "_N" + str(N) + "_samp" + str(numsamples) + "_lradap" + str(lr) + "_complexGRURNN_J1J2" + str(float(J2_)) + ending + "_zeromag"
+            np.save(os.path.join(save_dir, "meanEnergy" + tag + ".npy"), meanEnergy)
+            np.save(os.path.join(save_dir, "varEnergy" + tag + ".npy"), varEnergy)
+            if it % 500 == 0:
+                P.save_npz(os.path.join(save_dir, "RNNwavefunction" + tag + ".npz"), params)
+    run_J1J2.last_params = params
     return meanEnergy, varEnergy

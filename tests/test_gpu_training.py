@@ -69,3 +69,55 @@ def test_run_1dtfim_reaches_the_exact_ground_state_energy():
     assert final > ed - 0.02                    # variational (up to the Monte-Carlo error of the mean)
     assert abs(final - ed) < 0.03               # the notebook reaches -12.3808 after 1000 steps
     assert np.mean(varE[-50:]) < 0.5 * varE[0]  # zero-variance principle: variance collapses near an eigenstate
+
+
+def oracle_cost_complex(prm64, samples, eloc):
+    la = M.crnn_log_amplitude(prm64, samples, dtype=np.float64)
+    return 2 * np.real(np.mean(np.conj(la) * eloc) - np.conj(np.mean(la)) * np.mean(eloc))   # TrainingRNN_J1J2.py:197
+
+
+@pytest.mark.parametrize("N,H,ns", [(8, 6, 64), (12, 20, 48), (10, 50, 32)])
+def test_complex_gradient_matches_finite_differences_of_the_oracle(N, H, ns):
+    from rnnwavefunctions_amd import _lib
+    from rnnwavefunctions_amd.training import cost_gradient
+    heads = ("wf_dense_ampl", "wf_dense_phase")
+    prm = P.randomize_biases(P.scale_kernels(P.init_gru_params([H], seed=H, heads=heads), 1.5), H + 1)
+    wf = _lib.NativeWavefunction(_lib.MODEL_CRNN_U1, N, 1, (H,))
+    wf.set_params(prm, scope=SCOPE)
+    couplings = np.concatenate([np.ones(N), 0.5 * np.ones(N), np.zeros(N), [0.0, 0.0]])
+    out = wf.vmc_step(ns, seed=3, step=0, couplings=couplings, want_samples=True, want_eloc=True)
+    s, e = out["samples"], out["eloc"].astype(np.complex128)
+    grads = cost_gradient(wf, prm, SCOPE, e.mean(), ns)
+    prm64 = {k: v.astype(np.float64) for k, v in prm.items()}
+    rng = np.random.RandomState(0)
+    worst = 0.0
+    scale = max(np.abs(g).max() for g in grads.values())
+    for name, g in grads.items():
+        flat = prm64[name].ravel()
+        for idx in rng.choice(flat.size, size=min(flat.size, 10), replace=False):
+            old = flat[idx]
+            eps = 1e-5
+            flat[idx] = old + eps
+            cp = oracle_cost_complex(prm64, s, e)
+            flat[idx] = old - eps
+            cm = oracle_cost_complex(prm64, s, e)
+            flat[idx] = old
+            worst = max(worst, abs((cp - cm) / (2 * eps) - g.ravel()[idx]) / scale)
+    print("cRNN N=%d H=%d: max |grad - FD| / max|grad| = %.2e" % (N, H, worst))
+    assert worst < 2e-3
+
+
+def test_run_j1j2_approaches_the_exact_ground_state_energy():
+    """The reference's own run script (J1J2/run_j1j2.py: N=10, J2=0.2, 10 units, 200 samples, lr 5e-4) reaches
+    -3.9647 after 3000 steps (ED -3.9855798336170905, Tutorial_1DJ1J2.ipynb cells 8, 18)."""
+    from rnnwavefunctions_amd.J1J2.TrainingRNN_J1J2 import run_J1J2
+    meanE, varE = run_J1J2(numsteps=1500, systemsize=10, J1_=1.0, J2_=0.2, Marshall_sign=False, num_units=10,
+                           num_layers=1, numsamples=200, learningrate=5e-3, seed=111, verbose=False)
+    ed = -3.9855798336170905
+    final = np.mean(np.real(meanE[-50:]))
+    print("run_J1J2 N=10: E(first)=%.4f  mean of last 50 steps = %.5f  (ED %.5f)  var = %.4f" %
+          (np.real(meanE[0]), final, ed, np.mean(varE[-50:])))
+    assert np.real(meanE[0]) > -2.0
+    assert final > ed - 0.03                    # variational up to Monte-Carlo noise
+    assert final < -3.85                        # within 3.5 % of the ground state
+    assert abs(np.mean(np.imag(meanE[-50:]))) < 0.05
