@@ -154,7 +154,7 @@ int rnnwf_vmc_step(rnnwf_handle* h, int64_t numsamples, uint64_t seed, uint64_t 
                    const double* couplings, int64_t n_couplings, int32_t* out_samples, void* out_eloc,
                    double* moments);
 
-/* ---- gradient of the VMC cost (1D positive and complex GRU RNNs, f32) ------
+/* ---- gradient of the VMC cost (models GRU1D, CRNN_U1 (f32), GRU1D_F64, MDRNN2D (f64)) ----
  * rnnwf_vmc_gradient <- optimizer.compute_gradients(cost) with
  *   cost = mean(log_probs * Eloc) - mean(Eloc) * mean(log_probs)      (1DTFIM/TrainingRNN_1DTFIM.py:151-162)
  *   evaluated on the batch of the LAST rnnwf_vmc_step (its samples, per-site hidden states and E_loc are still
@@ -163,7 +163,9 @@ int rnnwf_vmc_step(rnnwf_handle* h, int64_t numsamples, uint64_t seed, uint64_t 
  *   rnnwf_allreduce_grads.  Back-propagation through time on the MFMA + a TN GEMM for the weight gradients.
  *   Complex RNN: cost = 2 Re(mean(conj(log_amplitudes) Eloc) - conj(mean(log_amplitudes)) mean(Eloc))
  *   (J1J2/TrainingRNN_J1J2.py:197), i.e. grad = 2/norm sum_s [(Re E_s - mean_energy) d Re log psi +
- *   (Im E_s - mean_energy_im) d Im log psi]; mean_energy_im is ignored for the positive RNN.
+ *   (Im E_s - mean_energy_im) d Im log psi]; mean_energy_im is ignored for the positive RNNs.
+ *   The 2D drivers (2DTFIM_2DRNN/Training2DRNN_2DTFIM.py:163, 2DTFIM_1DRNN/Training1DRNN_2DTFIM.py:160) use the
+ *   first cost in float64.  Limits: num_units <= 68 (f32, MDRNN), <= 52 (GRU1D_F64); else RNNWF_ERR_INVALID.
  * rnnwf_get_grad     <- the gradient of one TF variable (same names and shapes as rnnwf_set_param).
  * rnnwf_allreduce_grads: one RCCL all-reduce (sum) over all gradient arrays of the handle.             */
 int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double mean_energy_im, double norm);

@@ -1,4 +1,4 @@
-// grad.hip - host side of the VMC-cost gradient for the positive GRU RNN (f32, single layer):
+// grad.hip - host side of the VMC-cost gradient for the GRU RNNs (f32 1D positive / complex, f64 2D-lattice GRU):
 // rnnwf_vmc_gradient / rnnwf_get_grad / rnnwf_allreduce_grads.
 #include <algorithm>
 
@@ -10,10 +10,11 @@ using namespace rnnwf;
 
 namespace {
 
-template <int NFULL, int WAVES, int NOUT>
+template <typename T, int NFULL, int WAVES, int NOUT>
 struct GLaunch {
-    using L = GruLayout<float, NFULL, NOUT>;
-    using G = GradLayout<NFULL>;
+    using L = GruLayout<T, NFULL, NOUT>;
+    using G = GradLayout<NFULL, T>;
+    static constexpr size_t LDS = L::BYTES + G::BWD_BYTES;
 
     static std::vector<char> pack_bwd(const rnnwf_handle* h) {
         const int H = h->H;
@@ -21,10 +22,11 @@ struct GLaunch {
         const std::string pre = kGruPre;
         const auto& Wg = pv(h, pre + "gates/kernel");                         // [2+H, 2H]
         const auto& Wch = pv(h, pre + "candidate/hidden_projection/kernel");  // [H, H]
-        float* A = reinterpret_cast<float*>(img.data());
+        T* A = reinterpret_cast<T*>(img.data());
         for (int t = 0; t < G::NTO; ++t)
             for (int row = 0; row < 16; ++row) {
-                const int q = row >> 2, r = row & 3;
+                int q, r;
+                row_to_qr<T>(row, q, r);
                 if (t == NFULL && r != 0) continue;
                 const int kout = t < NFULL ? 16 * t + 4 * r + q : 16 * NFULL + q;   // hidden unit receiving dL/dh
                 if (kout >= H) continue;
@@ -37,17 +39,19 @@ struct GLaunch {
                         if (g == 0) w = Wg[(size_t)(2 + kout) * 2 * H + u];
                         else if (g == 1) w = Wg[(size_t)(2 + kout) * 2 * H + H + u];
                         else w = Wch[(size_t)kout * H + u];
-                        A[(((size_t)t * G::KBG + kk / 4) * 64 + lane) * 4 + (kk & 3)] = (float)w;
+                        A[(((size_t)t * G::KBG + kk / G::VW) * 64 + lane) * G::VW + (kk % G::VW)] = (T)w;
                     }
                 }
             }
         return img;
     }
 
-    static int run(rnnwf_handle* h, GradArgs a, int64_t R, float* dW) {
+    static int run(rnnwf_handle* h, GradArgs a, int64_t R, void* dW) {
         static int bpc = 0;
-        const void* fn = (const void*)gru_bwd_kernel<NFULL, WAVES, NOUT>;
-        const size_t lds = L::BYTES + G::BWD_BYTES;
+        const void* fn = (const void*)gru_bwd_kernel<T, NFULL, WAVES, NOUT>;
+        const size_t lds = LDS;
+        if (lds > 160 * 1024)
+            return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: forward + backward weight images (%zu B) exceed the 160 KB LDS", lds);
         if (!bpc) {
             RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             RNNWF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, WAVES * 64, lds));
@@ -55,18 +59,20 @@ struct GLaunch {
         }
         const int64_t need = (a.nsb + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
-        gru_bwd_kernel<NFULL, WAVES, NOUT><<<grid, WAVES * 64, lds, h->stream>>>(a);
+        gru_bwd_kernel<T, NFULL, WAVES, NOUT><<<grid, WAVES * 64, lds, h->stream>>>(a);
         RNNWF_HIP(h, hipGetLastError());
         int64_t rpb = (R + (int64_t)h->cu_count * 4 - 1) / ((int64_t)h->cu_count * 4);
         rpb = std::max<int64_t>(64, ((rpb + 3) / 4) * 4);
         const unsigned gblocks = (unsigned)((R + rpb - 1) / rpb);
-        tn_gemm_kernel<G::PCOLS / 16, G::QCOLS / 16><<<gblocks, 256, 0, h->stream>>>(a.P, a.Q, R, rpb, dW);
+        tn_gemm_kernel<T, G::PCOLS / 16, G::QCOLS / 16><<<gblocks, 256, 0, h->stream>>>((const T*)a.P, (const T*)a.Q, R, rpb, (T*)dW);
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }
 
     // dW image [PCOLS][QCOLS] + head gradients -> TF-named gradient arrays
-    static void unpack(rnnwf_handle* h, const float* dW, const float* hg) {
+    static void unpack(rnnwf_handle* h, const void* dW_, size_t head_off) {
+        const T* dW = (const T*)dW_;
+        const T* hg = dW + head_off;
         const int H = h->H;
         const int NT = G::NT;
         auto col_of_unit = [&](int k) { return k < 16 * NFULL ? 16 * (k / 16) + 4 * (k % 4) + (k % 16) / 4 : 16 * NFULL + 4 * (k - 16 * NFULL); };
@@ -138,17 +144,23 @@ struct GLaunch {
     do {                                                                \
         if ((h)->model == RNNWF_MODEL_CRNN_U1) {                        \
             switch ((h)->NFULL) {                                       \
-                case 1: { using K = GLaunch<1, 4, 3>; EXPR; }           \
-                case 2: { using K = GLaunch<2, 4, 3>; EXPR; }           \
-                case 3: { using K = GLaunch<3, 4, 3>; EXPR; }           \
-                case 4: { using K = GLaunch<4, 4, 3>; EXPR; }           \
+                case 1: { using K = GLaunch<float, 1, 4, 3>; EXPR; }    \
+                case 2: { using K = GLaunch<float, 2, 4, 3>; EXPR; }    \
+                case 3: { using K = GLaunch<float, 3, 4, 3>; EXPR; }    \
+                case 4: { using K = GLaunch<float, 4, 4, 3>; EXPR; }    \
+            }                                                           \
+        } else if ((h)->model == RNNWF_MODEL_GRU1D_F64) {               \
+            switch ((h)->NFULL) {                                       \
+                case 1: { using K = GLaunch<double, 1, 4, 1>; EXPR; }   \
+                case 2: { using K = GLaunch<double, 2, 4, 1>; EXPR; }   \
+                case 3: { using K = GLaunch<double, 3, 4, 1>; EXPR; }   \
             }                                                           \
         } else {                                                        \
             switch ((h)->NFULL) {                                       \
-                case 1: { using K = GLaunch<1, 4, 1>; EXPR; }           \
-                case 2: { using K = GLaunch<2, 4, 1>; EXPR; }           \
-                case 3: { using K = GLaunch<3, 4, 1>; EXPR; }           \
-                case 4: { using K = GLaunch<4, 4, 1>; EXPR; }           \
+                case 1: { using K = GLaunch<float, 1, 4, 1>; EXPR; }    \
+                case 2: { using K = GLaunch<float, 2, 4, 1>; EXPR; }    \
+                case 3: { using K = GLaunch<float, 3, 4, 1>; EXPR; }    \
+                case 4: { using K = GLaunch<float, 4, 4, 1>; EXPR; }    \
             }                                                           \
         }                                                               \
     } while (0)
@@ -158,10 +170,14 @@ struct GLaunch {
 extern "C" int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double mean_energy_im, double norm) {
     if (!h) return RNNWF_ERR_INVALID;
     if (!h->committed) return h->fail(RNNWF_ERR_STATE, "parameters not committed");
-    if (h->model != RNNWF_MODEL_GRU1D && h->model != RNNWF_MODEL_CRNN_U1)
-        return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: implemented for the 1D positive and complex GRU RNNs (f32) so far");
+    if (h->model == RNNWF_MODEL_MDRNN2D) return mdrnn_vmc_gradient(h, mean_energy, norm);
+    if (h->model != RNNWF_MODEL_GRU1D && h->model != RNNWF_MODEL_CRNN_U1 && h->model != RNNWF_MODEL_GRU1D_F64)
+        return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: not implemented for the parity-symmetrised GRU RNN");
     const bool cplx = h->model == RNNWF_MODEL_CRNN_U1;
-    if (h->NFULL > 4) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: num_units > 68 not implemented yet");
+    const bool f64 = h->model == RNNWF_MODEL_GRU1D_F64;
+    const size_t es = f64 ? 8 : 4;
+    if (h->NFULL > (f64 ? 3 : 4))
+        return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: num_units > %d not implemented (LDS budget of the backward image)", f64 ? 52 : 68);
     if (h->last_ns <= 0 || !h->last_has_ckpt)
         return h->fail(RNNWF_ERR_STATE, "rnnwf_vmc_gradient: call rnnwf_vmc_step first (its samples, states and E_loc are reused)");
     if (!(norm > 0)) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: norm must be positive");
@@ -177,11 +193,11 @@ extern "C" int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double me
         RNNWF_HIP(h, hipMemcpyAsync(h->wbwd.p, img.data(), img.size(), hipMemcpyHostToDevice, h->stream));
         RNNWF_HIP(h, hipStreamSynchronize(h->stream));
     }
-    if (int rc = ensure(h, h->gradP, (size_t)R * pcols * 4)) return rc;
-    if (int rc = ensure(h, h->gradQ, (size_t)R * qcols * 4)) return rc;
+    if (int rc = ensure(h, h->gradP, (size_t)R * pcols * es)) return rc;
+    if (int rc = ensure(h, h->gradQ, (size_t)R * qcols * es)) return rc;
     const size_t dw_floats = (size_t)pcols * qcols + hgn;
-    if (int rc = ensure(h, h->gradW, dw_floats * 4)) return rc;
-    RNNWF_HIP(h, hipMemsetAsync(h->gradW.p, 0, dw_floats * 4, h->stream));
+    if (int rc = ensure(h, h->gradW, dw_floats * es)) return rc;
+    RNNWF_HIP(h, hipMemsetAsync(h->gradW.p, 0, dw_floats * es, h->stream));
     GradArgs a{};
     a.wimg = h->wimg.p;
     a.wbwd = h->wbwd.p;
@@ -189,20 +205,20 @@ extern "C" int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double me
     a.ns = ns;
     a.nsb = (ns + kChains - 1) / kChains;
     a.bits = (const uint32_t*)h->bits.p;
-    a.hck = (const float*)h->hck.p;
+    a.hck = h->hck.p;
     a.eloc = (const double*)h->eloc.p;
     a.eloc_c = (const float2*)h->eloc.p;
     a.mean_e = mean_energy;
     a.mean_im = mean_energy_im;
     a.inv_norm = (cplx ? 2.0 : 1.0) / norm;      // the complex cost carries a factor 2 (TrainingRNN_J1J2.py:197)
-    a.P = (float*)h->gradP.p;
-    a.Q = (float*)h->gradQ.p;
-    a.head_grad = (float*)h->gradW.p + (size_t)pcols * qcols;
-    GRAD_DISPATCH(h, { if (int rc = K::run(h, a, R, (float*)h->gradW.p)) return rc; break; });
-    std::vector<float> host(dw_floats);
-    RNNWF_HIP(h, hipMemcpyAsync(host.data(), h->gradW.p, dw_floats * 4, hipMemcpyDeviceToHost, h->stream));
+    a.P = h->gradP.p;
+    a.Q = h->gradQ.p;
+    a.head_grad = (char*)h->gradW.p + (size_t)pcols * qcols * es;
+    GRAD_DISPATCH(h, { if (int rc = K::run(h, a, R, h->gradW.p)) return rc; break; });
+    std::vector<char> host(dw_floats * es);
+    RNNWF_HIP(h, hipMemcpyAsync(host.data(), h->gradW.p, dw_floats * es, hipMemcpyDeviceToHost, h->stream));
     RNNWF_HIP(h, hipStreamSynchronize(h->stream));
-    GRAD_DISPATCH(h, { K::unpack(h, host.data(), host.data() + (size_t)pcols * qcols); break; });
+    GRAD_DISPATCH(h, { K::unpack(h, host.data(), (size_t)pcols * qcols); break; });
     return RNNWF_OK;
 }
 

@@ -17,7 +17,7 @@
 
 namespace rnnwf {
 
-template <int NFULL>
+template <int NFULL, typename T = float>
 struct GradLayout {
     static constexpr int KT = 4 * NFULL + 1;
     static constexpr int NT = 3 * NFULL + 1;
@@ -25,8 +25,9 @@ struct GradLayout {
     static constexpr int PCOLS = 16 * (NT + NTO);         // [gate rows in image order | dy in unit-fragment order]
     static constexpr int QCOLS = 16 * NTO;                // [h_in in unit-fragment order ; x0, x1, 1 in the spare slots]
     static constexpr int KB = 3 * KT;                     // k-steps of the backward product (gate g, kt)
-    static constexpr int KBG = (KB + 3) / 4;              // groups of 4 k-steps (b128 LDS reads)
-    static constexpr size_t BWD_BYTES = (size_t)NTO * KBG * 64 * 16;   // [NTO][KBG][64] float4
+    static constexpr int VW = 16 / (int)sizeof(T);        // k-steps per 16-byte LDS vector
+    static constexpr int KBG = (KB + VW - 1) / VW;        // groups of VW k-steps (b128 LDS reads)
+    static constexpr size_t BWD_BYTES = (size_t)NTO * KBG * 64 * 16;   // [NTO][KBG][64] x 16 B
     static constexpr int HEAD_ROW = 4 * KT + 4;           // per head row: gradient per unit slot (4 KT) + bias (+ pad)
 };
 
@@ -36,23 +37,25 @@ struct GradArgs {
     int32_t N;
     int64_t ns, nsb;
     const uint32_t* bits;
-    const float* hck;          // [N-1][nsb][KT][64] state after each site
+    const void* hck;           // [N-1][nsb][KT][64] T, state after each site
     const double* eloc;        // [ns] f64 (positive RNN) ...
     const float2* eloc_c;      // ... or [ns] complex64 (complex RNN)
     double mean_e, mean_im, inv_norm;   // w_s = (E_s - mean) * inv_norm  (real and imaginary part separately)
-    float* P;                  // [N*ns][PCOLS]
-    float* Q;                  // [N*ns][QCOLS]
-    float* head_grad;          // [NOUT][HEAD_ROW], zeroed before the launch
+    void* P;                   // [N*ns][PCOLS] T
+    void* Q;                   // [N*ns][QCOLS] T
+    void* head_grad;           // [NOUT][HEAD_ROW] T, zeroed before the launch
 };
 
 // NOUT = 1: positive RNN, L = sum_s w_s log P(s).
 // NOUT = 3: complex RNN, L = sum_s [w_re Re log psi(s) + w_im Im log psi(s)]  (J1J2/TrainingRNN_J1J2.py:197:
 //           cost = 2 Re(mean(conj(log psi) E) - conj(mean log psi) mean E); the factor 2 is in inv_norm).
-template <int NFULL, int WAVES, int NOUT>
+template <typename T, int NFULL, int WAVES, int NOUT>
 __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
-    using C = GruCore<float, NFULL, NOUT>;
-    using G = GradLayout<NFULL>;
+    using C = GruCore<T, NFULL, NOUT>;
+    using G = GradLayout<NFULL, T>;
     using V4 = typename C::V4;
+    using VA = typename C::VA;
+    constexpr int VW = G::VW;
     constexpr int KT = C::KT, NT = C::NT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     C::stage(lds, a.wimg);
@@ -68,55 +71,55 @@ __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
     const int64_t gw = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * WAVES;
     const int N = a.N;
-    const float* wd = reinterpret_cast<const float*>(lds + C::L::OFF_WD) + q * C::L::WD_Q;
+    const T* wd = reinterpret_cast<const T*>(lds + C::L::OFF_WD) + q * C::L::WD_Q;
     for (int64_t sb = gw; sb < a.nsb; sb += nw) {
         const int64_t s = sb * kChains + c;
         const bool valid = s < a.ns;
         const int64_t sc = valid ? s : a.ns - 1;
-        float w = 0.0f, w_im = 0.0f;
+        T w = T(0), w_im = T(0);
         if (valid) {
             if constexpr (NOUT == 1) {
-                w = (float)((a.eloc[sc] - a.mean_e) * a.inv_norm);
+                w = (T)((a.eloc[sc] - a.mean_e) * a.inv_norm);
             } else {
                 const float2 e = a.eloc_c[sc];
-                w = (float)(((double)e.x - a.mean_e) * a.inv_norm);
-                w_im = (float)(((double)e.y - a.mean_im) * a.inv_norm);
+                w = (T)(((double)e.x - a.mean_e) * a.inv_norm);
+                w_im = (T)(((double)e.y - a.mean_im) * a.inv_norm);
             }
         }
         auto spin = [&](int n) { return (int)((a.bits[(int64_t)(n >> 5) * a.ns + sc] >> (n & 31)) & 1); };
-        float dh[KT], hg[NOUT][KT];
-        float gb[NOUT];
+        T dh[KT], hg[NOUT][KT];
+        T gb[NOUT];
 #pragma unroll
-        for (int k = 0; k < KT; ++k) dh[k] = 0.0f;
+        for (int k = 0; k < KT; ++k) dh[k] = T(0);
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) {
-            gb[o] = 0.0f;
+            gb[o] = T(0);
 #pragma unroll
-            for (int k = 0; k < KT; ++k) hg[o][k] = 0.0f;
+            for (int k = 0; k < KT; ++k) hg[o][k] = T(0);
         }
         int num_up = 0;                                   // complex RNN: up spins among sites < n (for the U(1) mask)
         if constexpr (NOUT == 3)
             for (int m = 0; m < N; ++m) num_up += spin(m);
         for (int n = N - 1; n >= 0; --n) {
-            float h[KT], hn[KT], rg[KT], ug[KT], cc[KT], qv[KT];
+            T h[KT], hn[KT], rg[KT], ug[KT], cc[KT], qv[KT];
             if (n > 0) {
-                const float* src = a.hck + (((int64_t)(n - 1) * a.nsb + sb) * KT) * 64 + lane;
+                const T* src = reinterpret_cast<const T*>(a.hck) + (((int64_t)(n - 1) * a.nsb + sb) * KT) * 64 + lane;
 #pragma unroll
                 for (int k = 0; k < KT; ++k) h[k] = src[k * 64];
             } else {
 #pragma unroll
-                for (int k = 0; k < KT; ++k) h[k] = 0.0f;
+                for (int k = 0; k < KT; ++k) h[k] = T(0);
             }
             const int sig_in = n > 0 ? spin(n - 1) : -1;
             const int sig = spin(n);
             C::step_keep(lds, sig_in, h, hn, rg, ug, cc, qv, lane);
-            float z[NOUT];
+            T z[NOUT];
             C::head(lds, hn, lane, z);
             // gradient of this site's term w.r.t. the head rows
-            float g[NOUT];
-            const float p1 = 1.0f - prob0(z[0]);
+            T g[NOUT];
+            const T p1 = T(1) - prob0(z[0]);
             if constexpr (NOUT == 1) {
-                g[0] = w * ((float)sig - p1);                           // d log p(sig) / d(z1 - z0) = sig - p1
+                g[0] = w * ((T)sig - p1);                           // d log p(sig) / d(z1 - z0) = sig - p1
             } else {
                 num_up -= sig;                                          // ups among sites < n
                 bool both = true;                                       // mask: a value that is forced has amplitude 1
@@ -124,37 +127,37 @@ __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
                     const int base = N / 2 - 1;
                     both = (base - (n - num_up) >= 0) && (base - num_up >= 0);
                 }
-                g[0] = both ? 0.5f * w * ((float)sig - p1) : 0.0f;      // d log a(sig) = 1/2 d log p(sig)
-                const float zs = sig ? z[2] : z[1];
-                const float den = 1.0f + fabsf(zs);
-                const float gp = w_im * 3.14159265358979323846f / (den * den);   // d (pi softsign(z)) / dz
-                g[1] = sig ? 0.0f : gp;
-                g[2] = sig ? gp : 0.0f;
+                g[0] = both ? T(0.5) * w * ((T)sig - p1) : T(0);      // d log a(sig) = 1/2 d log p(sig)
+                const T zs = sig ? z[2] : z[1];
+                const T den = T(1) + (zs < T(0) ? -zs : zs);
+                const T gp = w_im * T(3.14159265358979323846) / (den * den);   // d (pi softsign(z)) / dz
+                g[1] = sig ? T(0) : gp;
+                g[2] = sig ? gp : T(0);
             }
-            float dp[4 * G::KBG];
-            float dy[KT];
+            T dp[VW * G::KBG];
+            T dy[KT];
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) gb[o] += g[o];
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
-                float d = dh[k];                                        // total dL/dh_n of this lane's unit
+                T d = dh[k];                                        // total dL/dh_n of this lane's unit
 #pragma unroll
                 for (int o = 0; o < NOUT; ++o) {
-                    hg[o][k] = fmaf(g[o], hn[k], hg[o][k]);
-                    d = fmaf(g[o], wd[k * NOUT + o], d);
+                    hg[o][k] += g[o] * hn[k];
+                    d += g[o] * wd[k * NOUT + o];
                 }
-                const float du = d * (h[k] - cc[k]);
-                const float dc = d * (1.0f - ug[k]);
+                const T du = d * (h[k] - cc[k]);
+                const T dc = d * (T(1) - ug[k]);
                 dh[k] = d * ug[k];                                      // direct path to h_{n-1}
-                dy[k] = dc * (1.0f - cc[k] * cc[k]);
+                dy[k] = dc * (T(1) - cc[k] * cc[k]);
                 dp[2 * KT + k] = dy[k] * rg[k];                         // d q
-                dp[k] = dy[k] * qv[k] * rg[k] * (1.0f - rg[k]);         // d a_r
-                dp[KT + k] = du * ug[k] * (1.0f - ug[k]);               // d a_u
+                dp[k] = dy[k] * qv[k] * rg[k] * (T(1) - rg[k]);         // d a_r
+                dp[KT + k] = du * ug[k] * (T(1) - ug[k]);               // d a_u
             }
 #pragma unroll
-            for (int k = G::KB; k < 4 * G::KBG; ++k) dp[k] = 0.0f;
+            for (int k = G::KB; k < VW * G::KBG; ++k) dp[k] = T(0);
             if (valid) {
-                float* prow = a.P + ((int64_t)n * a.ns + s) * G::PCOLS + 4 * q;
+                T* prow = reinterpret_cast<T*>(a.P) + ((int64_t)n * a.ns + s) * G::PCOLS + 4 * q;
 #pragma unroll
                 for (int m = 0; m < NFULL; ++m) {
 #pragma unroll
@@ -165,36 +168,36 @@ __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
                     V4 vy = {dy[4 * m], dy[4 * m + 1], dy[4 * m + 2], dy[4 * m + 3]};
                     *reinterpret_cast<V4*>(prow + (NT + m) * 16) = vy;
                 }
-                V4 vm = {dp[KT - 1], dp[2 * KT - 1], dp[3 * KT - 1], 0.0f};    // mixed tile: row 4q + gate
+                V4 vm = {dp[KT - 1], dp[2 * KT - 1], dp[3 * KT - 1], T(0)};    // mixed tile: row 4q + gate
                 *reinterpret_cast<V4*>(prow + (NT - 1) * 16) = vm;
-                V4 vym = {dy[KT - 1], 0.0f, 0.0f, 0.0f};
+                V4 vym = {dy[KT - 1], T(0), T(0), T(0)};
                 *reinterpret_cast<V4*>(prow + (NT + NFULL) * 16) = vym;
-                float* qrow = a.Q + ((int64_t)n * a.ns + s) * G::QCOLS + 4 * q;
+                T* qrow = reinterpret_cast<T*>(a.Q) + ((int64_t)n * a.ns + s) * G::QCOLS + 4 * q;
 #pragma unroll
                 for (int m = 0; m < NFULL; ++m) {
                     V4 v = {h[4 * m], h[4 * m + 1], h[4 * m + 2], h[4 * m + 3]};
                     *reinterpret_cast<V4*>(qrow + m * 16) = v;
                 }
-                const float first = q == 0 ? 1.0f : 0.0f;
-                V4 vq = {h[KT - 1], first * (sig_in == 0 ? 1.0f : 0.0f), first * (sig_in == 1 ? 1.0f : 0.0f), first};
+                const T first = q == 0 ? T(1) : T(0);
+                V4 vq = {h[KT - 1], first * (sig_in == 0 ? T(1) : T(0)), first * (sig_in == 1 ? T(1) : T(0)), first};
                 *reinterpret_cast<V4*>(qrow + NFULL * 16) = vq;
             }
             // dL/dh_{n-1} += W_r d a_r + W_u d a_u + Wch d q   (A = transposed weights, B = dp fragments)
             V4 accb[G::NTO];
 #pragma unroll
-            for (int t = 0; t < G::NTO; ++t) accb[t] = V4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < G::NTO; ++t) accb[t] = V4{T(0), T(0), T(0), T(0)};
             asm volatile("" ::: "memory");
-            const V4* ab = reinterpret_cast<const V4*>(lbwd) + lane;
+            const VA* ab = reinterpret_cast<const VA*>(lbwd) + lane;
 #pragma unroll
             for (int kg = 0; kg < G::KBG; ++kg) {
-                V4 af[G::NTO];
+                VA af[G::NTO];
 #pragma unroll
                 for (int t = 0; t < G::NTO; ++t) af[t] = ab[(t * G::KBG + kg) * 64];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < VW; ++j)
 #pragma unroll
                     for (int t = 0; t < G::NTO; ++t)
-                        accb[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][j], dp[4 * kg + j], accb[t], 0, 0, 0);
+                        accb[t] = Frag<T>::mfma(af[t][j], dp[VW * kg + j], accb[t]);
             }
 #pragma unroll
             for (int m = 0; m < NFULL; ++m)
@@ -207,23 +210,23 @@ __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
         for (int o = 0; o < NOUT; ++o) {
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
-                float v = hg[o][k];
+                T v = hg[o][k];
                 v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-                if (c == 0) atomicAdd(&a.head_grad[o * G::HEAD_ROW + 4 * k + q], v);
+                if (c == 0) atomicAdd(&reinterpret_cast<T*>(a.head_grad)[o * G::HEAD_ROW + 4 * k + q], v);
             }
-            float v = gb[o];
+            T v = gb[o];
             v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-            if (c == 0 && q == 0) atomicAdd(&a.head_grad[o * G::HEAD_ROW + 4 * KT], v);
+            if (c == 0 && q == 0) atomicAdd(&reinterpret_cast<T*>(a.head_grad)[o * G::HEAD_ROW + 4 * KT], v);
         }
     }
 }
 
 // dW[PCOLS][QCOLS] += sum over rows of P[row][:]^T Q[row][:]; one block = 4 waves = one contiguous chunk of rows.
 // Wave w owns the 16-row output tiles mt = w, w+4, ... and all QCOLS/16 column tiles.
-template <int PT, int QT>
-__global__ void __launch_bounds__(256) tn_gemm_kernel(const float* __restrict__ P, const float* __restrict__ Q, int64_t R,
-                                                      int64_t rows_per_block, float* __restrict__ dW) {
-    typedef float V4 __attribute__((ext_vector_type(4)));
+template <typename T, int PT, int QT>
+__global__ void __launch_bounds__(256) tn_gemm_kernel(const T* __restrict__ P, const T* __restrict__ Q, int64_t R,
+                                                      int64_t rows_per_block, T* __restrict__ dW) {
+    using V4 = typename Frag<T>::V4;
     constexpr int MW = (PT + 3) / 4;                       // output row tiles per wave
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int li = lane & 15, lk = lane >> 4;
@@ -233,22 +236,22 @@ __global__ void __launch_bounds__(256) tn_gemm_kernel(const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < MW; ++i)
 #pragma unroll
-        for (int j = 0; j < QT; ++j) acc[i][j] = V4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < QT; ++j) acc[i][j] = V4{T(0), T(0), T(0), T(0)};
     for (int64_t r = r0; r < r1; r += 4) {
         const int64_t row = r + lk;
         const bool ok = row < r1;
-        float af[MW], bf[QT];
+        T af[MW], bf[QT];
 #pragma unroll
         for (int i = 0; i < MW; ++i) {
             const int mt = wave + 4 * i;
-            af[i] = (ok && mt < PT) ? P[row * (PT * 16) + mt * 16 + li] : 0.0f;
+            af[i] = (ok && mt < PT) ? P[row * (PT * 16) + mt * 16 + li] : T(0);
         }
 #pragma unroll
-        for (int j = 0; j < QT; ++j) bf[j] = ok ? Q[row * (QT * 16) + j * 16 + li] : 0.0f;
+        for (int j = 0; j < QT; ++j) bf[j] = ok ? Q[row * (QT * 16) + j * 16 + li] : T(0);
 #pragma unroll
         for (int i = 0; i < MW; ++i)
 #pragma unroll
-            for (int j = 0; j < QT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < QT; ++j) acc[i][j] = Frag<T>::mfma(af[i], bf[j], acc[i][j]);
     }
 #pragma unroll
     for (int i = 0; i < MW; ++i) {
@@ -257,8 +260,11 @@ __global__ void __launch_bounds__(256) tn_gemm_kernel(const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < QT; ++j)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
-                atomicAdd(&dW[(size_t)(mt * 16 + 4 * lk + rr) * (QT * 16) + j * 16 + li], acc[i][j][rr]);
+            for (int rr = 0; rr < 4; ++rr) {
+                // C/D fragment row of (lane quarter lk, register rr): f32 4 lk + rr, f64 lk + 4 rr
+                const int row = sizeof(T) == 4 ? 4 * lk + rr : lk + 4 * rr;
+                atomicAdd(&dW[(size_t)(mt * 16 + row) * (QT * 16) + j * 16 + li], acc[i][j][rr]);
+            }
     }
 }
 

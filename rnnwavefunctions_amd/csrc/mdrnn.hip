@@ -2,6 +2,8 @@
 // sample / log_probability / fused 2D-TFIM local energies / fused VMC step.
 #include <algorithm>
 
+#include "grad_kernels.h"
+#include "mdrnn_grad_kernels.h"
 #include "mdrnn_kernels.h"
 #include "models.h"
 #include "pack.h"
@@ -220,6 +222,7 @@ int rnnwf::mdrnn_pack_image(rnnwf_handle* h, std::vector<char>& img) {
 
 int rnnwf::mdrnn_log_prob(rnnwf_handle* h, const int32_t* samples, int64_t B, double* out) {
     const int N = h->N;
+    h->last_ns = 0;
     Maps m;
     if (int rc = get_maps(h, &m)) return rc;
     const int64_t chunk = max_chains_per_pass(h);
@@ -243,6 +246,7 @@ int rnnwf::mdrnn_log_prob(rnnwf_handle* h, const int32_t* samples, int64_t B, do
 int rnnwf::mdrnn_sample(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t step, int64_t offset, int32_t* out,
                         double* out_log) {
     const int N = h->N;
+    h->last_ns = 0;
     const int W = (N + 31) / 32;
     Maps m;
     if (int rc = get_maps(h, &m)) return rc;
@@ -267,6 +271,7 @@ int rnnwf::mdrnn_sample(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t ste
 int rnnwf::mdrnn_tfim_eloc(rnnwf_handle* h, const int32_t* samples, int64_t ns, const double* Jz, double Bx,
                            double* eloc, double* log_probs) {
     const int N = h->N;
+    h->last_ns = 0;
     Maps m;
     if (int rc = get_maps(h, &m)) return rc;
     if (int rc = ensure(h, h->coupl, (size_t)N * 8)) return rc;
@@ -300,5 +305,168 @@ int rnnwf::mdrnn_vmc_step(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t s
     if (int rc = eloc_on_device(h, ns, m, true, seed, step, offset, (const double*)h->coupl.p, couplings[N])) return rc;
     if (out_samples) if (int rc = unpack_and_download(h, h->bits, ns, out_samples, m.pos_of_site)) return rc;
     if (out_eloc) RNNWF_HIP(h, hipMemcpyAsync(out_eloc, h->eloc.p, (size_t)ns * 8, hipMemcpyDeviceToHost, h->stream));
+    h->last_ns = ns;              // bits, hs and eloc stay resident for rnnwf_vmc_gradient
+    h->last_has_ckpt = true;
     return run_moments(h, h->eloc.p, ns, false, moments);
+}
+
+// ---- gradient of the VMC cost (2DTFIM_2DRNN/Training2DRNN_2DTFIM.py:163-170) ----
+namespace {
+
+template <int NFULL, int WAVES>
+struct MGrad {
+    using G = MdGradLayout<NFULL>;
+
+    static std::vector<char> pack(const rnnwf_handle* h) {
+        const int H = h->H;
+        std::vector<char> img(G::BYTES, 0);
+        const auto& Wh = pv(h, "Wh_rnn_0");
+        const auto& Wv = pv(h, "Wv_rnn_0");
+        const auto& Wd = pv(h, "wf_dense/kernel");
+        const auto& bd = pv(h, "wf_dense/bias");
+        double* A = reinterpret_cast<double*>(img.data() + G::OFF_A);
+        for (int t = 0; t < G::NTO; ++t) {
+            const int tt = t % G::NT;
+            const auto& Wsrc = t < G::NT ? Wh : Wv;
+            for (int row = 0; row < 16; ++row) {
+                const int kout = 16 * tt + row;                    // unit receiving dL/dh (C/D row = natural order)
+                if (kout >= H || (tt == NFULL && row >= 4)) continue;
+                for (int kq = 0; kq < 4; ++kq) {
+                    const int lane = (kq << 4) | row;
+                    for (int kk = 0; kk < G::KT; ++kk) {
+                        const int u = 4 * kk + kq;
+                        if (u >= H) continue;
+                        A[(((size_t)t * G::KBG + kk / 2) * 64 + lane) * 2 + (kk & 1)] = Wsrc[(size_t)kout * H + u];
+                    }
+                }
+            }
+        }
+        double* WD = reinterpret_cast<double*>(img.data() + G::OFF_WD);
+        double* BD = reinterpret_cast<double*>(img.data() + G::OFF_BD);
+        for (int kt = 0; kt < G::KT; ++kt)
+            for (int q = 0; q < 4; ++q) {
+                const int unit = 4 * kt + q;
+                if (unit >= H) continue;
+                WD[(kt * 4 + q) * 2] = Wd[(size_t)unit * 2];
+                WD[(kt * 4 + q) * 2 + 1] = Wd[(size_t)unit * 2 + 1];
+            }
+        BD[0] = bd[0];
+        BD[1] = bd[1];
+        return img;
+    }
+
+    static int run(rnnwf_handle* h, MdGradArgs a, int64_t R, double* dW) {
+        static int bpc = 0;
+        const void* fn = (const void*)mdrnn_bwd_kernel<NFULL, WAVES>;
+        if (!bpc) {
+            RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::BYTES));
+            RNNWF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, WAVES * 64, G::BYTES));
+            bpc = std::max(bpc, 1);
+        }
+        const int64_t need = (a.nsb + WAVES - 1) / WAVES;
+        const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
+        if (int rc = ensure(h, h->rowbuf, (size_t)grid * WAVES * 2 * a.Nx * G::KT * 64 * 8)) return rc;
+        a.ring = (double*)h->rowbuf.p;
+        mdrnn_bwd_kernel<NFULL, WAVES><<<grid, WAVES * 64, G::BYTES, h->stream>>>(a);
+        RNNWF_HIP(h, hipGetLastError());
+        int64_t rpb = (R + (int64_t)h->cu_count * 4 - 1) / ((int64_t)h->cu_count * 4);
+        rpb = std::max<int64_t>(64, ((rpb + 3) / 4) * 4);
+        const unsigned gblocks = (unsigned)((R + rpb - 1) / rpb);
+        tn_gemm_kernel<double, G::PCOLS / 16, G::QCOLS / 16><<<gblocks, 256, 0, h->stream>>>(a.P, a.Q, R, rpb, dW);
+        RNNWF_HIP(h, hipGetLastError());
+        return 0;
+    }
+
+    static void unpack(rnnwf_handle* h, const double* dW, const double* hg) {
+        const int H = h->H;
+        auto col_of_unit = [&](int k) { return k < 16 * NFULL ? 16 * (k / 16) + 4 * (k % 4) + (k % 16) / 4 : 16 * NFULL + 4 * (k - 16 * NFULL); };
+        const int xcol = 16 * NFULL + 1, onecol = 16 * NFULL + 3, voff = 16 * G::NT;
+        auto at = [&](int prow, int col) { return dW[(size_t)prow * G::QCOLS + col]; };
+        auto& gWh = h->grads["Wh_rnn_0"];
+        auto& gUh = h->grads["Uh_rnn_0"];
+        auto& gWv = h->grads["Wv_rnn_0"];
+        auto& gUv = h->grads["Uv_rnn_0"];
+        auto& gb = h->grads["b_rnn_0"];
+        auto& gWd = h->grads["wf_dense/kernel"];
+        auto& gbd = h->grads["wf_dense/bias"];
+        gWh.assign((size_t)H * H, 0.0); gWv.assign((size_t)H * H, 0.0);
+        gUh.assign((size_t)2 * H, 0.0); gUv.assign((size_t)2 * H, 0.0);
+        gb.assign(H, 0.0); gWd.assign((size_t)H * 2, 0.0); gbd.assign(2, 0.0);
+        for (int u = 0; u < H; ++u) {
+            const int prow = col_of_unit(u);            // P uses the same tile / quarter / register order as Q
+            for (int k = 0; k < H; ++k) {
+                gWh[(size_t)k * H + u] = at(prow, col_of_unit(k));
+                gWv[(size_t)k * H + u] = at(prow, voff + col_of_unit(k));
+            }
+            for (int sg = 0; sg < 2; ++sg) {
+                gUh[(size_t)sg * H + u] = at(prow, xcol + sg);
+                gUv[(size_t)sg * H + u] = at(prow, voff + xcol + sg);
+            }
+            gb[u] = at(prow, onecol);
+            gWd[(size_t)u * 2] = hg[u];
+            gWd[(size_t)u * 2 + 1] = hg[G::HEAD_ROW + u];
+        }
+        gbd[0] = hg[4 * G::KT];
+        gbd[1] = hg[G::HEAD_ROW + 4 * G::KT];
+    }
+};
+
+#define MG_DISPATCH(h, EXPR)                                    \
+    do {                                                        \
+        switch ((h)->NFULL) {                                   \
+            case 1: { using K = MGrad<1, 4>; EXPR; }            \
+            case 2: { using K = MGrad<2, 4>; EXPR; }            \
+            case 3: { using K = MGrad<3, 4>; EXPR; }            \
+            case 4: { using K = MGrad<4, 4>; EXPR; }            \
+        }                                                       \
+    } while (0)
+
+}  // namespace
+
+int rnnwf::mdrnn_vmc_gradient(rnnwf_handle* h, double mean_energy, double norm) {
+    if (h->NFULL > 4) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: num_units > 68 not implemented");
+    if (h->last_ns <= 0 || !h->last_has_ckpt)
+        return h->fail(RNNWF_ERR_STATE, "rnnwf_vmc_gradient: call rnnwf_vmc_step first (its samples, states and E_loc are reused)");
+    if (!(norm > 0)) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: norm must be positive");
+    RNNWF_HIP(h, hipSetDevice(h->cfg.device));
+    Maps m;
+    if (int rc = get_maps(h, &m)) return rc;
+    const int N = h->N;
+    const int64_t ns = h->last_ns, R = ns * N;
+    int pcols = 0, qcols = 0, hgn = 0;
+    MG_DISPATCH(h, { pcols = K::G::PCOLS; qcols = K::G::QCOLS; hgn = 2 * K::G::HEAD_ROW; break; });
+    if (!h->wbwd.p) {
+        std::vector<char> img;
+        MG_DISPATCH(h, { img = K::pack(h); break; });
+        if (int rc = ensure(h, h->wbwd, img.size())) return rc;
+        RNNWF_HIP(h, hipMemcpyAsync(h->wbwd.p, img.data(), img.size(), hipMemcpyHostToDevice, h->stream));
+        RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    if (int rc = ensure(h, h->gradP, (size_t)R * pcols * 8)) return rc;
+    if (int rc = ensure(h, h->gradQ, (size_t)R * qcols * 8)) return rc;
+    const size_t dwn = (size_t)pcols * qcols + hgn;
+    if (int rc = ensure(h, h->gradW, dwn * 8)) return rc;
+    RNNWF_HIP(h, hipMemsetAsync(h->gradW.p, 0, dwn * 8, h->stream));
+    MdGradArgs a{};
+    a.wbwd = h->wbwd.p;
+    a.N = N;
+    a.Nx = h->Nx;
+    a.ns = ns;
+    a.nsb = (ns + kChains - 1) / kChains;
+    a.bits = (const uint32_t*)h->bits.p;
+    a.hs = (const double*)h->hck.p;
+    a.eloc = (const double*)h->eloc.p;
+    a.mean_e = mean_energy;
+    a.inv_norm = 1.0 / norm;
+    a.P = (double*)h->gradP.p;
+    a.Q = (double*)h->gradQ.p;
+    a.head_grad = (double*)h->gradW.p + (size_t)pcols * qcols;
+    a.vert_pos = m.vert_pos;
+    a.row_first = m.row_first;
+    MG_DISPATCH(h, { if (int rc = K::run(h, a, R, (double*)h->gradW.p)) return rc; break; });
+    std::vector<double> host(dwn);
+    RNNWF_HIP(h, hipMemcpyAsync(host.data(), h->gradW.p, dwn * 8, hipMemcpyDeviceToHost, h->stream));
+    RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+    MG_DISPATCH(h, { K::unpack(h, host.data(), host.data() + (size_t)pcols * qcols); break; });
+    return RNNWF_OK;
 }

@@ -50,6 +50,7 @@ int mdrnn_vmc_step(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t step, in
                    int32_t* out_samples, double* out_eloc, double* moments);
 
 // ---- gradient (grad.hip) ---------------------------------------------------------------------------
+int mdrnn_vmc_gradient(rnnwf_handle* h, double mean_energy, double norm);
 void grad_invalidate(rnnwf_handle* h);
 
 }  // namespace rnnwf

@@ -1,7 +1,9 @@
 """VMC training drivers with the reference's call signatures.
 
-    run_1DTFIM  <- 1DTFIM/TrainingRNN_1DTFIM.py:79-229
-    run_J1J2    <- J1J2/TrainingRNN_J1J2.py:131-308
+    run_1DTFIM        <- 1DTFIM/TrainingRNN_1DTFIM.py:79-229
+    run_J1J2          <- J1J2/TrainingRNN_J1J2.py:131-308
+    run_2DTFIM_2DRNN  <- 2DTFIM_2DRNN/Training2DRNN_2DTFIM.py:88-231   (exported there as run_2DTFIM)
+    run_2DTFIM_1DRNN  <- 2DTFIM_1DRNN/Training1DRNN_2DTFIM.py:85-233   (exported there as run_2DTFIM)
 
 One iteration of the reference loop (:199-227) is: draw samples, local energies, mean/var, print every 10 steps,
 Adam step on  cost = mean(log_probs * Eloc) - mean(Eloc) * mean(log_probs)  (:156).  Here the whole iteration but
@@ -134,3 +136,69 @@ def run_J1J2(numsteps=10 ** 5, systemsize=20, J1_=1.0, J2_=0.0, Marshall_sign=Fa
                 P.save_npz(os.path.join(save_dir, "RNNwavefunction" + tag + ".npz"), params)
     run_J1J2.last_params = params
     return meanEnergy, varEnergy
+
+
+def _run_2d(model, params, units, Nx, Ny, Bx, numsteps, numsamples, lr, lr_of_it, seed, save_dir, tag, device, verbose):
+    """Shared loop of the two 2D drivers (both: cost of TrainingRNN_1DTFIM.py:156 on float64 wave functions,
+    default Adam, learning rate adapted per iteration)."""
+    scope = "RNNwavefunction"
+    wf = _lib.NativeWavefunction(model, Nx, Ny, tuple(units), device=device)
+    wf.set_params(params, scope=scope)
+    if verbose:
+        print("The number of params is {0}".format(P.count_params(params)))
+    couplings = np.append(np.ones(Nx * Ny), float(Bx))          # Jz = +np.ones((Nx, Ny))
+    opt = Adam()
+    meanEnergy, varEnergy = [], []
+    for it in range(numsteps + 1):
+        s1, s2, n, _ = wf.vmc_step(numsamples, seed=seed, step=it, couplings=couplings)["moments"]
+        meanE = s1 / n
+        varE = s2 / n - meanE * meanE
+        meanEnergy.append(meanE)
+        varEnergy.append(varE)
+        if verbose and it % 10 == 0:
+            print("mean(E): {0}, var(E): {1}, #samples {2}, #Step {3} \n\n".format(meanE, varE, numsamples, it))
+        if save_dir is not None and it % 10 == 0:
+            np.save(os.path.join(save_dir, "meanEnergy_" + tag + ".npy"), meanEnergy)
+            np.save(os.path.join(save_dir, "varEnergy_" + tag + ".npy"), varEnergy)
+            if it % 500 == 0:
+                P.save_npz(os.path.join(save_dir, "RNNwavefunction_" + tag + ".npz"), params)
+        grads = cost_gradient(wf, params, scope, meanE, numsamples)
+        params = opt.step(params, grads, lr_of_it(lr, it))
+        wf.set_params(params, scope=scope)
+    return meanEnergy, varEnergy, params
+
+
+def run_2DTFIM_2DRNN(numsteps=2 * 10 ** 4, systemsize_x=5, systemsize_y=5, Bx=+2, num_units=50, numsamples=500,
+                     learningrate=5e-3, seed=111, save_dir=None, device=0, verbose=True):
+    """Train the 2D MDRNN (float64, zig-zag path) on the open square-lattice transverse-field Ising model;
+    learning rate  lr (1 + it/5000)^-1  (Training2DRNN_2DTFIM.py:228).  The reference builds Jz from Nx, Ny one
+    line before it defines them (:96-99, a NameError as published); here the sizes are read first."""
+    Nx, Ny = systemsize_x, systemsize_y
+    lr = np.float64(learningrate)
+    units = [num_units]
+    params = P.init_mdrnn_params(num_units, seed=seed)
+    tag = "2DVanillaRNN_" + str(Nx) + "x" + str(Ny) + "_Bx" + str(Bx) + "_lradap" + str(lr) + "_samp" + str(numsamples) + \
+        "_units" + "".join("_{0}".format(u) for u in units)
+    meanE, varE, params = _run_2d(_lib.MODEL_MDRNN2D, params, units, Nx, Ny, Bx, numsteps, numsamples, lr,
+                                  lambda lr0, it: lr0 * (1 + it / 5000) ** (-1), seed, save_dir, tag, device, verbose)
+    run_2DTFIM_2DRNN.last_params = params
+    return meanE, varE
+
+
+def run_2DTFIM_1DRNN(numsteps=2 * 10 ** 4, systemsize_x=5, systemsize_y=5, Bx=+2, num_units=50, num_layers=1,
+                     numsamples=500, learningrate=1e-3, seed=333, save_dir=None, device=0, verbose=True):
+    """Train the float64 1D GRU wave function over the raster path of the square lattice; learning rate
+    1 / (1/lr + it/10)  (Training1DRNN_2DTFIM.py:231).  The reference seeds numpy / TF with `seed` but builds the
+    wave function with its class default seed 111 (:104); the initial weights here follow the latter."""
+    if num_layers != 1:
+        raise ValueError("only num_layers = 1 is implemented on gfx950 (the reference's run scripts use 1)")
+    Nx, Ny = systemsize_x, systemsize_y
+    lr = np.float64(learningrate)
+    units = [num_units] * num_layers
+    params = P.init_gru_params(units, seed=111, dtype=np.float64)
+    tag = "GRURNN_" + str(Nx) + "x" + str(Ny) + "_Bx" + str(Bx) + "_lradap" + str(lr) + "_samp" + str(numsamples) + \
+        "_units" + "".join("_{0}".format(u) for u in units)
+    meanE, varE, params = _run_2d(_lib.MODEL_GRU1D_F64, params, units, Nx, Ny, Bx, numsteps, numsamples, lr,
+                                  lambda lr0, it: 1.0 / ((1.0 / lr0) + it / 10), seed, save_dir, tag, device, verbose)
+    run_2DTFIM_1DRNN.last_params = params
+    return meanE, varE
