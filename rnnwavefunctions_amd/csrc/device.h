@@ -38,6 +38,30 @@ __device__ __forceinline__ float tanh_(float x) {
 }
 __device__ __forceinline__ double sigmoid_(double x) { return 1.0 / (1.0 + exp(-x)); }
 __device__ __forceinline__ double tanh_(double x) { return tanh(x); }
+// exp for x in [-700, 700] without the special-case handling of ocml: k = rint(x log2 e), r = x - k ln2 in two
+// steps (fdlibm's ln2 split), degree-13 Taylor polynomial on |r| <= 0.3466 (truncation 4e-18), v_ldexp_f64.
+// 20 VALU instructions against ~40 for ocml's exp and ~60 (with branches) for expm1; relative error < 3e-16.
+__device__ __forceinline__ double exp_fast(double x) {
+    x = x < -700.0 ? -700.0 : x;
+    const double kf = __builtin_rint(x * 1.4426950408889634074);
+    double r = __builtin_fma(kf, -6.93147180369123816490e-01, x);
+    r = __builtin_fma(kf, -1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;
+    p = __builtin_fma(p, r, 1.0 / 479001600.0);
+    p = __builtin_fma(p, r, 1.0 / 39916800.0);
+    p = __builtin_fma(p, r, 1.0 / 3628800.0);
+    p = __builtin_fma(p, r, 1.0 / 362880.0);
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return ldexp(p, (int)kf);
+}
 __device__ __forceinline__ float exp_(float x) { return expf(x); }
 __device__ __forceinline__ double exp_(double x) { return exp(x); }
 __device__ __forceinline__ float sqrt_(float x) { return sqrtf(x); }

@@ -46,16 +46,17 @@ struct MLaunch {
     static int flip(rnnwf_handle* h, MdArgs a) {
         unsigned grid = 0;
         if (int rc = flip_grid(h, a.ntiles, &grid)) return rc;
-        const size_t ring_bytes = (size_t)grid * WAVES * 2 * a.Nx * L::KT * 64 * 8;
+        const size_t ring_bytes = (size_t)grid * WAVES * 2 * a.Nx * ((L::KT + 1) / 2) * 64 * 16;
         if (int rc = ensure(h, h->rowbuf, ring_bytes)) return rc;
         a.ring = (double*)h->rowbuf.p;
+        if (const char* e = getenv("RNNWF_ABLATE")) a.ablate = atoi(e);   // diagnostics only
         TimedLaunch tl(h, 1);
         mdrnn_flip_kernel<NFULL, WAVES><<<grid, WAVES * 64, L::BYTES, h->stream>>>(a);
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }
-    static size_t hs_bytes_per_block() { return (size_t)L::KT * 64 * 8; }
-    static double mfma_flops_per_step() { return (double)L::NT * 2 * L::KT * 2048.0; }
+    static size_t hs_bytes_per_block() { return (size_t)((L::KT + 1) / 2) * 64 * 16; }
+    static double mfma_flops_per_step() { return (double)NFULL * 2 * L::KT * 2048.0; }
 
     static std::vector<char> pack(const rnnwf_handle* h) {
         const int H = h->H;
@@ -68,10 +69,10 @@ struct MLaunch {
         const auto& Wd = pv(h, "wf_dense/kernel");
         const auto& bd = pv(h, "wf_dense/bias");
         double* A = reinterpret_cast<double*>(img.data() + L::OFF_A);
-        for (int t = 0; t < L::NT; ++t)
+        for (int t = 0; t < NFULL; ++t)
             for (int row = 0; row < 16; ++row) {
                 const int unit = 16 * t + row;
-                if (unit >= H || (t == NFULL && row >= 4)) continue;
+                if (unit >= H) continue;
                 for (int kq = 0; kq < 4; ++kq) {
                     const int lane = (kq << 4) | row;
                     for (int kk = 0; kk < 2 * L::KT; ++kk) {
@@ -80,6 +81,17 @@ struct MLaunch {
                         const double w = kk < L::KT ? Wh[(size_t)k * H + unit] : Wv[(size_t)k * H + unit];
                         A[(((size_t)t * L::KT + kk / 2) * 64 + lane) * 2 + (kk & 1)] = w;
                     }
+                }
+            }
+        double* WR = reinterpret_cast<double*>(img.data() + L::OFF_WR);
+        for (int kk = 0; kk < 2 * L::KT; ++kk)
+            for (int q = 0; q < 4; ++q) {
+                const int k = 4 * (kk < L::KT ? kk : kk - L::KT) + q;
+                if (k >= H) continue;
+                for (int j = 0; j < 4; ++j) {
+                    const int unit = 16 * NFULL + j;
+                    if (unit >= H) continue;
+                    WR[(kk * 4 + q) * 4 + j] = kk < L::KT ? Wh[(size_t)k * H + unit] : Wv[(size_t)k * H + unit];
                 }
             }
         for (int v = 0; v < 3; ++v) {
@@ -106,6 +118,9 @@ struct MLaunch {
             }
         BD[0] = bd[0];
         BD[1] = bd[1];
+        double* WDD = reinterpret_cast<double*>(img.data() + L::OFF_WDD);
+        for (int unit = 0; unit < H; ++unit) WDD[unit] = Wd[(size_t)unit * 2 + 1] - Wd[(size_t)unit * 2];   // slot 4 kt + q
+        WDD[L::KT * 4] = bd[1] - bd[0];
         return img;
     }
 };
@@ -179,6 +194,7 @@ MdArgs base_args(rnnwf_handle* h, int64_t ns, const Maps& m) {
     a.wimg = h->wimg.p;
     a.N = h->N;
     a.Nx = h->Nx;
+    a.rem = h->H - 16 * h->NFULL;
     a.ns = ns;
     a.nsb = (ns + kChains - 1) / kChains;
     a.vert_pos = m.vert_pos;

@@ -33,7 +33,7 @@ struct MdGradArgs {
     int32_t N, Nx;
     int64_t ns, nsb;
     const uint32_t* bits;          // spins in visit order
-    const double* hs;              // [N][nsb][KT][64] states of the forward pass
+    const double* hs;              // [N][nsb][KP][64] double2 states of the forward pass (mdrnn_kernels.h)
     double* ring;                  // [total waves][2 Nx][KT][64]
     const double* eloc;            // [ns]
     double mean_e, inv_norm;
@@ -47,6 +47,7 @@ struct MdGradArgs {
 template <int NFULL, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) mdrnn_bwd_kernel(MdGradArgs a) {
     using G = MdGradLayout<NFULL>;
+    using C = MdCore<NFULL>;
     using F = Frag<double>;
     using V4 = F::V4;
     typedef double V2 __attribute__((ext_vector_type(2)));
@@ -81,11 +82,7 @@ __global__ void __launch_bounds__(WAVES * 64) mdrnn_bwd_kernel(MdGradArgs a) {
             const int pv = a.vert_pos[p];
             const bool first = a.row_first[p] != 0;
             double hn[KT];
-            {
-                const double* src = a.hs + (((int64_t)p * a.nsb + sb) * KT) * 64 + lane;
-#pragma unroll
-                for (int k = 0; k < KT; ++k) hn[k] = src[k * 64];
-            }
+            C::load_state(a.hs + (((int64_t)p * a.nsb + sb) * C::KP) * 128 + 2 * lane, hn);
             asm volatile("" ::: "memory");
             double z0 = 0.0, z1 = 0.0;
 #pragma unroll
@@ -120,18 +117,14 @@ __global__ void __launch_bounds__(WAVES * 64) mdrnn_bwd_kernel(MdGradArgs a) {
                 double hh[KT], hv[KT];
                 int sig_h = -1, sig_v = -1;
                 if (!first) {
-                    const double* src = a.hs + (((int64_t)(p - 1) * a.nsb + sb) * KT) * 64 + lane;
-#pragma unroll
-                    for (int k = 0; k < KT; ++k) hh[k] = src[k * 64];
+                    C::load_state(a.hs + (((int64_t)(p - 1) * a.nsb + sb) * C::KP) * 128 + 2 * lane, hh);
                     sig_h = md_spin(a.bits, a.ns, sc, p - 1);
                 } else {
 #pragma unroll
                     for (int k = 0; k < KT; ++k) hh[k] = 0.0;
                 }
                 if (pv >= 0) {
-                    const double* src = a.hs + (((int64_t)pv * a.nsb + sb) * KT) * 64 + lane;
-#pragma unroll
-                    for (int k = 0; k < KT; ++k) hv[k] = src[k * 64];
+                    C::load_state(a.hs + (((int64_t)pv * a.nsb + sb) * C::KP) * 128 + 2 * lane, hv);
                     sig_v = md_spin(a.bits, a.ns, sc, pv);
                 } else {
 #pragma unroll

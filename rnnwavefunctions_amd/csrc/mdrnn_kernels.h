@@ -4,8 +4,11 @@
 // One step:  h' = elu(x_h Uh + h_h Wh + x_v Uv + h_v Wv + b)  as  D^T = [Wh^T | Wv^T] [h_h ; h_v]  on the
 // f64 16x16x4 MFMA (C/D row = q + 4 r, so the fragment order is the natural unit order and, as for the GRU,
 // the output fragment is directly the next step's B operand).  One-hot inputs fold into the accumulator
-// initialisation.  Hidden states of all sites live in HBM in fragment order:
-//   hs [N][nsb][KT][64] f64  state after visit position p (base pass: out; flip pass: in)
+// initialisation.  The units beyond the last full 16-row tile (2 of 50) are NOT padded to a fifth MFMA tile:
+// on gfx950 the f64 MFMA and the f64 VALU have the same flop rate, so a tile with 2 live rows of 16 costs
+// 26 MFMAs (1664 cycles) where 2 x 26 FMAs per lane plus three cross-quarter shuffles do the same work.  Hidden states of all sites live in HBM in fragment order:
+//   hs [N][nsb][KP][64] double2  state after visit position p, k-steps in pairs (KP = ceil(KT/2); base pass: out;
+//                                flip pass and gradient: in)
 // because every site needs its vertical neighbour from the previous row.  A flip chain re-evaluates
 // positions i+1..N-1; states it produces itself go to a private ring of 2*Nx positions per wave.
 #pragma once
@@ -18,22 +21,25 @@ struct MdLayout {
     static constexpr int NFULL = NFULL_;
     static constexpr int KT = 4 * NFULL + 1;          // k-steps per hidden vector
     static constexpr int NT = NFULL + 1;              // 16-row output tiles (last: units 16 NFULL + q in reg 0)
-    static constexpr size_t OFF_A = 0;                                       // [NT][KT][64] double2 (k-steps 2g, 2g+1 of [h_h ; h_v])
-    static constexpr size_t OFF_BH = OFF_A + (size_t)NT * KT * 64 * 16;      // [3][NT][4][4] f64 : b + Uh[x_h]
+    static constexpr size_t OFF_A = 0;                                       // [NFULL][KT][64] double2 (k-steps 2g, 2g+1 of [h_h ; h_v])
+    static constexpr size_t OFF_WR = OFF_A + (size_t)NFULL * KT * 64 * 16;   // [2 KT][4 q][4 j] f64: row 4 kt + q of W -> remainder unit j
+    static constexpr size_t OFF_BH = OFF_WR + (size_t)2 * KT * 16 * 8;       // [3][NT][4][4] f64 : b + Uh[x_h]
     static constexpr size_t SZ_B = ((size_t)NT * 16 + 4) * 8;
     static constexpr size_t OFF_BV = OFF_BH + 3 * SZ_B;                      // [3][NT][4][4] f64 : Uv[x_v]
     static constexpr size_t OFF_WD = OFF_BV + 3 * SZ_B;                      // [KT][4][2] f64
     static constexpr size_t OFF_BD = OFF_WD + (size_t)KT * 4 * 2 * 8;        // [2] f64
-    static constexpr size_t BYTES = ((OFF_BD + 16 + 15) / 16) * 16;
+    static constexpr size_t OFF_WDD = OFF_BD + 16;                           // [KT][4] f64: Wd[:,1] - Wd[:,0], then bd[1] - bd[0]
+    static constexpr size_t BYTES = ((OFF_WDD + ((size_t)KT * 4 + 1) * 8 + 15) / 16) * 16;
 };
 
 struct MdArgs {
     const void* wimg;
     int32_t N, Nx;
+    int32_t rem;                   // num_units - 16 NFULL (1..4): units computed on the VALU
     int64_t ns, nsb;
     uint32_t* bits;                // spins in visit order
-    double* hs;                    // [N][nsb][KT][64]
-    double* ring;                  // flip pass: [total waves][2 Nx][KT][64] private states
+    double* hs;                    // [N][nsb][KP][64] double2
+    double* ring;                  // flip pass: [total waves][2 Nx][KP][64] double2 private states
     double* lpq;                   // [N+1][ns]
     double* out_lp;                // [ns]
     const int32_t* vert_pos;       // [N] visit position of the vertical neighbour, -1 at the first row
@@ -42,6 +48,7 @@ struct MdArgs {
     uint64_t seed, step;
     int64_t sample_offset;
     int32_t sampling;
+    int32_t ablate;                // diagnostics only (RNNWF_ABLATE), flip pass: 1 no ring stores, 2 no h_v loads, 4 no head
     int64_t ntiles;
 };
 
@@ -60,60 +67,107 @@ struct MdCore {
         __syncthreads();
     }
 
-    // hk[0..KT) = h_h fragment, hk[KT..2KT) = h_v fragment; result in out[KT]
-    static __device__ __forceinline__ void step(const char* lds, int sig_h, int sig_v, const double (&hk)[2 * KT],
-                                                double (&out)[KT], int lane) {
-        const int q = lane >> 4;
-        asm volatile("" ::: "memory");   // keep the weight fragments in LDS, not in registers (see gru_core.h)
-        V4 acc[NT];
-        {
-            const char* bh = lds + L::OFF_BH + (size_t)(sig_h + 1) * L::SZ_B + (size_t)q * 32;
-            const char* bv = lds + L::OFF_BV + (size_t)(sig_v + 1) * L::SZ_B + (size_t)q * 32;
+    static constexpr int KP = (KT + 1) / 2;           // a stored state: [KP][64] double2 (16-byte accesses; last pair padded)
+    static __device__ __forceinline__ void load_state(const double* base, double* dst) {   // base includes + 2 * lane
+        const V2* src = reinterpret_cast<const V2*>(base);
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                acc[t] = *reinterpret_cast<const V4*>(bh + t * 128) + *reinterpret_cast<const V4*>(bv + t * 128);
+        for (int g = 0; g < KP; ++g) {
+            const V2 v = src[g * 64];
+            dst[2 * g] = v[0];
+            if (2 * g + 1 < KT) dst[2 * g + 1] = v[1];
         }
+    }
+    static __device__ __forceinline__ void store_state(double* base, const double* srcv) {
+        V2* dst = reinterpret_cast<V2*>(base);
+#pragma unroll
+        for (int g = 0; g < KP; ++g) dst[g * 64] = V2{srcv[2 * g], 2 * g + 1 < KT ? srcv[2 * g + 1] : 0.0};
+    }
+
+    static __device__ __forceinline__ double elu(double x) {
+        const double e = exp_fast(x < 0.0 ? x : 0.0) - 1.0;             // tf.nn.elu; abs error < 3e-16
+        return x > 0.0 ? x : e;
+    }
+
+    // hh = h_h fragment, hv = h_v fragment; result in out[KT].  rem = num_units - 16 NFULL (1..4).
+    static __device__ __forceinline__ void step(const char* lds, int sig_h, int sig_v, const double (&hh)[KT],
+                                                const double (&hv)[KT], double (&out)[KT], int lane, int rem) {
+        const int q = lane >> 4;
+        double hk[2 * KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) { hk[kt] = hh[kt]; hk[KT + kt] = hv[kt]; }
+        asm volatile("" ::: "memory");   // keep the weight fragments in LDS, not in registers (see gru_core.h)
+        const char* bh = lds + L::OFF_BH + (size_t)(sig_h + 1) * L::SZ_B + (size_t)q * 32;
+        const char* bv = lds + L::OFF_BV + (size_t)(sig_v + 1) * L::SZ_B + (size_t)q * 32;
+        // remainder units on the VALU: this lane's rows 4 kt + q of [Wh ; Wv] against its own fragment values
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        {
+            const V2* wr = reinterpret_cast<const V2*>(lds + L::OFF_WR) + q * 2;
+#pragma unroll
+            for (int kk = 0; kk < 2 * KT; ++kk) {
+                const V2 w01 = wr[kk * 8];
+                s0 = __builtin_fma(hk[kk], w01[0], s0);
+                s1 = __builtin_fma(hk[kk], w01[1], s1);
+            }
+            if (rem > 2) {
+#pragma unroll
+                for (int kk = 0; kk < 2 * KT; ++kk) {
+                    const V2 w23 = wr[kk * 8 + 1];
+                    s2 = __builtin_fma(hk[kk], w23[0], s2);
+                    s3 = __builtin_fma(hk[kk], w23[1], s3);
+                }
+            }
+        }
+        // quarter q keeps unit j = q: fold the four quarters' partial sums with three exchanges
+        const bool lo = q < 2;
+        double ka = lo ? s0 : s2, kb = lo ? s1 : s3;
+        ka += __shfl_xor(lo ? s2 : s0, 32);
+        kb += __shfl_xor(lo ? s3 : s1, 32);
+        const bool even = (q & 1) == 0;
+        double mine = even ? ka : kb;
+        mine += __shfl_xor(even ? kb : ka, 16);
+        mine += *reinterpret_cast<const double*>(bh + NFULL * 128) + *reinterpret_cast<const double*>(bv + NFULL * 128);
+        asm volatile("" ::: "memory");
+        V4 acc[NFULL];
+#pragma unroll
+        for (int t = 0; t < NFULL; ++t)
+            acc[t] = *reinterpret_cast<const V4*>(bh + t * 128) + *reinterpret_cast<const V4*>(bv + t * 128);
         const V2* av = reinterpret_cast<const V2*>(lds + L::OFF_A) + lane;
 #pragma unroll
         for (int g = 0; g < KT; ++g) {
-            V2 a[NT];
+            V2 a[NFULL];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) a[t] = av[(t * KT + g) * 64];
+            for (int t = 0; t < NFULL; ++t) a[t] = av[(t * KT + g) * 64];
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = F::mfma(a[t][j], hk[2 * g + j], acc[t]);
+                for (int t = 0; t < NFULL; ++t) acc[t] = F::mfma(a[t][j], hk[2 * g + j], acc[t]);
         }
 #pragma unroll
         for (int m = 0; m < NFULL; ++m)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double x = acc[m][r];
-                out[4 * m + r] = x > 0.0 ? x : expm1(x);          // tf.nn.elu
-            }
-        {
-            const double x = acc[NT - 1][0];
-            out[KT - 1] = x > 0.0 ? x : expm1(x);
-        }
+            for (int r = 0; r < 4; ++r) out[4 * m + r] = elu(acc[m][r]);
+        out[KT - 1] = q < rem ? elu(mine) : 0.0;
     }
 
-    static __device__ __forceinline__ void head(const char* lds, const double (&h)[KT], int lane, double& p0, double& p1) {
+    // log p(0), log p(1) of the Dense(2)+softmax head (and p(0) for the sampler), from the logit difference:
+    // log p0 = -softplus(d), log p1 = -softplus(-d), d = z1 - z0; one exp and one log per site.
+    static __device__ __forceinline__ void head(const char* lds, const double (&h)[KT], int lane, double& lp0,
+                                                double& lp1, double& p0) {
         const int q = lane >> 4;
         asm volatile("" ::: "memory");
-        const double* wd = reinterpret_cast<const double*>(lds + L::OFF_WD) + q * 2;
-        double z0 = 0.0, z1 = 0.0;
+        const double* wdd = reinterpret_cast<const double*>(lds + L::OFF_WDD);
+        double d = 0.0;
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            z0 += h[kt] * wd[kt * 8];
-            z1 += h[kt] * wd[kt * 8 + 1];
-        }
-        const double* bd = reinterpret_cast<const double*>(lds + L::OFF_BD);
-        z0 += __shfl_xor(z0, 16); z0 += __shfl_xor(z0, 32); z0 += bd[0];
-        z1 += __shfl_xor(z1, 16); z1 += __shfl_xor(z1, 32); z1 += bd[1];
-        const double m = z0 > z1 ? z0 : z1;
-        const double e0 = exp(z0 - m), e1 = exp(z1 - m);
-        p0 = e0 / (e0 + e1);
-        p1 = e1 / (e0 + e1);
+        for (int kt = 0; kt < KT; ++kt) d = __builtin_fma(h[kt], wdd[kt * 4 + q], d);
+        d += __shfl_xor(d, 16); d += __shfl_xor(d, 32); d += wdd[KT * 4];
+        const double ad = d < 0.0 ? -d : d;
+        const double e = exp_fast(-ad);                     // in (0, 1]
+        const double lg = log(1.0 + e);
+        const double big = -(ad + lg), small = -lg;         // log-probability of the less / more likely value
+        lp0 = d > 0.0 ? big : small;
+        lp1 = d > 0.0 ? small : big;
+        const double inv = 1.0 / (1.0 + e);
+        p0 = d > 0.0 ? e * inv : inv;
     }
 };
 
@@ -122,7 +176,7 @@ __device__ __forceinline__ int md_spin(const uint32_t* bits, int64_t ns, int64_t
 }
 
 template <int NFULL, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64) mdrnn_base_kernel(MdArgs a) {
+__global__ void __launch_bounds__(WAVES * 64, NFULL <= 3 ? 2 : 1) mdrnn_base_kernel(MdArgs a) {
     using C = MdCore<NFULL>;
     constexpr int KT = C::KT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -136,7 +190,7 @@ __global__ void __launch_bounds__(WAVES * 64) mdrnn_base_kernel(MdArgs a) {
         const int64_t s = sb * kChains + c;
         const bool valid = s < a.ns;
         const int64_t sc = valid ? s : a.ns - 1;
-        double hk[2 * KT];      // [h_h | h_v]
+        double hh[KT], hv[KT];  // horizontal / vertical neighbour states
         double hn[KT];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) hn[kt] = 0.0;
@@ -150,32 +204,30 @@ __global__ void __launch_bounds__(WAVES * 64) mdrnn_base_kernel(MdArgs a) {
             const bool first = a.row_first[p] != 0;
             // horizontal neighbour = previous visit unless this site starts a row
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) hk[kt] = first ? 0.0 : hn[kt];
+            for (int kt = 0; kt < KT; ++kt) hh[kt] = first ? 0.0 : hn[kt];
             const int sig_h = first ? -1 : sig_prev;
             int sig_v = -1;
             if (pv < 0) {
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt) hk[KT + kt] = 0.0;
+                for (int kt = 0; kt < KT; ++kt) hv[kt] = 0.0;
             } else if (pv == p - 1) {           // row turn: the vertical neighbour was computed one step ago
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt) hk[KT + kt] = hn[kt];
+                for (int kt = 0; kt < KT; ++kt) hv[kt] = hn[kt];
                 sig_v = sig_prev;
             } else {
-                const double* src = a.hs + (((int64_t)pv * a.nsb + sb) * KT) * 64 + lane;
-#pragma unroll
-                for (int kt = 0; kt < KT; ++kt) hk[KT + kt] = src[kt * 64];
+                C::load_state(a.hs + (((int64_t)pv * a.nsb + sb) * C::KP) * 128 + 2 * lane, hv);
                 uint32_t wv = 0;
 #pragma unroll
                 for (int w = 0; w < 8; ++w) if (w == (pv >> 5)) wv = words[w];
                 sig_v = (wv >> (pv & 31)) & 1;
             }
-            C::step(lds, sig_h, sig_v, hk, hn, lane);
-            double p0, p1;
-            C::head(lds, hn, lane, p0, p1);
+            C::step(lds, sig_h, sig_v, hh, hv, hn, lane, a.rem);
+            double lp0, lp1, p0;
+            C::head(lds, hn, lane, lp0, lp1, p0);
             int sig;
             if (a.sampling) {
                 const float u = philox_uniform(a.seed, a.step, (uint64_t)(a.sample_offset + sc), p);
-                sig = ((double)u * (p0 + p1) < p0) ? 0 : 1;
+                sig = ((double)u < p0) ? 0 : 1;
 #pragma unroll
                 for (int w = 0; w < 8; ++w) if (w == (p >> 5)) words[w] |= (uint32_t)sig << (p & 31);
             } else {
@@ -184,14 +236,10 @@ __global__ void __launch_bounds__(WAVES * 64) mdrnn_base_kernel(MdArgs a) {
                 for (int w = 0; w < 8; ++w) if (w == (p >> 5)) wp = words[w];
                 sig = (wp >> (p & 31)) & 1;
             }
-            const double lsel = log(sig ? p1 : p0);
-            if (a.lpq && valid && q == 0) a.lpq[(int64_t)a.row_of_pos[p] * a.ns + s] = cum + log(sig ? p0 : p1);
+            const double lsel = sig ? lp1 : lp0;
+            if (a.lpq && valid && q == 0) a.lpq[(int64_t)a.row_of_pos[p] * a.ns + s] = cum + (sig ? lp0 : lp1);
             cum += lsel;
-            if (a.hs) {
-                double* dst = a.hs + (((int64_t)p * a.nsb + sb) * KT) * 64 + lane;
-#pragma unroll
-                for (int kt = 0; kt < KT; ++kt) dst[kt * 64] = hn[kt];
-            }
+            if (a.hs) C::store_state(a.hs + (((int64_t)p * a.nsb + sb) * C::KP) * 128 + 2 * lane, hn);
             sig_prev = sig;
         }
         if (valid && q == 0) {
@@ -205,7 +253,7 @@ __global__ void __launch_bounds__(WAVES * 64) mdrnn_base_kernel(MdArgs a) {
 }
 
 template <int NFULL, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64) mdrnn_flip_kernel(MdArgs a) {
+__global__ void __launch_bounds__(WAVES * 64, NFULL <= 3 ? 2 : 1) mdrnn_flip_kernel(MdArgs a) {
     using C = MdCore<NFULL>;
     constexpr int KT = C::KT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -216,7 +264,7 @@ __global__ void __launch_bounds__(WAVES * 64) mdrnn_flip_kernel(MdArgs a) {
     const int N = a.N;
     const int W = (N + 31) / 32;
     const int R = 2 * a.Nx;                                            // ring slots (positions) per wave
-    double* ring = a.ring + (int64_t)gw * R * KT * 64 + lane;
+    double* ring = a.ring + (int64_t)gw * R * C::KP * 128 + 2 * lane;
     for (int64_t tile = gw; tile < a.ntiles; tile += nw) {
         const int i = (int)(tile / a.nsb);
         const int64_t sb = tile - (int64_t)i * a.nsb;
@@ -228,56 +276,56 @@ __global__ void __launch_bounds__(WAVES * 64) mdrnn_flip_kernel(MdArgs a) {
         for (int w = 0; w < 8; ++w) words[w] = w < W ? a.bits[(int64_t)w * a.ns + sc] : 0u;
 #pragma unroll
         for (int w = 0; w < 8; ++w) if (w == (i >> 5)) words[w] ^= 1u << (i & 31);    // the flipped configuration
-        double hk[2 * KT], hn[KT];
-        {
-            const double* src = a.hs + (((int64_t)i * a.nsb + sb) * KT) * 64 + lane;  // state after position i (unchanged)
+        double hh[KT], hv[KT], hn[KT];
+        C::load_state(a.hs + (((int64_t)i * a.nsb + sb) * C::KP) * 128 + 2 * lane, hn);   // state after position i (unchanged)
+        // h_v operand of position p: zero (first row), the state just computed (row turn), a base-pass state
+        // (pv <= i) or one this chain produced (ring).  (Fetching one step ahead, behind the previous position's
+        // head, measured 3 % SLOWER at config 4, and non-temporal ring accesses made no difference: the loads are
+        // not latency-bound at 2 waves/SIMD.)
+        auto fetch_v = [&](int p) {
+            const int pv = a.vert_pos[p];
+            if (pv < 0) {
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) hn[kt] = src[kt * 64];
-        }
+                for (int kt = 0; kt < KT; ++kt) hv[kt] = 0.0;
+            } else if (pv == p - 1) {
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) hv[kt] = hn[kt];
+            } else if (a.ablate & 2) {
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) hv[kt] = hn[kt] * 0.5;
+            } else if (pv <= i) {
+                C::load_state(a.hs + (((int64_t)pv * a.nsb + sb) * C::KP) * 128 + 2 * lane, hv);
+            } else {
+                C::load_state(ring + (int64_t)(pv % R) * C::KP * 128, hv);
+            }
+        };
         double lp = 0.0;
         for (int p = i + 1; p < N; ++p) {
             const int pv = a.vert_pos[p];
             const bool first = a.row_first[p] != 0;
+            fetch_v(p);
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) hk[kt] = first ? 0.0 : hn[kt];
+            for (int kt = 0; kt < KT; ++kt) hh[kt] = first ? 0.0 : hn[kt];
             uint32_t wq = 0;
 #pragma unroll
             for (int w = 0; w < 8; ++w) if (w == ((p - 1) >> 5)) wq = words[w];
             const int sig_h = first ? -1 : (int)((wq >> ((p - 1) & 31)) & 1);
             int sig_v = -1;
-            if (pv < 0) {
-#pragma unroll
-                for (int kt = 0; kt < KT; ++kt) hk[KT + kt] = 0.0;
-            } else {
-                if (pv == p - 1) {
-#pragma unroll
-                    for (int kt = 0; kt < KT; ++kt) hk[KT + kt] = hn[kt];
-                } else if (pv <= i) {        // produced by the base pass
-                    const double* src = a.hs + (((int64_t)pv * a.nsb + sb) * KT) * 64 + lane;
-#pragma unroll
-                    for (int kt = 0; kt < KT; ++kt) hk[KT + kt] = src[kt * 64];
-                } else {                     // produced by this chain
-                    const double* src = ring + (int64_t)(pv % R) * KT * 64;
-#pragma unroll
-                    for (int kt = 0; kt < KT; ++kt) hk[KT + kt] = src[kt * 64];
-                }
+            if (pv >= 0) {
                 uint32_t wv = 0;
 #pragma unroll
                 for (int w = 0; w < 8; ++w) if (w == (pv >> 5)) wv = words[w];
                 sig_v = (wv >> (pv & 31)) & 1;
             }
-            C::step(lds, sig_h, sig_v, hk, hn, lane);
-            double p0, p1;
-            C::head(lds, hn, lane, p0, p1);
+            C::step(lds, sig_h, sig_v, hh, hv, hn, lane, a.rem);
+            double lp0 = hn[0], lp1 = hn[1], p0;
+            if (!(a.ablate & 4)) C::head(lds, hn, lane, lp0, lp1, p0);
             uint32_t wp = 0;
 #pragma unroll
             for (int w = 0; w < 8; ++w) if (w == (p >> 5)) wp = words[w];
-            lp += log(((wp >> (p & 31)) & 1) ? p1 : p0);
-            {
-                double* dst = ring + (int64_t)(p % R) * KT * 64;
-#pragma unroll
-                for (int kt = 0; kt < KT; ++kt) dst[kt * 64] = hn[kt];
-            }
+            lp += ((wp >> (p & 31)) & 1) ? lp1 : lp0;
+            // the last row has no vertical successor: nothing reads its states
+            if (p < N - a.Nx && !(a.ablate & 1)) C::store_state(ring + (int64_t)(p % R) * C::KP * 128, hn);
         }
         if (valid && q == 0) a.lpq[(int64_t)a.row_of_pos[i] * a.ns + s] += lp;
     }
