@@ -173,6 +173,7 @@ extern "C" int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double me
     if (h->model == RNNWF_MODEL_MDRNN2D) return mdrnn_vmc_gradient(h, mean_energy, norm);
     if (h->model != RNNWF_MODEL_GRU1D && h->model != RNNWF_MODEL_CRNN_U1 && h->model != RNNWF_MODEL_GRU1D_F64)
         return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: not implemented for the parity-symmetrised GRU RNN");
+    if (h->NL != 1) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: stacked layers (len(units) > 1) are forward-only so far");
     const bool cplx = h->model == RNNWF_MODEL_CRNN_U1;
     const bool f64 = h->model == RNNWF_MODEL_GRU1D_F64;
     const size_t es = f64 ? 8 : 4;

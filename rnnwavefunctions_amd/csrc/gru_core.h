@@ -219,4 +219,70 @@ struct GruCore {
     }
 };
 
+// One step of a stacked GRU layer above the first (UpperLayout): x = new state of the layer below.
+template <int NFULL>
+struct UpperCore {
+    using U = UpperLayout<NFULL>;
+    using F = Frag<float>;
+    using A = Act<float>;
+    using V4 = F::V4;
+    static constexpr int KT = U::KT, NT = U::NT, NT2 = U::NT2, NG = U::NG;
+
+    template <bool XBLOCK>
+    static __device__ __forceinline__ void block(const char* lds, const float (&v)[KT], V4 (&acc)[NT2], int lane) {
+        const V4* av = reinterpret_cast<const V4*>(lds + (XBLOCK ? U::OFF_AX : U::OFF_AH)) + lane;
+        const float* ar = reinterpret_cast<const float*>(lds + (XBLOCK ? U::OFF_AXR : U::OFF_AHR)) + lane;
+        // block tile t -> accumulator tile: r, u unchanged; third group -> y (X block) or q (H block); mixed last
+        auto dst = [](int t) { return t < 2 * NFULL ? t : t < 3 * NFULL ? (XBLOCK ? t + NFULL : t) : NT2 - 1; };
+        constexpr int TC = 5;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int t0 = 0; t0 < NT; t0 += TC) {
+                V4 a[TC];
+#pragma unroll
+                for (int t = 0; t < TC; ++t)
+                    if (t0 + t < NT) a[t] = av[((t0 + t) * NG + g) * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < TC; ++t)
+                        if (t0 + t < NT) acc[dst(t0 + t)] = F::mfma(a[t][j], v[g * 4 + j], acc[dst(t0 + t)]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[dst(t)] = F::mfma(ar[t * 64], v[KT - 1], acc[dst(t)]);
+    }
+
+    static __device__ __forceinline__ void step(const char* lds, const float (&x)[KT], float (&h)[KT], int lane) {
+        const int q = lane >> 4;
+        asm volatile("" ::: "memory");
+        V4 acc[NT2];
+        {
+            const char* b = lds + U::OFF_B + (size_t)q * 16;
+#pragma unroll
+            for (int t = 0; t < NT2; ++t) acc[t] = *reinterpret_cast<const V4*>(b + (size_t)t * 64);
+        }
+        block<true>(lds, x, acc, lane);
+        asm volatile("" ::: "memory");
+        block<false>(lds, h, acc, lane);
+#pragma unroll
+        for (int m = 0; m < NFULL; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float rg = A::sigmoid_scaled(acc[m][r]);
+                const float ug = A::sigmoid_scaled(acc[NFULL + m][r]);
+                const float cc = A::tanh_scaled(acc[3 * NFULL + m][r] + rg * acc[2 * NFULL + m][r]);
+                h[4 * m + r] = cc + ug * (h[4 * m + r] - cc);
+            }
+        {
+            const V4 a = acc[NT2 - 1];
+            const float rg = A::sigmoid_scaled(a[0]);
+            const float ug = A::sigmoid_scaled(a[1]);
+            const float cc = A::tanh_scaled(a[3] + rg * a[2]);
+            h[KT - 1] = cc + ug * (h[KT - 1] - cc);
+        }
+    }
+};
+
 }  // namespace rnnwf

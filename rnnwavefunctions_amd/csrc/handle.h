@@ -39,6 +39,7 @@ struct rnnwf_handle {
     bool f64 = false;
     int H = 0;       // num_units
     int NFULL = 0;   // padded hidden size = 16 NFULL + 4
+    int NL = 1;      // stacked GRU layers (len(units)); > 1 only for the f32 1D positive RNN
     int N = 0;       // chain length (nx * ny)
     int Nx = 1, Ny = 1;
     int cu_count = 0;

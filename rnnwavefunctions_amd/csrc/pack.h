@@ -1,6 +1,7 @@
 // pack.h - host-side packing of TF-named parameters into the LDS weight image of layout.h.
 #pragma once
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "handle.h"
@@ -117,6 +118,72 @@ std::vector<char> pack_gru_image(const rnnwf_handle* h) {
         bd[1] = (T)bp[0];
         bd[2] = (T)bp[1];
     }
+    return img;
+}
+
+// Image of GRU layer `layer` >= 1 (input = state of the layer below, dimension H), UpperLayout<NFULL>.
+template <int NFULL>
+std::vector<char> pack_upper_image(const rnnwf_handle* h, int layer) {
+    using U = UpperLayout<NFULL>;
+    const int H = h->H;
+    std::vector<char> img(U::BYTES, 0);
+    const std::string pre = "multi_rnn_cell/cell_" + std::to_string(layer) + "/cudnn_compatible_gru_cell/";
+    const auto& Wg = pv(h, pre + "gates/kernel");                         // [H + H, 2H]: input rows first, cols r | u
+    const auto& bg = pv(h, pre + "gates/bias");
+    const auto& Wci = pv(h, pre + "candidate/input_projection/kernel");   // [H, H]
+    const auto& bci = pv(h, pre + "candidate/input_projection/bias");
+    const auto& Wch = pv(h, pre + "candidate/hidden_projection/kernel");  // [H, H]
+    const auto& bch = pv(h, pre + "candidate/hidden_projection/bias");
+    const double sg = PackScale<float>::gate, sc = PackScale<float>::cand;
+    // gate ids: 0 r, 1 u, 2 q (hidden candidate), 3 y (input candidate)
+    auto decode = [&](bool xblock, int tile, int q, int r, int& gate, int& unit) -> bool {
+        if (tile < 3 * NFULL) {
+            gate = tile / NFULL;
+            if (gate == 2 && xblock) gate = 3;
+            unit = 16 * (tile % NFULL) + 4 * r + q;
+        } else {
+            if (r == (xblock ? 2 : 3)) return false;
+            gate = r;
+            unit = 16 * NFULL + q;
+        }
+        return unit < H;
+    };
+    auto wt = [&](bool xblock, int gate, int unit, int k) -> double {
+        if (k >= H) return 0.0;
+        const size_t row = xblock ? k : H + k;
+        if (gate == 0) return sg * Wg[row * 2 * H + unit];
+        if (gate == 1) return sg * Wg[row * 2 * H + H + unit];
+        if (gate == 2) return sc * Wch[(size_t)k * H + unit];
+        return sc * Wci[(size_t)k * H + unit];
+    };
+    for (int blk = 0; blk < 2; ++blk) {
+        const bool xb = blk == 0;
+        float* avec = reinterpret_cast<float*>(img.data() + (xb ? U::OFF_AX : U::OFF_AH));
+        float* arem = reinterpret_cast<float*>(img.data() + (xb ? U::OFF_AXR : U::OFF_AHR));
+        for (int tile = 0; tile < U::NT; ++tile)
+            for (int row = 0; row < 16; ++row) {
+                int q, r, gate, unit;
+                row_to_qr<float>(row, q, r);
+                if (!decode(xb, tile, q, r, gate, unit)) continue;
+                for (int kq = 0; kq < 4; ++kq) {
+                    const int lane = (kq << 4) | row;
+                    for (int g = 0; g < U::NG; ++g)
+                        for (int j = 0; j < 4; ++j)
+                            avec[(((size_t)tile * U::NG + g) * 64 + lane) * 4 + j] = (float)wt(xb, gate, unit, 4 * (g * 4 + j) + kq);
+                    arem[(size_t)tile * 64 + lane] = (float)wt(xb, gate, unit, 4 * (U::KT - 1) + kq);
+                }
+            }
+    }
+    float* b = reinterpret_cast<float*>(img.data() + U::OFF_B);
+    for (int t = 0; t < U::NT2; ++t)
+        for (int q = 0; q < 4; ++q)
+            for (int r = 0; r < 4; ++r) {
+                const int gate = t < 4 * NFULL ? t / NFULL : r;
+                const int unit = t < 4 * NFULL ? 16 * (t % NFULL) + 4 * r + q : 16 * NFULL + q;
+                if (unit >= H) continue;
+                const double v = gate == 0 ? sg * bg[unit] : gate == 1 ? sg * bg[H + unit] : gate == 2 ? sc * bch[unit] : sc * bci[unit];
+                b[t * 16 + q * 4 + r] = (float)v;
+            }
     return img;
 }
 

@@ -4,6 +4,7 @@
 #include <cstdlib>
 
 #include "gru_kernels.h"
+#include "ml_kernels.h"
 #include "models.h"
 #include "pack.h"
 #include "pack_split.h"
@@ -53,10 +54,68 @@ struct Launch {
     static double mfma_flops_per_step() { return (double)L::NT * L::KT * 2048.0; }
 };
 
-// one place that maps (dtype, NFULL) to an instantiation
+// stacked layers (f32): same interface, kernels of ml_kernels.h
+template <int NFULL, int NL, int WAVES>
+struct MLaunchL {
+    using M = MlCore<NFULL, NL>;
+    static int blocks_per_cu(rnnwf_handle* h, const void* fn, int* out) {
+        RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)M::BYTES));
+        int nb = 0;
+        RNNWF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, WAVES * 64, M::BYTES));
+        *out = std::max(nb, 1);
+        return 0;
+    }
+    static int base(rnnwf_handle* h, const PrnnArgs& a) {
+        static int bpc = 0;
+        const void* fn = (const void*)prnn_ml_base_kernel<NFULL, NL, WAVES>;
+        if (!bpc) if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
+        const int64_t need = (a.nsb + WAVES - 1) / WAVES;
+        const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
+        TimedLaunch tl(h, 0);
+        prnn_ml_base_kernel<NFULL, NL, WAVES><<<grid, WAVES * 64, M::BYTES, h->stream>>>(a);
+        RNNWF_HIP(h, hipGetLastError());
+        return 0;
+    }
+    static int flip(rnnwf_handle* h, const PrnnArgs& a) {
+        static int bpc = 0;
+        const void* fn = (const void*)prnn_ml_flip_kernel<NFULL, NL, WAVES>;
+        if (!bpc) if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
+        const int64_t need = (a.ntiles + WAVES - 1) / WAVES;
+        const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
+        TimedLaunch tl(h, 1);
+        prnn_ml_flip_kernel<NFULL, NL, WAVES><<<grid, WAVES * 64, M::BYTES, h->stream>>>(a);
+        RNNWF_HIP(h, hipGetLastError());
+        return 0;
+    }
+    static std::vector<char> pack(const rnnwf_handle* h) {
+        std::vector<char> img = pack_gru_image<float, NFULL, 1>(h);
+        for (int l = 1; l < NL; ++l) {
+            const std::vector<char> up = pack_upper_image<NFULL>(h, l);
+            img.insert(img.end(), up.begin(), up.end());
+        }
+        return img;
+    }
+    static size_t hck_bytes_per_block() { return (size_t)NL * M::KT * 64 * sizeof(float); }
+    static double mfma_flops_per_step() {
+        return ((double)M::C0::L::NT + 2.0 * (NL - 1) * M::CU::U::NT) * M::KT * 2048.0;
+    }
+};
+
+// one place that maps (dtype, NFULL, layers) to an instantiation
 #define PRNN_DISPATCH(h, EXPR)                                                              \
     do {                                                                                    \
-        if (!(h)->f64) {                                                                    \
+        if ((h)->NL == 2) {                                                                 \
+            switch ((h)->NFULL) {                                                           \
+                case 1: { using K = MLaunchL<1, 2, 4>; EXPR; }                              \
+                case 2: { using K = MLaunchL<2, 2, 4>; EXPR; }                              \
+                case 3: { using K = MLaunchL<3, 2, 8>; EXPR; }                              \
+            }                                                                               \
+        } else if ((h)->NL == 3) {                                                          \
+            switch ((h)->NFULL) {                                                           \
+                case 1: { using K = MLaunchL<1, 3, 4>; EXPR; }                              \
+                case 2: { using K = MLaunchL<2, 3, 8>; EXPR; }                              \
+            }                                                                               \
+        } else if (!(h)->f64) {                                                             \
             switch ((h)->NFULL) {                                                           \
                 case 1: { using K = Launch<float, 1, 4>; EXPR; }                            \
                 case 2: { using K = Launch<float, 2, 4>; EXPR; }                            \
@@ -233,7 +292,7 @@ int rnnwf::prnn_pack_image(rnnwf_handle* h, std::vector<char>& img) {
     // flip-pass engine: bf16x3 on the matrix core for the f32 models up to 68 units (RNNWF_ENGINE=f32 keeps the
     // f32-input MFMA everywhere); the base pass, sampling and log_probability always run the f32-MFMA kernels
     const char* eng = getenv("RNNWF_ENGINE");
-    h->engine_split = !h->f64 && h->NFULL <= 4 && !(eng && std::string(eng) == "f32");
+    h->engine_split = !h->f64 && h->NL == 1 && h->NFULL <= 4 && !(eng && std::string(eng) == "f32");
     if (h->engine_split) {
         std::vector<char> simg;
         SPLIT_DISPATCH(h, { simg = K::pack(h); break; });

@@ -44,6 +44,15 @@ static void declare_params(rnnwf_handle* h) {
     declare(h, pre + "candidate/input_projection/bias", {H});
     declare(h, pre + "candidate/hidden_projection/kernel", {H, H});
     declare(h, pre + "candidate/hidden_projection/bias", {H});
+    for (int l = 1; l < h->NL; ++l) {
+        const std::string pl = "multi_rnn_cell/cell_" + std::to_string(l) + "/cudnn_compatible_gru_cell/";
+        declare(h, pl + "gates/kernel", {H + H, 2 * H});
+        declare(h, pl + "gates/bias", {2 * H});
+        declare(h, pl + "candidate/input_projection/kernel", {H, H});
+        declare(h, pl + "candidate/input_projection/bias", {H});
+        declare(h, pl + "candidate/hidden_projection/kernel", {H, H});
+        declare(h, pl + "candidate/hidden_projection/bias", {H});
+    }
     if (h->model == RNNWF_MODEL_CRNN_U1) {
         declare(h, "wf_dense_ampl/kernel", {H, 2});
         declare(h, "wf_dense_ampl/bias", {2});
@@ -83,9 +92,19 @@ extern "C" int rnnwf_create(const rnnwf_config* cfg, rnnwf_handle** out) {
     if (cfg->abi_version != RNNWF_ABI_VERSION) return bad("rnnwf_create: ABI version mismatch");
     if (cfg->model < 0 || cfg->model > RNNWF_MODEL_MDRNN2D) return bad("rnnwf_create: unknown model");
     if (cfg->nx < 1 || cfg->ny < 1) return bad("rnnwf_create: system size must be positive");
-    if (cfg->num_layers != 1)
-        return bad("rnnwf_create: only single-layer wave functions (len(units) == 1) are implemented on gfx950");
+    if (cfg->num_layers < 1 || cfg->num_layers > 3)
+        return bad("rnnwf_create: len(units) must be 1..3");
     if (cfg->units[0] < 1) return bad("rnnwf_create: units[0] must be positive");
+    if (cfg->num_layers > 1) {
+        // MultiRNNCell stacks (1DTFIM/RNNwavefunction.py:32): f32 positive RNN only, equal widths, image must fit LDS
+        if (cfg->model != RNNWF_MODEL_GRU1D && cfg->model != RNNWF_MODEL_GRU1D_PARITY)
+            return bad("rnnwf_create: stacked layers (len(units) > 1) are implemented for the 1D positive GRU RNN only");
+        for (int l = 1; l < cfg->num_layers; ++l)
+            if (cfg->units[l] != cfg->units[0]) return bad("rnnwf_create: stacked layers must have equal num_units");
+        const int limit = cfg->num_layers == 2 ? 52 : 36;
+        if (cfg->units[0] > limit)
+            return bad("rnnwf_create: stacked layers: num_units <= 52 (2 layers) / 36 (3 layers), the LDS budget of the weight images");
+    }
     const bool two_d = cfg->model == RNNWF_MODEL_MDRNN2D || cfg->model == RNNWF_MODEL_GRU1D_F64;
     if (!two_d && cfg->ny != 1) return bad("rnnwf_create: ny must be 1 for the 1D models");
     if (cfg->model == RNNWF_MODEL_CRNN_U1 && (cfg->nx % 2)) return bad("rnnwf_create: the U(1) cRNN needs an even number of sites");
@@ -106,6 +125,7 @@ extern "C" int rnnwf_create(const rnnwf_config* cfg, rnnwf_handle** out) {
     h->Nx = cfg->nx;
     h->Ny = cfg->ny;
     h->N = cfg->nx * cfg->ny;
+    h->NL = cfg->num_layers;
     h->NFULL = pick_nfull(h->H, h->f64, h->model == RNNWF_MODEL_MDRNN2D);
     if (h->NFULL < 0) {
         delete h;

@@ -68,6 +68,55 @@ class MomentsAllReduce:
         return t.numpy()
 
 
+class ShardComm:
+    """What a sharded training loop needs from the transport: who am I, and sum-all-reduce of float64 arrays.
+
+    ShardComm()                          single process (identity)
+    ShardComm.from_torch(group=None)     any initialised torch.distributed group (gloo on CPU tensors; used by the
+                                         2-process test on the one-GPU box, where RCCL cannot place two ranks on one device)
+    ShardComm.from_rccl(native)          RCCL through the C ABI (rnnwf_allreduce_moments / rnnwf_allreduce_grads)
+    """
+
+    def __init__(self, rank=0, world=1, allreduce=None, native=None):
+        self.rank, self.world = int(rank), int(world)
+        self._allreduce = allreduce
+        self.native = native          # handle whose RCCL communicator reduces gradients inside the library
+
+    @classmethod
+    def from_torch(cls, group=None):
+        import torch
+        import torch.distributed as dist
+
+        def allreduce(a):
+            t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).copy())
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            return t.numpy()
+        return cls(dist.get_rank(group), dist.get_world_size(group), allreduce)
+
+    @classmethod
+    def from_rccl(cls, native, rank, world):
+        return cls(rank, world, lambda a: native.allreduce_moments(np.ascontiguousarray(a, dtype=np.float64)), native=native)
+
+    def allreduce(self, a):
+        if self.world == 1 or self._allreduce is None:
+            return np.asarray(a, dtype=np.float64)
+        return self._allreduce(a)
+
+    def allreduce_grads(self, grads):
+        """{name: array} summed over ranks (one flat all-reduce, names in sorted order on every rank)."""
+        if self.world == 1 or self._allreduce is None:
+            return grads
+        names = sorted(grads)
+        flat = np.concatenate([np.asarray(grads[k], dtype=np.float64).ravel() for k in names])
+        flat = self._allreduce(flat)
+        out, off = {}, 0
+        for k in names:
+            n = grads[k].size
+            out[k] = flat[off:off + n].reshape(grads[k].shape)
+            off += n
+        return out
+
+
 def init_rccl_from_env(native, dist=None):
     """One process per GPU, launched by ``python -m torch.distributed.run``: rank 0 creates the RCCL unique id,
     the launcher's process group (gloo) carries its 128 bytes to the other ranks, every rank joins."""

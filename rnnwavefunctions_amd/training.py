@@ -16,6 +16,7 @@ import os
 import numpy as np
 
 from . import _lib
+from . import distributed as D
 from . import params as P
 
 
@@ -49,52 +50,90 @@ def cost_gradient(native, params, scope, mean_energy, norm, allreduce=False):
     return {scope + "/" + k: v for k, v in g.items()}
 
 
+def _train(wf, params, scope, couplings, numsteps, numsamples, seed, lr, lr_of_it, opt, complex_energy, comm, verbose,
+           on_step=None):
+    """The loop all four drivers share (1DTFIM/TrainingRNN_1DTFIM.py:199-227 and its siblings): sample + local
+    energies + moments on the GPU, mean/var, print every 10 steps, gradient of the cost, Adam.
+
+    Sharded over `comm.world` processes (one per GPU): rank r draws the global samples shard_range(numsamples, r, world)
+    - the RNG is keyed by the global index, so the union is the single-process batch -, the four moments and the
+    gradient partial sums are all-reduced, and every rank applies the identical Adam step."""
+    comm = comm or D.ShardComm()
+    offset, count = D.shard_range(numsamples, comm.rank, comm.world)
+    meanEnergy, varEnergy = [], []
+    for it in range(numsteps + 1):
+        m = wf.vmc_step(count, seed=seed, step=it, couplings=couplings, sample_offset=offset)["moments"]
+        s1, s2, n, si = comm.allreduce(m)
+        meanE = complex(s1 / n, si / n) if complex_energy else s1 / n
+        varE = s2 / n - (s1 / n) ** 2
+        meanEnergy.append(np.complex64(meanE) if complex_energy else meanE)
+        varEnergy.append(varE)
+        if verbose and comm.rank == 0 and it % 10 == 0:
+            print("mean(E): {0}, var(E): {1}, #samples {2}, #Step {3} \n\n".format(meanEnergy[-1], varE, numsamples, it))
+        if on_step is not None and comm.rank == 0:
+            on_step(it, meanEnergy, varEnergy, params)
+        native_reduce = comm.native is not None and comm.world > 1
+        grads = cost_gradient(wf, params, scope, meanE, n, allreduce=native_reduce)
+        if not native_reduce:
+            grads = comm.allreduce_grads(grads)
+        params = opt.step(params, grads, lr_of_it(lr, it))
+        wf.set_params(params, scope=scope)
+    return meanEnergy, varEnergy, params
+
+
+def _resolve_comm(comm, wf):
+    """comm=None: single process; a distributed.ShardComm: used as is; "env": one process per GPU launched by
+    `python -m torch.distributed.run` - the launcher's (gloo) group carries RCCL's unique id, all-reduces run on RCCL."""
+    if comm == "env":
+        rank, world = D.init_rccl_from_env(wf)
+        return D.ShardComm.from_rccl(wf, rank, world)
+    return comm
+
+
+def _saver(save_dir, tag_mean, tag_var, tag_model):
+    if save_dir is None:
+        return None
+
+    def on_step(it, meanEnergy, varEnergy, params):
+        if it % 10 == 0:
+            np.save(os.path.join(save_dir, tag_mean + ".npy"), meanEnergy)
+            np.save(os.path.join(save_dir, tag_var + ".npy"), varEnergy)
+        if it % 500 == 0:
+            P.save_npz(os.path.join(save_dir, tag_model + ".npz"), params)
+    return on_step
+
+
 def run_1DTFIM(numsteps=10 ** 4, systemsize=20, num_units=50, Bx=1, num_layers=1, numsamples=500, learningrate=5e-3,
-               seed=111, save_dir=None, device=0, verbose=True):
+               seed=111, save_dir=None, device=0, verbose=True, comm=None):
     """Train the 1D pRNN wave function on the open transverse-field Ising chain; returns (meanEnergy, varEnergy)
-    lists with one entry per iteration, as the reference's run_1DTFIM."""
+    lists with one entry per iteration, as the reference's run_1DTFIM.  `comm` (distributed.ShardComm) shards the
+    batch over one process per GPU."""
     if num_layers != 1:
-        raise ValueError("only num_layers = 1 is implemented on gfx950 (the reference's run scripts use 1)")
+        raise ValueError("training is implemented for num_layers = 1 (the reference's run scripts); stacked layers are forward-only")
     N = systemsize
     scope = "RNNwavefunction"
     Jz = +np.ones(N)
-    lr = np.float64(learningrate)
     units = [num_units] * num_layers
     params = P.init_gru_params(units, seed=seed, scope=scope)
     wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D, N, 1, tuple(units), device=device)
     wf.set_params(params, scope=scope)
-    if verbose:
+    comm = _resolve_comm(comm, wf)
+    if verbose and (comm is None or comm.rank == 0):
         for k, v in params.items():
             print(k, (v.size,))
         print("The number of params is {0}".format(P.count_params(params)))
-    couplings = np.append(Jz, float(Bx))
-    opt = Adam()
     ending = "_units" + "".join("_{0}".format(u) for u in units)
-    meanEnergy, varEnergy = [], []
-    for it in range(numsteps + 1):
-        out = wf.vmc_step(numsamples, seed=seed, step=it, couplings=couplings)
-        s1, s2, n, _ = out["moments"]
-        meanE = s1 / n
-        varE = s2 / n - meanE * meanE
-        meanEnergy.append(meanE)
-        varEnergy.append(varE)
-        if verbose and it % 10 == 0:
-            print("mean(E): {0}, var(E): {1}, #samples {2}, #Step {3} \n\n".format(meanE, varE, numsamples, it))
-        grads = cost_gradient(wf, params, scope, meanE, numsamples)
-        params = opt.step(params, grads, lr)
-        wf.set_params(params, scope=scope)
-        if save_dir is not None and it % 10 == 0:
-            tag = "_N" + str(N) + "_samp" + str(numsamples) + "_Jz" + str(Jz[0]) + "_Bx" + str(Bx) + "_GRURNN_OBC_TFIM" + ending
-            np.save(os.path.join(save_dir, "meanEnergy" + tag + ".npy"), meanEnergy)
-            np.save(os.path.join(save_dir, "varEnergy" + tag + ".npy"), varEnergy)
-            if it % 500 == 0:
-                P.save_npz(os.path.join(save_dir, "RNNwavefunction" + tag + ".npz"), params)
+    tag = "_N" + str(N) + "_samp" + str(numsamples) + "_Jz" + str(Jz[0]) + "_Bx" + str(Bx) + "_GRURNN_OBC_TFIM" + ending
+    meanEnergy, varEnergy, params = _train(
+        wf, params, scope, np.append(Jz, float(Bx)), numsteps, numsamples, seed, np.float64(learningrate),
+        lambda lr0, it: lr0, Adam(), False, comm, verbose,
+        _saver(save_dir, "meanEnergy" + tag, "varEnergy" + tag, "RNNwavefunction" + tag))
     run_1DTFIM.last_params = params
     return meanEnergy, varEnergy
 
 
 def run_J1J2(numsteps=10 ** 5, systemsize=20, J1_=1.0, J2_=0.0, Marshall_sign=False, num_units=50, num_layers=1,
-             numsamples=500, learningrate=2.5 * 1e-4, seed=111, save_dir=None, device=0, verbose=True):
+             numsamples=500, learningrate=2.5 * 1e-4, seed=111, save_dir=None, device=0, verbose=True, comm=None):
     """Train the complex RNN wave function (U(1) zero magnetisation) on the open J1-J2 chain; returns
     (meanEnergy, varEnergy) as the reference's run_J1J2 (meanEnergy complex, varEnergy = var of the real part).
 
@@ -110,66 +149,38 @@ def run_J1J2(numsteps=10 ** 5, systemsize=20, J1_=1.0, J2_=0.0, Marshall_sign=Fa
     params = P.init_gru_params(units, seed=seed, scope=scope, heads=("wf_dense_ampl", "wf_dense_phase"))
     wf = _lib.NativeWavefunction(_lib.MODEL_CRNN_U1, N, 1, tuple(units), device=device)
     wf.set_params(params, scope=scope)
-    if verbose:
+    comm = _resolve_comm(comm, wf)
+    if verbose and (comm is None or comm.rank == 0):
         print("The number of params is {0}".format(P.count_params(params)))
     periodic = 1.0 if Marshall_sign else 0.0          # the reference's quirk, see the docstring
     couplings = np.concatenate([J1_ * np.ones(N), J2_ * np.ones(N), np.zeros(N), [periodic, 0.0]])
-    opt = Adam(beta1=0.9, beta2=0.999, epsilon=1e-8)
     ending = "_units" + "".join("_{0}".format(u) for u in units)
-    meanEnergy, varEnergy = [], []
-    for it in range(numsteps + 1):
-        s1, s2, n, si = wf.vmc_step(numsamples, seed=seed, step=it, couplings=couplings)["moments"]
-        meanE = np.complex64(complex(s1 / n, si / n))
-        varE = s2 / n - (s1 / n) ** 2
-        meanEnergy.append(meanE)
-        varEnergy.append(varE)
-        if verbose and it % 10 == 0:
-            print("mean(E): {0}, var(E): {1}, #samples {2}, #Step {3} \n\n".format(meanE, varE, numsamples, it))
-        grads = cost_gradient(wf, params, scope, complex(s1 / n, si / n), numsamples)
-        params = opt.step(params, grads, lr)
-        wf.set_params(params, scope=scope)
-        if save_dir is not None and it % 10 == 0:
-            tag = "_N" + str(N) + "_samp" + str(numsamples) + "_lradap" + str(lr) + "_complexGRURNN_J1J2" + str(float(J2_)) + ending + "_zeromag"
-            np.save(os.path.join(save_dir, "meanEnergy" + tag + ".npy"), meanEnergy)
-            np.save(os.path.join(save_dir, "varEnergy" + tag + ".npy"), varEnergy)
-            if it % 500 == 0:
-                P.save_npz(os.path.join(save_dir, "RNNwavefunction" + tag + ".npz"), params)
+    tag = "_N" + str(N) + "_samp" + str(numsamples) + "_lradap" + str(lr) + "_complexGRURNN_J1J2" + str(float(J2_)) + ending + "_zeromag"
+    meanEnergy, varEnergy, params = _train(
+        wf, params, scope, couplings, numsteps, numsamples, seed, lr, lambda lr0, it: lr0,
+        Adam(beta1=0.9, beta2=0.999, epsilon=1e-8), True, comm, verbose,
+        _saver(save_dir, "meanEnergy" + tag, "varEnergy" + tag, "RNNwavefunction" + tag))
     run_J1J2.last_params = params
     return meanEnergy, varEnergy
 
 
-def _run_2d(model, params, units, Nx, Ny, Bx, numsteps, numsamples, lr, lr_of_it, seed, save_dir, tag, device, verbose):
-    """Shared loop of the two 2D drivers (both: cost of TrainingRNN_1DTFIM.py:156 on float64 wave functions,
+def _run_2d(model, params, units, Nx, Ny, Bx, numsteps, numsamples, lr, lr_of_it, seed, save_dir, tag, device, verbose,
+            comm):
+    """Shared part of the two 2D drivers (both: cost of TrainingRNN_1DTFIM.py:156 on float64 wave functions,
     default Adam, learning rate adapted per iteration)."""
     scope = "RNNwavefunction"
     wf = _lib.NativeWavefunction(model, Nx, Ny, tuple(units), device=device)
     wf.set_params(params, scope=scope)
-    if verbose:
+    comm = _resolve_comm(comm, wf)
+    if verbose and (comm is None or comm.rank == 0):
         print("The number of params is {0}".format(P.count_params(params)))
     couplings = np.append(np.ones(Nx * Ny), float(Bx))          # Jz = +np.ones((Nx, Ny))
-    opt = Adam()
-    meanEnergy, varEnergy = [], []
-    for it in range(numsteps + 1):
-        s1, s2, n, _ = wf.vmc_step(numsamples, seed=seed, step=it, couplings=couplings)["moments"]
-        meanE = s1 / n
-        varE = s2 / n - meanE * meanE
-        meanEnergy.append(meanE)
-        varEnergy.append(varE)
-        if verbose and it % 10 == 0:
-            print("mean(E): {0}, var(E): {1}, #samples {2}, #Step {3} \n\n".format(meanE, varE, numsamples, it))
-        if save_dir is not None and it % 10 == 0:
-            np.save(os.path.join(save_dir, "meanEnergy_" + tag + ".npy"), meanEnergy)
-            np.save(os.path.join(save_dir, "varEnergy_" + tag + ".npy"), varEnergy)
-            if it % 500 == 0:
-                P.save_npz(os.path.join(save_dir, "RNNwavefunction_" + tag + ".npz"), params)
-        grads = cost_gradient(wf, params, scope, meanE, numsamples)
-        params = opt.step(params, grads, lr_of_it(lr, it))
-        wf.set_params(params, scope=scope)
-    return meanEnergy, varEnergy, params
+    return _train(wf, params, scope, couplings, numsteps, numsamples, seed, lr, lr_of_it, Adam(), False, comm, verbose,
+                  _saver(save_dir, "meanEnergy_" + tag, "varEnergy_" + tag, "RNNwavefunction_" + tag))
 
 
 def run_2DTFIM_2DRNN(numsteps=2 * 10 ** 4, systemsize_x=5, systemsize_y=5, Bx=+2, num_units=50, numsamples=500,
-                     learningrate=5e-3, seed=111, save_dir=None, device=0, verbose=True):
+                     learningrate=5e-3, seed=111, save_dir=None, device=0, verbose=True, comm=None):
     """Train the 2D MDRNN (float64, zig-zag path) on the open square-lattice transverse-field Ising model;
     learning rate  lr (1 + it/5000)^-1  (Training2DRNN_2DTFIM.py:228).  The reference builds Jz from Nx, Ny one
     line before it defines them (:96-99, a NameError as published); here the sizes are read first."""
@@ -180,13 +191,13 @@ def run_2DTFIM_2DRNN(numsteps=2 * 10 ** 4, systemsize_x=5, systemsize_y=5, Bx=+2
     tag = "2DVanillaRNN_" + str(Nx) + "x" + str(Ny) + "_Bx" + str(Bx) + "_lradap" + str(lr) + "_samp" + str(numsamples) + \
         "_units" + "".join("_{0}".format(u) for u in units)
     meanE, varE, params = _run_2d(_lib.MODEL_MDRNN2D, params, units, Nx, Ny, Bx, numsteps, numsamples, lr,
-                                  lambda lr0, it: lr0 * (1 + it / 5000) ** (-1), seed, save_dir, tag, device, verbose)
+                                  lambda lr0, it: lr0 * (1 + it / 5000) ** (-1), seed, save_dir, tag, device, verbose, comm)
     run_2DTFIM_2DRNN.last_params = params
     return meanE, varE
 
 
 def run_2DTFIM_1DRNN(numsteps=2 * 10 ** 4, systemsize_x=5, systemsize_y=5, Bx=+2, num_units=50, num_layers=1,
-                     numsamples=500, learningrate=1e-3, seed=333, save_dir=None, device=0, verbose=True):
+                     numsamples=500, learningrate=1e-3, seed=333, save_dir=None, device=0, verbose=True, comm=None):
     """Train the float64 1D GRU wave function over the raster path of the square lattice; learning rate
     1 / (1/lr + it/10)  (Training1DRNN_2DTFIM.py:231).  The reference seeds numpy / TF with `seed` but builds the
     wave function with its class default seed 111 (:104); the initial weights here follow the latter."""
@@ -199,6 +210,6 @@ def run_2DTFIM_1DRNN(numsteps=2 * 10 ** 4, systemsize_x=5, systemsize_y=5, Bx=+2
     tag = "GRURNN_" + str(Nx) + "x" + str(Ny) + "_Bx" + str(Bx) + "_lradap" + str(lr) + "_samp" + str(numsamples) + \
         "_units" + "".join("_{0}".format(u) for u in units)
     meanE, varE, params = _run_2d(_lib.MODEL_GRU1D_F64, params, units, Nx, Ny, Bx, numsteps, numsamples, lr,
-                                  lambda lr0, it: 1.0 / ((1.0 / lr0) + it / 10), seed, save_dir, tag, device, verbose)
+                                  lambda lr0, it: 1.0 / ((1.0 / lr0) + it / 10), seed, save_dir, tag, device, verbose, comm)
     run_2DTFIM_1DRNN.last_params = params
     return meanE, varE

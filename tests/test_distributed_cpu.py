@@ -54,7 +54,11 @@ def _worker(rank, world, port, out_dir):
     s, _ = M.prnn_sample(prm, N, u)
     e = E.ising_local_energies(np.ones(N), 1.0, s, lambda x: M.prnn_log_probability(prm, x))
     m = DD.MomentsAllReduce()(DD.local_moments(e))
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), s=s, e=e, m=m, offset=offset)
+    comm = DD.ShardComm.from_torch()                        # the transport of the sharded training loop
+    assert (comm.rank, comm.world) == (rank, world)
+    m2 = comm.allreduce(DD.local_moments(e))
+    g = comm.allreduce_grads({"b/kernel": np.full((3, 2), rank + 1.0), "a/bias": np.arange(4.0) * (rank + 1)})
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), s=s, e=e, m=m, m2=m2, offset=offset, gk=g["b/kernel"], gb=g["a/bias"])
     dist.barrier()
     dist.destroy_process_group()
 
@@ -77,6 +81,17 @@ def test_two_rank_gloo_equals_single_process(tmp_path):
     assert np.array_equal(np.concatenate([r[0]["s"], r[1]["s"]]), s_full)      # union of shards == one batch
     assert np.allclose(np.concatenate([r[0]["e"], r[1]["e"]]), e_full, rtol=1e-6)
     assert np.array_equal(r[0]["m"], r[1]["m"])                               # every rank holds the global sums
+    for k in range(2):
+        assert np.array_equal(r[k]["m2"], r[0]["m"])
+        assert np.array_equal(r[k]["gk"], np.full((3, 2), 3.0)) and np.array_equal(r[k]["gb"], np.arange(4.0) * 3)
     mean, var = D.moments_to_energy(r[0]["m"])
     assert r[0]["m"][2] == total
     assert np.isclose(mean, e_full.mean(), rtol=1e-6) and np.isclose(var, e_full.var(), rtol=1e-5)
+
+
+def test_shard_comm_single_process_is_identity():
+    c = D.ShardComm()
+    assert (c.rank, c.world) == (0, 1)
+    assert np.array_equal(c.allreduce([1.0, 2.0]), [1.0, 2.0])
+    g = {"w": np.ones((2, 2))}
+    assert c.allreduce_grads(g) is g

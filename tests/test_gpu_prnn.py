@@ -273,3 +273,84 @@ def test_both_flip_engines_agree_with_the_f64_oracle(N, H, ns, monkeypatch):
         assert err_lp <= 2e-6 * N + 2e-6
         assert err_e <= 2e-5
     assert np.allclose(got["f32"][0], got["bf16x3"][0], rtol=2e-5)
+
+
+# ---- stacked layers (units = [h] * num_layers, 1DTFIM/TrainingRNN_1DTFIM.py:98; MultiRNNCell, RNNwavefunction.py:32) ----
+
+def stacked_like(H, L, seed):
+    return P.randomize_biases(P.scale_kernels(P.init_gru_params([H] * L, seed=seed), 1.6), seed + 1)
+
+
+def make_stacked(model, N, H, L, prm):
+    from rnnwavefunctions_amd import _lib
+    wf = _lib.NativeWavefunction(model, N, 1, (H,) * L)
+    wf.set_params(prm, scope=SCOPE)
+    return wf
+
+
+@pytest.mark.parametrize("N,H,L,B", [(12, 20, 2, 40), (9, 10, 3, 33), (20, 50, 2, 24), (7, 36, 3, 17), (10, 4, 2, 16),
+                                      (16, 52, 2, 16)])
+def test_stacked_layers_log_prob_and_eloc_match_oracle(N, H, L, B):
+    from rnnwavefunctions_amd import _lib
+    prm = stacked_like(H, L, seed=H + L)
+    assert M.num_gru_layers(prm) == L
+    wf = make_stacked(_lib.MODEL_GRU1D, N, H, L, prm)
+    assert wf.num_params() == P.count_params(prm)
+    rng = np.random.RandomState(N)
+    s = rng.randint(0, 2, (B, N)).astype(np.int32)
+    got = wf.log_prob(s)
+    prm64 = {k: v.astype(np.float64) for k, v in prm.items()}
+    ref64 = M.prnn_log_probability(prm64, s, dtype=np.float64)
+    print("L=%d N=%d H=%d: |hip-oracle64|=%.2e" % (L, N, H, np.abs(got - ref64).max()))
+    assert np.abs(got - ref64).max() <= 2e-6 * N * L + 2e-6
+    Jz = 1.0 + 0.1 * rng.standard_normal(N)
+    lp = np.zeros((N + 1) * B)
+    e = wf.tfim_eloc(s, Jz, 0.9, log_probs=lp)
+    e_ref, lp_ref = E.ising_local_energies(Jz, 0.9, s, lambda x: M.prnn_log_probability(prm64, x, dtype=np.float64),
+                                           return_log_probs=True)
+    assert np.allclose(lp, lp_ref.ravel(), rtol=0, atol=2e-6 * N * L + 2e-6)
+    assert np.allclose(e, e_ref, rtol=3e-5)
+
+
+def test_stacked_layers_sampling_vmc_step_and_parity_model():
+    from rnnwavefunctions_amd import _lib
+    N, H, L, ns = 14, 20, 2, 600
+    prm = stacked_like(H, L, seed=4)
+    wf = make_stacked(_lib.MODEL_GRU1D, N, H, L, prm)
+    s, lg = wf.sample(ns, seed=11, step=2, return_log=True)
+    u = philox.uniforms(11, 2, 0, ns, N)
+    s_ref, lg_ref = M.prnn_sample(prm, N, u)
+    bad = np.where((s != s_ref).any(axis=1))[0]
+    assert len(bad) <= 2
+    good = np.setdiff1d(np.arange(ns), bad)
+    assert np.allclose(lg[good], lg_ref[good], rtol=0, atol=4e-6 * N + 2e-6)
+    lp_all = wf.log_prob(all_configs(N))
+    assert abs(np.exp(lp_all).sum() - 1) < 3e-5                     # normalised over the 2^14 configurations
+    out = wf.vmc_step(ns, seed=11, step=2, couplings=np.append(np.ones(N), 1.0), want_samples=True, want_eloc=True)
+    assert np.array_equal(out["samples"], s)
+    assert np.allclose(out["eloc"], wf.tfim_eloc(s, np.ones(N), 1.0), rtol=1e-12)
+    assert wf.engine_name() == "f32mfma"                            # no bf16x3 image for stacked layers
+    with pytest.raises(ValueError, match="forward-only"):
+        wf.vmc_gradient(0.0, ns, {"wf_dense/bias": (2,)})
+    wfp = make_stacked(_lib.MODEL_GRU1D_PARITY, N, H, L, prm)
+    sp = s[:64].astype(np.int32)
+    ref = M.prnn_paritysym_log_probability(prm, sp)
+    assert np.allclose(wfp.log_prob(sp), ref, rtol=0, atol=4e-6 * N + 2e-6)
+
+
+def test_stacked_layers_limits_and_facade():
+    from rnnwavefunctions_amd import _lib
+    from rnnwavefunctions_amd.TFIM1D.RNNwavefunction import RNNwavefunction
+    with pytest.raises(ValueError, match="equal num_units"):
+        _lib.NativeWavefunction(_lib.MODEL_GRU1D, 10, 1, (20, 10))
+    with pytest.raises(ValueError, match="LDS budget"):
+        _lib.NativeWavefunction(_lib.MODEL_GRU1D, 10, 1, (64, 64))
+    with pytest.raises(ValueError, match="1D positive GRU"):
+        _lib.NativeWavefunction(_lib.MODEL_CRNN_U1, 10, 1, (10, 10))
+    wf = RNNwavefunction(10, cell="CudnnCompatibleGRUCell", units=[10, 10], seed=111)
+    # layer 0: 12*20 + 20 + 2*10 + 10 + 10*10 + 10 = 400; layer 1: 20*20 + 20 + 10*10 + 10 + 10*10 + 10 = 640; head 22
+    assert wf.num_params() == 400 + 640 + 22
+    prm = wf.get_params()
+    smp = wf._native.sample(50, seed=111, step=0)
+    lp = wf._native.log_prob(smp)
+    assert np.allclose(lp, M.prnn_log_probability(prm, smp), rtol=0, atol=1e-4)
