@@ -132,7 +132,7 @@ CrnnArgs base_args(rnnwf_handle* h, int64_t ns) {
 
 int64_t max_chains_per_pass(rnnwf_handle* h) {
     const size_t per_block = (size_t)std::max(h->N - 1, 1) * hck_bytes_per_block(h);
-    return std::max<int64_t>(1, (int64_t)(kHckBudget / per_block)) * kChains;
+    return std::max<int64_t>(1, (int64_t)(state_budget_bytes(kHckBudget) / per_block)) * kChains;
 }
 
 // J1-J2 local energies of the ns chains whose packed spins are in h->bits (drawn here when `sampling`).

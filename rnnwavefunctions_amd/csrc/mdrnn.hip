@@ -186,7 +186,7 @@ int get_maps(rnnwf_handle* h, Maps* m) {
 
 int64_t max_chains_per_pass(rnnwf_handle* h) {
     const size_t per_block = (size_t)h->N * hs_bytes_per_block(h);
-    return std::max<int64_t>(1, (int64_t)(kHsBudget / per_block)) * kChains;
+    return std::max<int64_t>(1, (int64_t)(state_budget_bytes(kHsBudget) / per_block)) * kChains;
 }
 
 MdArgs base_args(rnnwf_handle* h, int64_t ns, const Maps& m) {

@@ -282,7 +282,7 @@ int eloc_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
 
 int64_t max_chains_per_pass(rnnwf_handle* h) {
     const size_t per_block = (size_t)std::max(h->N - 1, 1) * hck_bytes_per_block(h);
-    const int64_t blocks = std::max<int64_t>(1, (int64_t)(kHckBudget / per_block));
+    const int64_t blocks = std::max<int64_t>(1, (int64_t)(state_budget_bytes(kHckBudget) / per_block));
     return blocks * kChains;
 }
 

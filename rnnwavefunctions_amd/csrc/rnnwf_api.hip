@@ -1,5 +1,6 @@
 // rnnwf_api.hip - C ABI (include/rnnwf.h) over the gfx950 kernels: handle life cycle, parameters,
 // pRNN sample / log_prob / TFIM local energies, fused VMC step, timing.
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -62,6 +63,14 @@ static void declare_params(rnnwf_handle* h) {
         declare(h, "wf_dense/kernel", {H, 2});
         declare(h, "wf_dense/bias", {2});
     }
+}
+
+size_t rnnwf::state_budget_bytes(size_t dflt) {
+    if (const char* e = getenv("RNNWF_STATE_BUDGET_MB")) {
+        const long long mb = atoll(e);
+        if (mb > 0) return (size_t)mb << 20;
+    }
+    return dflt;
 }
 
 static int pick_nfull(int H, bool f64, bool mdrnn) {

@@ -354,3 +354,55 @@ def test_stacked_layers_limits_and_facade():
     smp = wf._native.sample(50, seed=111, step=0)
     lp = wf._native.log_prob(smp)
     assert np.allclose(lp, M.prnn_log_probability(prm, smp), rtol=0, atol=1e-4)
+
+
+def test_multi_pass_estimators_equal_the_single_pass(monkeypatch):
+    """Batches larger than the hidden-state budget run in several passes (RNNWF_STATE_BUDGET_MB shrinks the budget so
+    that this happens at test sizes); results must not depend on the pass boundaries."""
+    from rnnwavefunctions_amd import _lib
+    rng = np.random.RandomState(0)
+    N, H, ns = 24, 20, 3000                                   # checkpoints: 23 * 188 * 5 KB = 24 MB
+    prm = trained_like(H, seed=1)
+    for model in (_lib.MODEL_GRU1D, _lib.MODEL_GRU1D_PARITY):
+        wf = make_wf(model, N, H, prm)
+        s = rng.randint(0, 2, (ns, N)).astype(np.int32)
+        lp1 = np.zeros((N + 1) * ns)
+        e1 = wf.tfim_eloc(s, np.ones(N), 1.0, log_probs=lp1)
+        monkeypatch.setenv("RNNWF_STATE_BUDGET_MB", "1")
+        lp2 = np.zeros((N + 1) * ns)
+        e2 = wf.tfim_eloc(s, np.ones(N), 1.0, log_probs=lp2)
+        with pytest.raises(_lib.RnnwfError, match="split the batch"):
+            wf.vmc_step(ns, seed=1, step=0, couplings=np.append(np.ones(N), 1.0))
+        monkeypatch.delenv("RNNWF_STATE_BUDGET_MB")
+        assert np.array_equal(e1, e2) and np.array_equal(lp1, lp2)
+    # 2D MDRNN and the complex RNN take the same route
+    from rnnwavefunctions_amd import params as PP
+    wf = _lib.NativeWavefunction(_lib.MODEL_MDRNN2D, 4, 4, (20,))
+    wf.set_params(PP.init_mdrnn_params(20, seed=3), scope=SCOPE)
+    s2 = rng.randint(0, 2, (2000, 4, 4)).astype(np.int32)
+    e1 = wf.tfim_eloc(s2, np.ones((4, 4)), 2.0)
+    monkeypatch.setenv("RNNWF_STATE_BUDGET_MB", "1")
+    e2 = wf.tfim_eloc(s2, np.ones((4, 4)), 2.0)
+    monkeypatch.delenv("RNNWF_STATE_BUDGET_MB")
+    assert np.array_equal(e1, e2)
+    wfc = _lib.NativeWavefunction(_lib.MODEL_CRNN_U1, 12, 1, (20,))
+    wfc.set_params(trained_like(20, seed=5, heads=("wf_dense_ampl", "wf_dense_phase")), scope=SCOPE)
+    sc = wfc.sample(3000, seed=2, step=0)
+    e1 = wfc.j1j2_eloc(sc, np.ones(12), 0.5 * np.ones(12), np.zeros(12))
+    monkeypatch.setenv("RNNWF_STATE_BUDGET_MB", "1")
+    e2 = wfc.j1j2_eloc(sc, np.ones(12), 0.5 * np.ones(12), np.zeros(12))
+    monkeypatch.delenv("RNNWF_STATE_BUDGET_MB")
+    assert e1[1] == e2[1] and np.allclose(e1[0], e2[0], rtol=1e-6, atol=1e-6)
+
+
+def test_log_prob_beyond_one_device_chunk():
+    """log_probability uploads 2^20 rows per pass; a larger batch must come back in order."""
+    from rnnwavefunctions_amd import _lib
+    N, H = 4, 6
+    prm = trained_like(H, seed=2)
+    wf = make_wf(_lib.MODEL_GRU1D, N, H, prm)
+    cfgs = all_configs(N)                                       # 16 configurations
+    B = (1 << 20) + 4097
+    idx = np.random.RandomState(1).randint(0, 16, B)
+    lp = wf.log_prob(cfgs[idx])
+    assert np.array_equal(lp, wf.log_prob(cfgs)[idx])
