@@ -166,6 +166,7 @@ int rnnwf_vmc_step(rnnwf_handle* h, int64_t numsamples, uint64_t seed, uint64_t 
  *   (Im E_s - mean_energy_im) d Im log psi]; mean_energy_im is ignored for the positive RNNs.
  *   The 2D drivers (2DTFIM_2DRNN/Training2DRNN_2DTFIM.py:163, 2DTFIM_1DRNN/Training1DRNN_2DTFIM.py:160) use the
  *   first cost in float64.  Limits: num_units <= 68 (f32, MDRNN), <= 52 (GRU1D_F64); else RNNWF_ERR_INVALID.
+ *   Stacked layers (GRU1D, len(units) 2..3): one backward pass per layer, top first.
  * rnnwf_get_grad     <- the gradient of one TF variable (same names and shapes as rnnwf_set_param).
  * rnnwf_allreduce_grads: one RCCL all-reduce (sum) over all gradient arrays of the handle.             */
 int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double mean_energy_im, double norm);

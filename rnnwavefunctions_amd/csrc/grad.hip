@@ -3,6 +3,7 @@
 #include <algorithm>
 
 #include "grad_kernels.h"
+#include "ml_grad_kernels.h"
 #include "models.h"
 #include "pack.h"
 
@@ -165,6 +166,207 @@ struct GLaunch {
         }                                                               \
     } while (0)
 
+// ---- stacked layers: one backward pass per layer, top first (ml_grad_kernels.h) ---------------------------------
+template <int NFULL, int NL, int WAVES>
+struct MLGrad {
+    using G0 = GLaunch<float, NFULL, WAVES, 1>;
+    using L0 = GruLayout<float, NFULL, 1>;
+    using U = UpperLayout<NFULL>;
+    using GU = UpperGradLayout<NFULL>;
+    static constexpr size_t DW0 = (size_t)G0::G::PCOLS * G0::G::QCOLS;     // floats
+    static constexpr size_t HEAD = G0::G::HEAD_ROW;
+    static constexpr size_t DWU = (size_t)GU::PCOLS * GU::QCOLS;
+    static constexpr size_t DW_FLOATS = DW0 + HEAD + (NL - 1) * DWU;       // [dW layer 0 | head | dW layer 1 | ...]
+
+    static std::vector<char> pack_upper_bwd(const rnnwf_handle* h, int layer) {
+        const int H = h->H;
+        std::vector<char> img(GU::BWD_BYTES, 0);
+        const std::string pre = "multi_rnn_cell/cell_" + std::to_string(layer) + "/cudnn_compatible_gru_cell/";
+        const auto& Wg = pv(h, pre + "gates/kernel");                         // [H + H, 2H]
+        const auto& Wci = pv(h, pre + "candidate/input_projection/kernel");   // [H, H]
+        const auto& Wch = pv(h, pre + "candidate/hidden_projection/kernel");  // [H, H]
+        for (int side = 0; side < 2; ++side) {                                // 0: H side (-> dh), 1: X side (-> dx)
+            float* A = reinterpret_cast<float*>(img.data() + side * GU::SIDE_BYTES);
+            for (int t = 0; t < GU::NTO; ++t)
+                for (int row = 0; row < 16; ++row) {
+                    const int q = row >> 2, r = row & 3;
+                    if (t == NFULL && r != 0) continue;
+                    const int kout = t < NFULL ? 16 * t + 4 * r + q : 16 * NFULL + q;
+                    if (kout >= H) continue;
+                    const size_t grow = side == 0 ? (size_t)H + kout : (size_t)kout;   // row of the gates kernel
+                    for (int kq = 0; kq < 4; ++kq) {
+                        const int lane = (kq << 4) | row;
+                        for (int kk = 0; kk < GU::KB; ++kk) {
+                            const int g = kk / GU::KT, kt = kk % GU::KT, u = 4 * kt + kq;
+                            if (u >= H) continue;
+                            double w;
+                            if (g == 0) w = Wg[grow * 2 * H + u];
+                            else if (g == 1) w = Wg[grow * 2 * H + H + u];
+                            else w = side == 0 ? Wch[(size_t)kout * H + u] : Wci[(size_t)kout * H + u];
+                            A[(((size_t)t * GU::KBG + kk / 4) * 64 + lane) * 4 + (kk & 3)] = (float)w;
+                        }
+                    }
+                }
+        }
+        return img;
+    }
+
+    static std::vector<char> pack_all(const rnnwf_handle* h) {
+        std::vector<char> img = G0::pack_bwd(h);
+        for (int l = 1; l < NL; ++l) {
+            const std::vector<char> up = pack_upper_bwd(h, l);
+            img.insert(img.end(), up.begin(), up.end());
+        }
+        return img;
+    }
+
+    template <bool TOP>
+    static int upper_pass(rnnwf_handle* h, const UpperGradArgs& a) {
+        static int bpc = 0;
+        const void* fn = (const void*)gru_upper_bwd_kernel<NFULL, WAVES, TOP>;
+        const size_t lds = U::BYTES + GU::BWD_BYTES + (TOP ? GU::HEAD_BYTES : 0);
+        if (lds > 160 * 1024) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: stacked-layer images (%zu B) exceed the 160 KB LDS", lds);
+        if (!bpc) {
+            RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            RNNWF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, WAVES * 64, lds));
+            bpc = std::max(bpc, 1);
+        }
+        const int64_t need = (a.nsb + WAVES - 1) / WAVES;
+        const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
+        gru_upper_bwd_kernel<NFULL, WAVES, TOP><<<grid, WAVES * 64, lds, h->stream>>>(a);
+        RNNWF_HIP(h, hipGetLastError());
+        return 0;
+    }
+
+    static int gemm(rnnwf_handle* h, const float* P, const float* Q, int64_t R, float* dW, bool upper) {
+        int64_t rpb = (R + (int64_t)h->cu_count * 4 - 1) / ((int64_t)h->cu_count * 4);
+        rpb = std::max<int64_t>(64, ((rpb + 3) / 4) * 4);
+        const unsigned gblocks = (unsigned)((R + rpb - 1) / rpb);
+        if (upper) tn_gemm_kernel<float, GU::PCOLS / 16, GU::QCOLS / 16><<<gblocks, 256, 0, h->stream>>>(P, Q, R, rpb, dW);
+        else tn_gemm_kernel<float, G0::G::PCOLS / 16, G0::G::QCOLS / 16><<<gblocks, 256, 0, h->stream>>>(P, Q, R, rpb, dW);
+        RNNWF_HIP(h, hipGetLastError());
+        return 0;
+    }
+
+    static int run(rnnwf_handle* h, double mean_energy, double norm) {
+        const int N = h->N;
+        const int64_t ns = h->last_ns, R = ns * N, nsb = (ns + kChains - 1) / kChains;
+        if (!h->wbwd.p) {
+            const std::vector<char> img = pack_all(h);
+            if (int rc = ensure(h, h->wbwd, img.size())) return rc;
+            RNNWF_HIP(h, hipMemcpyAsync(h->wbwd.p, img.data(), img.size(), hipMemcpyHostToDevice, h->stream));
+            RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+        }
+        if (int rc = ensure(h, h->gradP, (size_t)R * GU::PCOLS * 4)) return rc;
+        if (int rc = ensure(h, h->gradQ, (size_t)R * GU::QCOLS * 4)) return rc;
+        if (int rc = ensure(h, h->gradW, (DW_FLOATS + HEAD) * 4)) return rc;     // + a scratch head row for layer 0's pass
+        const size_t dx_bytes = (size_t)N * nsb * L0::KT * 64 * 4;
+        for (int i = 0; i < (NL > 2 ? 2 : 1); ++i) if (int rc = ensure(h, h->gradDX[i], dx_bytes)) return rc;
+        RNNWF_HIP(h, hipMemsetAsync(h->gradW.p, 0, (DW_FLOATS + HEAD) * 4, h->stream));
+        float* dW = (float*)h->gradW.p;
+        const char* bwd = (const char*)h->wbwd.p;
+        const float* dh_in = nullptr;
+        for (int l = NL - 1; l >= 1; --l) {
+            UpperGradArgs a{};
+            a.wup = (const char*)h->wimg.p + L0::BYTES + (size_t)(l - 1) * U::BYTES;
+            a.wbwd = bwd + G0::G::BWD_BYTES + (size_t)(l - 1) * GU::BWD_BYTES;
+            a.whead = (const char*)h->wimg.p + L0::OFF_WD;
+            a.N = N; a.layer = l; a.hck_nl = NL;
+            a.ns = ns; a.nsb = nsb;
+            a.bits = (const uint32_t*)h->bits.p;
+            a.hck = (const float*)h->hck.p;
+            a.eloc = (const double*)h->eloc.p;
+            a.mean_e = mean_energy;
+            a.inv_norm = 1.0 / norm;
+            a.dh_in = dh_in;
+            a.dx_out = (float*)h->gradDX[(NL - 1 - l) & 1].p;
+            a.P = (float*)h->gradP.p;
+            a.Q = (float*)h->gradQ.p;
+            a.head_grad = dW + DW0;
+            if (l == NL - 1) { if (int rc = upper_pass<true>(h, a)) return rc; }
+            else { if (int rc = upper_pass<false>(h, a)) return rc; }
+            if (int rc = gemm(h, a.P, a.Q, R, dW + DW0 + HEAD + (size_t)(l - 1) * DWU, true)) return rc;
+            dh_in = a.dx_out;
+        }
+        GradArgs a{};
+        a.wimg = h->wimg.p;
+        a.wbwd = h->wbwd.p;
+        a.N = N; a.ns = ns; a.nsb = nsb;
+        a.bits = (const uint32_t*)h->bits.p;
+        a.hck = h->hck.p;
+        a.eloc = (const double*)h->eloc.p;
+        a.mean_e = mean_energy;
+        a.inv_norm = 1.0 / norm;
+        a.P = h->gradP.p;
+        a.Q = h->gradQ.p;
+        a.head_grad = dW + DW_FLOATS;          // scratch row: layer 0 has no head term here (its adds are zeros)
+        a.dh_in = dh_in;
+        a.hck_nl = NL;
+        if (int rc = G0::run(h, a, R, dW)) return rc;
+        std::vector<float> host(DW_FLOATS);
+        RNNWF_HIP(h, hipMemcpyAsync(host.data(), h->gradW.p, DW_FLOATS * 4, hipMemcpyDeviceToHost, h->stream));
+        RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+        G0::unpack(h, host.data(), DW0);                       // layer 0 + head (written by the top layer's pass)
+        for (int l = 1; l < NL; ++l) unpack_upper(h, host.data() + DW0 + HEAD + (size_t)(l - 1) * DWU, l);
+        return RNNWF_OK;
+    }
+
+    static void unpack_upper(rnnwf_handle* h, const float* dW, int layer) {
+        const int H = h->H;
+        const int NT = GU::NT;
+        auto col_of_unit = [&](int k) { return k < 16 * NFULL ? 16 * (k / 16) + 4 * (k % 4) + (k % 16) / 4 : 16 * NFULL + 4 * (k - 16 * NFULL); };
+        const int hoff = 16 * GU::NTO, onecol = hoff + 16 * NFULL + 1;
+        auto at = [&](int prow, int col) { return (double)dW[(size_t)prow * GU::QCOLS + col]; };
+        const std::string pre = "multi_rnn_cell/cell_" + std::to_string(layer) + "/cudnn_compatible_gru_cell/";
+        auto& gWg = h->grads[pre + "gates/kernel"];
+        auto& gbg = h->grads[pre + "gates/bias"];
+        auto& gWci = h->grads[pre + "candidate/input_projection/kernel"];
+        auto& gbci = h->grads[pre + "candidate/input_projection/bias"];
+        auto& gWch = h->grads[pre + "candidate/hidden_projection/kernel"];
+        auto& gbch = h->grads[pre + "candidate/hidden_projection/bias"];
+        gWg.assign((size_t)2 * H * 2 * H, 0.0); gbg.assign(2 * H, 0.0);
+        gWci.assign((size_t)H * H, 0.0); gbci.assign(H, 0.0);
+        gWch.assign((size_t)H * H, 0.0); gbch.assign(H, 0.0);
+        for (int u = 0; u < H; ++u) {
+            const int m = u / 16, r = (u % 16) / 4, q = u % 4;
+            const bool full = u < 16 * NFULL;
+            const int uq = u - 16 * NFULL;
+            int prow[3];
+            for (int g = 0; g < 3; ++g) prow[g] = full ? (g * NFULL + m) * 16 + 4 * q + r : (NT - 1) * 16 + 4 * uq + g;
+            const int prow_y = full ? (NT + m) * 16 + 4 * q + r : (NT + NFULL) * 16 + 4 * uq;
+            for (int k = 0; k < H; ++k) {
+                const int cx = col_of_unit(k), ch = hoff + col_of_unit(k);
+                gWg[(size_t)k * 2 * H + u] = at(prow[0], cx);
+                gWg[(size_t)k * 2 * H + H + u] = at(prow[1], cx);
+                gWg[(size_t)(H + k) * 2 * H + u] = at(prow[0], ch);
+                gWg[(size_t)(H + k) * 2 * H + H + u] = at(prow[1], ch);
+                gWci[(size_t)k * H + u] = at(prow_y, cx);
+                gWch[(size_t)k * H + u] = at(prow[2], ch);
+            }
+            gbg[u] = at(prow[0], onecol);
+            gbg[H + u] = at(prow[1], onecol);
+            gbch[u] = at(prow[2], onecol);
+            gbci[u] = at(prow_y, onecol);
+        }
+    }
+};
+
+#define MLGRAD_DISPATCH(h, EXPR)                                        \
+    do {                                                                \
+        if ((h)->NL == 2) {                                             \
+            switch ((h)->NFULL) {                                       \
+                case 1: { using K = MLGrad<1, 2, 4>; EXPR; }            \
+                case 2: { using K = MLGrad<2, 2, 4>; EXPR; }            \
+                case 3: { using K = MLGrad<3, 2, 4>; EXPR; }            \
+            }                                                           \
+        } else if ((h)->NL == 3) {                                      \
+            switch ((h)->NFULL) {                                       \
+                case 1: { using K = MLGrad<1, 3, 4>; EXPR; }            \
+                case 2: { using K = MLGrad<2, 3, 4>; EXPR; }            \
+            }                                                           \
+        }                                                               \
+    } while (0)
+
 }  // namespace
 
 extern "C" int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double mean_energy_im, double norm) {
@@ -173,7 +375,15 @@ extern "C" int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double me
     if (h->model == RNNWF_MODEL_MDRNN2D) return mdrnn_vmc_gradient(h, mean_energy, norm);
     if (h->model != RNNWF_MODEL_GRU1D && h->model != RNNWF_MODEL_CRNN_U1 && h->model != RNNWF_MODEL_GRU1D_F64)
         return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: not implemented for the parity-symmetrised GRU RNN");
-    if (h->NL != 1) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: stacked layers (len(units) > 1) are forward-only so far");
+    if (h->NL != 1) {
+        if (h->model != RNNWF_MODEL_GRU1D) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: not implemented for the parity-symmetrised GRU RNN");
+        if (h->last_ns <= 0 || !h->last_has_ckpt)
+            return h->fail(RNNWF_ERR_STATE, "rnnwf_vmc_gradient: call rnnwf_vmc_step first (its samples, states and E_loc are reused)");
+        if (!(norm > 0)) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: norm must be positive");
+        RNNWF_HIP(h, hipSetDevice(h->cfg.device));
+        MLGRAD_DISPATCH(h, return K::run(h, mean_energy, norm));
+        return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: no stacked-layer kernel for this width");
+    }
     const bool cplx = h->model == RNNWF_MODEL_CRNN_U1;
     const bool f64 = h->model == RNNWF_MODEL_GRU1D_F64;
     const size_t es = f64 ? 8 : 4;

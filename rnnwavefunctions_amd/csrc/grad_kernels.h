@@ -44,6 +44,10 @@ struct GradArgs {
     void* P;                   // [N*ns][PCOLS] T
     void* Q;                   // [N*ns][QCOLS] T
     void* head_grad;           // [NOUT][HEAD_ROW] T, zeroed before the launch
+    // stacked layers (f32, NOUT = 1): this kernel is then the LAST pass (layer 0); dL/dh of every site arrives from
+    // the layer above instead of from the head, and hck holds hck_nl layers per (site, block)
+    const float* dh_in;        // [N][nsb][KT][64] or nullptr
+    int32_t hck_nl;            // layers per checkpoint entry (0 or 1: single layer)
 };
 
 // NOUT = 1: positive RNN, L = sum_s w_s log P(s).
@@ -72,6 +76,7 @@ __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
     const int64_t nw = (int64_t)gridDim.x * WAVES;
     const int N = a.N;
     const T* wd = reinterpret_cast<const T*>(lds + C::L::OFF_WD) + q * C::L::WD_Q;
+    const int hck_nl = a.hck_nl > 1 ? a.hck_nl : 1;
     for (int64_t sb = gw; sb < a.nsb; sb += nw) {
         const int64_t s = sb * kChains + c;
         const bool valid = s < a.ns;
@@ -103,7 +108,7 @@ __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
         for (int n = N - 1; n >= 0; --n) {
             T h[KT], hn[KT], rg[KT], ug[KT], cc[KT], qv[KT];
             if (n > 0) {
-                const T* src = reinterpret_cast<const T*>(a.hck) + (((int64_t)(n - 1) * a.nsb + sb) * KT) * 64 + lane;
+                const T* src = reinterpret_cast<const T*>(a.hck) + (((int64_t)(n - 1) * a.nsb + sb) * hck_nl * KT) * 64 + lane;
 #pragma unroll
                 for (int k = 0; k < KT; ++k) h[k] = src[k * 64];
             } else {
@@ -119,7 +124,7 @@ __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
             T g[NOUT];
             const T p1 = T(1) - prob0(z[0]);
             if constexpr (NOUT == 1) {
-                g[0] = w * ((T)sig - p1);                           // d log p(sig) / d(z1 - z0) = sig - p1
+                g[0] = a.dh_in ? T(0) : w * ((T)sig - p1);          // d log p(sig) / d(z1 - z0) = sig - p1
             } else {
                 num_up -= sig;                                          // ups among sites < n
                 bool both = true;                                       // mask: a value that is forced has amplitude 1
@@ -141,6 +146,8 @@ __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
                 T d = dh[k];                                        // total dL/dh_n of this lane's unit
+                if constexpr (NOUT == 1 && sizeof(T) == 4)
+                    if (a.dh_in) d += a.dh_in[(((int64_t)n * a.nsb + sb) * KT + k) * 64 + lane];
 #pragma unroll
                 for (int o = 0; o < NOUT; ++o) {
                     hg[o][k] += g[o] * hn[k];

@@ -254,6 +254,43 @@ struct UpperCore {
         for (int t = 0; t < NT; ++t) acc[dst(t)] = F::mfma(ar[t * 64], v[KT - 1], acc[dst(t)]);
     }
 
+    // forward step that keeps this lane's gate values for the backward pass (q = h Wch + bch un-scaled)
+    static __device__ __forceinline__ void step_keep(const char* lds, const float (&x)[KT], const float (&h)[KT],
+                                                     float (&hn)[KT], float (&rg)[KT], float (&ug)[KT], float (&cc)[KT],
+                                                     float (&qv)[KT], int lane) {
+        const int q = lane >> 4;
+        asm volatile("" ::: "memory");
+        V4 acc[NT2];
+        {
+            const char* b = lds + U::OFF_B + (size_t)q * 16;
+#pragma unroll
+            for (int t = 0; t < NT2; ++t) acc[t] = *reinterpret_cast<const V4*>(b + (size_t)t * 64);
+        }
+        block<true>(lds, x, acc, lane);
+        asm volatile("" ::: "memory");
+        block<false>(lds, h, acc, lane);
+        const float inv_cs = (float)(1.0 / A::kCandScale);
+#pragma unroll
+        for (int m = 0; m < NFULL; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 4 * m + r;
+                rg[k] = A::sigmoid_scaled(acc[m][r]);
+                ug[k] = A::sigmoid_scaled(acc[NFULL + m][r]);
+                qv[k] = acc[2 * NFULL + m][r] * inv_cs;
+                cc[k] = A::tanh_scaled(acc[3 * NFULL + m][r] + rg[k] * acc[2 * NFULL + m][r]);
+                hn[k] = cc[k] + ug[k] * (h[k] - cc[k]);
+            }
+        {
+            const V4 a = acc[NT2 - 1];
+            rg[KT - 1] = A::sigmoid_scaled(a[0]);
+            ug[KT - 1] = A::sigmoid_scaled(a[1]);
+            qv[KT - 1] = a[2] * inv_cs;
+            cc[KT - 1] = A::tanh_scaled(a[3] + rg[KT - 1] * a[2]);
+            hn[KT - 1] = cc[KT - 1] + ug[KT - 1] * (h[KT - 1] - cc[KT - 1]);
+        }
+    }
+
     static __device__ __forceinline__ void step(const char* lds, const float (&x)[KT], float (&h)[KT], int lane) {
         const int q = lane >> 4;
         asm volatile("" ::: "memory");

@@ -1,0 +1,202 @@
+// ml_grad_kernels.h - back-propagation through a stacked GRU layer above the first (f32).
+//
+// The gradient of a stack is taken layer by layer, top first: the pass of layer l walks the sites N-1 .. 0, re-computes
+// the layer's gates from the stored states (x = new state of layer l-1 at this site, h = own state of the previous
+// site; the base pass stored every layer's state of every site), and back-propagates
+//     dL/dh_{n-1} = u * d + [Wg_h(r) Wg_h(u) Wch] [da_r; da_u; dq]      (carried in registers, as in gru_bwd_kernel)
+//     dL/dx_n     =         [Wg_x(r) Wg_x(u) Wci] [da_r; da_u; dy]      (written to HBM: the dh_in of layer l-1's pass)
+// with both products on the f32 MFMA.  dL/dh_n comes from the head (top layer) or from the pass of the layer above.
+// Weight gradients are P^T Q with the same P rows as the first layer and Q = [x | h_{n-1}, 1].
+// One pass needs only this layer's images in LDS: forward 67 KB + two backward operands 80 KB at 50 units.
+#pragma once
+#include "grad_kernels.h"
+
+namespace rnnwf {
+
+template <int NFULL>
+struct UpperGradLayout {
+    static constexpr int KT = 4 * NFULL + 1;
+    static constexpr int NT = 3 * NFULL + 1;
+    static constexpr int NTO = NFULL + 1;
+    static constexpr int PCOLS = 16 * (NT + NTO);         // as GradLayout: [gate rows in image order | dy]
+    static constexpr int QCOLS = 32 * NTO;                // [x | h_{n-1} with the constant 1 in a spare slot]
+    static constexpr int KB = 3 * KT;
+    static constexpr int KBG = (KB + 3) / 4;
+    static constexpr size_t SIDE_BYTES = (size_t)NTO * KBG * 64 * 16;    // [NTO][KBG][64] float4
+    static constexpr size_t BWD_BYTES = 2 * SIDE_BYTES;                  // H side (-> dh), X side (-> dx)
+    static constexpr int WD_Q = ((KT + 3) / 4) * 4;                      // GruLayout<float, NFULL, 1>::WD_Q
+    static constexpr size_t HEAD_BYTES = ((size_t)(4 * WD_Q + 8) * 4 + 15) / 16 * 16;   // [4 q][WD_Q] + bias
+};
+
+struct UpperGradArgs {
+    const void* wup;           // forward image of this layer (UpperLayout)
+    const void* wbwd;          // UpperGradLayout::BWD_BYTES
+    const void* whead;         // OFF_WD section of the first layer's image (head weights), top layer only
+    int32_t N, layer, hck_nl;
+    int64_t ns, nsb;
+    const uint32_t* bits;
+    const float* hck;          // [N][nsb][NL][KT][64]
+    const double* eloc;
+    double mean_e, inv_norm;
+    const float* dh_in;        // [N][nsb][KT][64] from the layer above (nullptr: top layer, head)
+    float* dx_out;             // [N][nsb][KT][64]
+    float* P;
+    float* Q;
+    float* head_grad;          // [HEAD_ROW] (top layer)
+};
+
+template <int NFULL, int WAVES, bool TOP>
+__global__ void __launch_bounds__(WAVES * 64) gru_upper_bwd_kernel(UpperGradArgs a) {
+    using CU = UpperCore<NFULL>;
+    using G = UpperGradLayout<NFULL>;
+    using V4 = typename CU::V4;
+    constexpr int KT = CU::KT, NT = G::NT;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    {
+        auto copy = [&](char* dst_, const void* src_, size_t bytes) {
+            const uint4* src = reinterpret_cast<const uint4*>(src_);
+            uint4* dst = reinterpret_cast<uint4*>(dst_);
+            for (int i = threadIdx.x; i < (int)(bytes / 16); i += blockDim.x) dst[i] = src[i];
+        };
+        copy(lds, a.wup, CU::U::BYTES);
+        copy(lds + CU::U::BYTES, a.wbwd, G::BWD_BYTES);
+        if (TOP) copy(lds + CU::U::BYTES + G::BWD_BYTES, a.whead, G::HEAD_BYTES);
+        __syncthreads();
+    }
+    const char* lbh = lds + CU::U::BYTES;
+    const char* lbx = lbh + G::SIDE_BYTES;
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int64_t gw = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * WAVES;
+    const int N = a.N;
+    const float* wd = reinterpret_cast<const float*>(lds + CU::U::BYTES + G::BWD_BYTES) + q * G::WD_Q;
+    const float* bd = reinterpret_cast<const float*>(lds + CU::U::BYTES + G::BWD_BYTES) + 4 * G::WD_Q;
+    float hg[KT], gb = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) hg[k] = 0.0f;
+    for (int64_t sb = gw; sb < a.nsb; sb += nw) {
+        const int64_t s = sb * kChains + c;
+        const bool valid = s < a.ns;
+        const int64_t sc = valid ? s : a.ns - 1;
+        const float w = (TOP && valid) ? (float)((a.eloc[sc] - a.mean_e) * a.inv_norm) : 0.0f;
+        float dh[KT];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) dh[k] = 0.0f;
+        for (int n = N - 1; n >= 0; --n) {
+            float x[KT], h[KT], hn[KT], rg[KT], ug[KT], cc[KT], qv[KT];
+            {
+                const float* src = a.hck + ((((int64_t)n * a.nsb + sb) * a.hck_nl + a.layer - 1) * KT) * 64 + lane;
+#pragma unroll
+                for (int k = 0; k < KT; ++k) x[k] = src[k * 64];
+            }
+            if (n > 0) {
+                const float* src = a.hck + ((((int64_t)(n - 1) * a.nsb + sb) * a.hck_nl + a.layer) * KT) * 64 + lane;
+#pragma unroll
+                for (int k = 0; k < KT; ++k) h[k] = src[k * 64];
+            } else {
+#pragma unroll
+                for (int k = 0; k < KT; ++k) h[k] = 0.0f;
+            }
+            CU::step_keep(lds, x, h, hn, rg, ug, cc, qv, lane);
+            float g = 0.0f;
+            if (TOP) {
+                asm volatile("" ::: "memory");
+                float z = 0.0f;
+#pragma unroll
+                for (int k = 0; k < KT; ++k) z += hn[k] * wd[k];
+                z += __shfl_xor(z, 16); z += __shfl_xor(z, 32); z += bd[0];
+                const int sig = (int)((a.bits[(int64_t)(n >> 5) * a.ns + sc] >> (n & 31)) & 1);
+                g = w * ((float)sig - (1.0f - prob0(z)));        // d log p(sig) / d(z1 - z0) = sig - p1
+                gb += g;
+            }
+            float dpH[4 * G::KBG], dpX[4 * G::KBG];
+            float dy[KT];
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                float d = dh[k];
+                if (TOP) {
+                    hg[k] += g * hn[k];
+                    d += g * wd[k];
+                } else {
+                    d += a.dh_in[(((int64_t)n * a.nsb + sb) * KT + k) * 64 + lane];
+                }
+                const float du = d * (h[k] - cc[k]);
+                const float dc = d * (1.0f - ug[k]);
+                dh[k] = d * ug[k];
+                dy[k] = dc * (1.0f - cc[k] * cc[k]);
+                dpH[k] = dpX[k] = dy[k] * qv[k] * rg[k] * (1.0f - rg[k]);     // d a_r
+                dpH[KT + k] = dpX[KT + k] = du * ug[k] * (1.0f - ug[k]);     // d a_u
+                dpH[2 * KT + k] = dy[k] * rg[k];                             // d q
+                dpX[2 * KT + k] = dy[k];                                     // d y
+            }
+#pragma unroll
+            for (int k = G::KB; k < 4 * G::KBG; ++k) dpH[k] = dpX[k] = 0.0f;
+            if (valid) {
+                float* prow = a.P + ((int64_t)n * a.ns + s) * G::PCOLS + 4 * q;
+#pragma unroll
+                for (int m = 0; m < NFULL; ++m) {
+#pragma unroll
+                    for (int gt = 0; gt < 3; ++gt)
+                        *reinterpret_cast<V4*>(prow + (gt * NFULL + m) * 16) =
+                            V4{dpH[gt * KT + 4 * m], dpH[gt * KT + 4 * m + 1], dpH[gt * KT + 4 * m + 2], dpH[gt * KT + 4 * m + 3]};
+                    *reinterpret_cast<V4*>(prow + (NT + m) * 16) = V4{dy[4 * m], dy[4 * m + 1], dy[4 * m + 2], dy[4 * m + 3]};
+                }
+                *reinterpret_cast<V4*>(prow + (NT - 1) * 16) = V4{dpH[KT - 1], dpH[2 * KT - 1], dpH[3 * KT - 1], 0.0f};
+                *reinterpret_cast<V4*>(prow + (NT + NFULL) * 16) = V4{dy[KT - 1], 0.0f, 0.0f, 0.0f};
+                float* qrow = a.Q + ((int64_t)n * a.ns + s) * G::QCOLS + 4 * q;
+#pragma unroll
+                for (int m = 0; m < NFULL; ++m) {
+                    *reinterpret_cast<V4*>(qrow + m * 16) = V4{x[4 * m], x[4 * m + 1], x[4 * m + 2], x[4 * m + 3]};
+                    *reinterpret_cast<V4*>(qrow + (G::NTO + m) * 16) = V4{h[4 * m], h[4 * m + 1], h[4 * m + 2], h[4 * m + 3]};
+                }
+                *reinterpret_cast<V4*>(qrow + NFULL * 16) = V4{x[KT - 1], 0.0f, 0.0f, 0.0f};
+                *reinterpret_cast<V4*>(qrow + (G::NTO + NFULL) * 16) = V4{h[KT - 1], q == 0 ? 1.0f : 0.0f, 0.0f, 0.0f};
+            }
+            V4 accH[G::NTO], accX[G::NTO];
+#pragma unroll
+            for (int t = 0; t < G::NTO; ++t) accH[t] = accX[t] = V4{0.f, 0.f, 0.f, 0.f};
+            asm volatile("" ::: "memory");
+            const V4* abh = reinterpret_cast<const V4*>(lbh) + lane;
+            const V4* abx = reinterpret_cast<const V4*>(lbx) + lane;
+#pragma unroll
+            for (int kg = 0; kg < G::KBG; ++kg) {
+                V4 afh[G::NTO], afx[G::NTO];
+#pragma unroll
+                for (int t = 0; t < G::NTO; ++t) {
+                    afh[t] = abh[(t * G::KBG + kg) * 64];
+                    afx[t] = abx[(t * G::KBG + kg) * 64];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < G::NTO; ++t) {
+                        accH[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(afh[t][j], dpH[4 * kg + j], accH[t], 0, 0, 0);
+                        accX[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(afx[t][j], dpX[4 * kg + j], accX[t], 0, 0, 0);
+                    }
+            }
+            float* dxo = a.dx_out + (((int64_t)n * a.nsb + sb) * KT) * 64 + lane;
+#pragma unroll
+            for (int m = 0; m < NFULL; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dh[4 * m + r] += accH[m][r];
+                    dxo[(4 * m + r) * 64] = accX[m][r];
+                }
+            dh[KT - 1] += accH[NFULL][0];
+            dxo[(KT - 1) * 64] = accX[NFULL][0];
+        }
+    }
+    if (TOP) {
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            float v = hg[k];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            if (c == 0) atomicAdd(&a.head_grad[4 * k + q], v);
+        }
+        float v = gb;
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+        if (c == 0 && q == 0) atomicAdd(&a.head_grad[4 * KT], v);
+    }
+}
+
+}  // namespace rnnwf

@@ -4,7 +4,8 @@
 // Same decomposition as gru_kernels.h.  Every layer's state stays in registers in B-fragment order; the new
 // state of layer l is directly the X operand of layer l+1 (gru_core.h, UpperCore), the head reads the top layer.
 // LDS image: [GruLayout<float, NFULL, 1> | UpperLayout<NFULL> x (NL-1)].
-//   hck [N-1][nsb][NL][KT][64] f32   states of all layers after site n
+//   hck [N][nsb][NL][KT][64] f32   states of all layers after site n (all N sites: the layer-wise gradient of
+//                                  ml_grad_kernels.h needs the last site's lower-layer states too)
 #pragma once
 #include "gru_kernels.h"
 
@@ -77,7 +78,7 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_ml_base_kernel(PrnnArgs a) {
                 if (valid && q == 0) a.lpq[row * a.ns + s] = cum + (double)(sig ? lp0 : lp1);
             }
             cum += lsel;
-            if (a.hck && n < N - 1) {
+            if (a.hck) {
                 float* dst = reinterpret_cast<float*>(a.hck) + (((int64_t)n * a.nsb + sb) * NL * KT) * 64 + lane;
 #pragma unroll
                 for (int l = 0; l < NL; ++l)

@@ -223,7 +223,7 @@ int eloc_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
     const int N = h->N;
     const int64_t nsb = (ns + kChains - 1) / kChains;
     const bool parity = h->model == RNNWF_MODEL_GRU1D_PARITY;
-    const size_t hck_bytes = (size_t)std::max(N - 1, 1) * nsb * hck_bytes_per_block(h);
+    const size_t hck_bytes = (size_t)(h->NL > 1 ? N : std::max(N - 1, 1)) * nsb * hck_bytes_per_block(h);
     if (int rc = ensure(h, h->lpq, (size_t)(N + 1) * ns * 8)) return rc;
     if (int rc = ensure(h, h->eloc, (size_t)ns * 8)) return rc;
     if (int rc = ensure(h, h->hck, hck_bytes)) return rc;    // always: the gradient pass reuses the states
@@ -281,7 +281,7 @@ int eloc_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
 }
 
 int64_t max_chains_per_pass(rnnwf_handle* h) {
-    const size_t per_block = (size_t)std::max(h->N - 1, 1) * hck_bytes_per_block(h);
+    const size_t per_block = (size_t)(h->NL > 1 ? h->N : std::max(h->N - 1, 1)) * hck_bytes_per_block(h);
     const int64_t blocks = std::max<int64_t>(1, (int64_t)(state_budget_bytes(kHckBudget) / per_block));
     return blocks * kChains;
 }

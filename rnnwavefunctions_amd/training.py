@@ -108,8 +108,8 @@ def run_1DTFIM(numsteps=10 ** 4, systemsize=20, num_units=50, Bx=1, num_layers=1
     """Train the 1D pRNN wave function on the open transverse-field Ising chain; returns (meanEnergy, varEnergy)
     lists with one entry per iteration, as the reference's run_1DTFIM.  `comm` (distributed.ShardComm) shards the
     batch over one process per GPU."""
-    if num_layers != 1:
-        raise ValueError("training is implemented for num_layers = 1 (the reference's run scripts); stacked layers are forward-only")
+    if not 1 <= num_layers <= 3:
+        raise ValueError("num_layers must be 1..3 (stacked layers: num_units <= 52 for 2, <= 36 for 3)")
     N = systemsize
     scope = "RNNwavefunction"
     Jz = +np.ones(N)

@@ -330,8 +330,6 @@ def test_stacked_layers_sampling_vmc_step_and_parity_model():
     assert np.array_equal(out["samples"], s)
     assert np.allclose(out["eloc"], wf.tfim_eloc(s, np.ones(N), 1.0), rtol=1e-12)
     assert wf.engine_name() == "f32mfma"                            # no bf16x3 image for stacked layers
-    with pytest.raises(ValueError, match="forward-only"):
-        wf.vmc_gradient(0.0, ns, {"wf_dense/bias": (2,)})
     wfp = make_stacked(_lib.MODEL_GRU1D_PARITY, N, H, L, prm)
     sp = s[:64].astype(np.int32)
     ref = M.prnn_paritysym_log_probability(prm, sp)

@@ -275,3 +275,32 @@ def test_two_process_sharded_training_reproduces_the_single_process_run(tmp_path
     assert np.allclose(meanE[:6], r[0]["meanE"][:6], atol=2e-3)           # same trajectory while no draw sits on a tie
     ed = -12.38148999965476
     assert abs(r[0]["meanE"][-50:].mean() - ed) < 0.04
+
+
+# ---- stacked layers: gradient layer by layer, top first ---------------------------------------------------------
+
+@pytest.mark.parametrize("N,H,L,ns", [(6, 6, 2, 64), (8, 20, 2, 48), (7, 50, 2, 32), (6, 10, 3, 40), (5, 36, 3, 24)])
+def test_stacked_gradient_matches_finite_differences_of_the_oracle(N, H, L, ns):
+    from rnnwavefunctions_amd import _lib
+    from rnnwavefunctions_amd.training import cost_gradient
+    prm = P.randomize_biases(P.scale_kernels(P.init_gru_params([H] * L, seed=H + L), 1.5), H + 1)
+    wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D, N, 1, (H,) * L)
+    wf.set_params(prm, scope=SCOPE)
+    out = wf.vmc_step(ns, seed=3, step=0, couplings=np.append(np.ones(N), 1.0), want_samples=True, want_eloc=True)
+    s, e = out["samples"], out["eloc"]
+    grads = cost_gradient(wf, prm, SCOPE, e.mean(), ns)
+    assert set(grads) == set(prm)
+    prm64 = {k: v.astype(np.float64) for k, v in prm.items()}
+    worst = _fd_check(grads, prm64, lambda: oracle_cost(prm64, s, e), n_per_tensor=8, eps=1e-5)
+    print("stacked L=%d N=%d H=%d: max |grad - FD| / max|grad| = %.2e" % (L, N, H, worst))
+    assert worst < 2e-3
+
+
+def test_run_1dtfim_with_two_layers_reaches_the_ground_state():
+    from rnnwavefunctions_amd.TFIM1D.TrainingRNN_1DTFIM import run_1DTFIM
+    meanE, varE = run_1DTFIM(numsteps=500, systemsize=10, num_units=10, Bx=1, num_layers=2, numsamples=200,
+                             learningrate=5e-3, seed=111, verbose=False)
+    ed = -12.38148999965476
+    final = np.mean(meanE[-50:])
+    print("run_1DTFIM 2 layers N=10: E(first)=%.4f  last-50 mean=%.5f (ED %.5f) var=%.4f" % (meanE[0], final, ed, np.mean(varE[-50:])))
+    assert final > ed - 0.02 and abs(final - ed) < 0.04
