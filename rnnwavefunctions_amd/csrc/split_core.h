@@ -125,6 +125,8 @@ struct SplitCore {
             const float cc = Act<float>::tanh_scaled(xc[e] + rg * ac);
             h[e] = cc + ug * (h[e] - cc);
         };
+        // (A pair-wise variant of `gate` on v_pk_add_f32 / v_pk_fma_f32 cut the VALU instructions of a wave-step from
+        //  520 to 459 and changed nothing: flip kernel 3.16 vs 3.15 ms at config 2, more s_nop padding - not kept.)
         // (weight part, state part), smallest products first.  The A fragments of k-step k+1 are read from LDS while
         // k-step k's MFMAs run (two register sets); the compiler barrier keeps later reads from being hoisted too
         // (120 fragment quads in flight would cost all the occupancy).  Two passes over the k-steps: first the mixed
