@@ -275,10 +275,13 @@ int rnnwf::crnn_j1j2_eloc(rnnwf_handle* h, const int32_t* samples, int64_t ns, c
                           const double* Bz, int periodic, int marshall, float* eloc, int64_t* ncon) {
     const int N = h->N;
     h->last_ns = 0;
-    if (int rc = ensure(h, h->coupl, (size_t)3 * N * 8)) return rc;
-    RNNWF_HIP(h, hipMemcpyAsync(h->coupl.p, J1, (size_t)N * 8, hipMemcpyHostToDevice, h->stream));
-    RNNWF_HIP(h, hipMemcpyAsync((double*)h->coupl.p + N, J2, (size_t)N * 8, hipMemcpyHostToDevice, h->stream));
-    RNNWF_HIP(h, hipMemcpyAsync((double*)h->coupl.p + 2 * N, Bz, (size_t)N * 8, hipMemcpyHostToDevice, h->stream));
+    {
+        std::vector<double> c((size_t)3 * N);
+        std::copy(J1, J1 + N, c.begin());
+        std::copy(J2, J2 + N, c.begin() + N);
+        std::copy(Bz, Bz + N, c.begin() + 2 * N);
+        if (int rc = upload_couplings(h, c.data(), c.size())) return rc;
+    }
     const int64_t chunk = max_chains_per_pass(h);
     int64_t total = 0;
     for (int64_t off = 0; off < ns; off += chunk) {
@@ -301,8 +304,7 @@ int rnnwf::crnn_vmc_step(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t st
         return h->fail(RNNWF_ERR_NOMEM, "rnnwf_vmc_step: %lld samples exceed the checkpoint budget; split the batch",
                        (long long)ns);
     if (int rc = ensure(h, h->bits, (size_t)W * ns * 4)) return rc;
-    if (int rc = ensure(h, h->coupl, (size_t)3 * N * 8)) return rc;
-    RNNWF_HIP(h, hipMemcpyAsync(h->coupl.p, couplings, (size_t)3 * N * 8, hipMemcpyHostToDevice, h->stream));
+    if (int rc = upload_couplings(h, couplings, (size_t)3 * N)) return rc;
     const int periodic = couplings[3 * N] != 0.0, marshall = couplings[3 * N + 1] != 0.0;
     if (int rc = j1j2_on_device(h, ns, true, seed, step, offset, (const double*)h->coupl.p, periodic, marshall)) return rc;
     if (out_samples) if (int rc = unpack_and_download(h, h->bits, ns, out_samples, nullptr)) return rc;

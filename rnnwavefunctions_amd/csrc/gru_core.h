@@ -76,17 +76,19 @@ struct GruCore {
     // h[kt] of lane (c, q) holds unit 4 kt + q of chain c.  sig: input spin of this step (-1: zero vector).
     // `ablate` (diagnostics, RNNWF_ABLATE): 1 skips the MFMAs, 2 the gate arithmetic - used to measure that on
     // gfx950 f32 MFMA time and VALU time ADD (no overlap across the waves of a SIMD): see DESIGN.md section 6.
+    // BIAS_LAST: the bias / one-hot-input rows are added AFTER the products (base pass: its cooperative variant,
+    // prnn_base_coop_kernel, starts the products before the input spin is known and must agree bit for bit).
+    template <bool BIAS_LAST = false>
     static __device__ __forceinline__ void step(const char* lds, int sig, T (&h)[KT], int lane, int ablate = 0) {
         const int q = lane >> 4;
         // The weight image never changes, so the compiler would hoist all ~NT*KT fragment loads out of
         // the site loop and pin them in registers (1 wave/SIMD).  Re-read them from LDS every step.
         asm volatile("" ::: "memory");
         V4 acc[NT];
-        {
-            const char* b = lds + L::OFF_BINIT + (size_t)(sig + 1) * L::SZ_BINIT_VARIANT + (size_t)q * 4 * sizeof(T);
+        const char* binit = lds + L::OFF_BINIT + (size_t)(sig + 1) * L::SZ_BINIT_VARIANT + (size_t)q * 4 * sizeof(T);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = *reinterpret_cast<const V4*>(b + (size_t)t * 16 * sizeof(T));
-        }
+        for (int t = 0; t < NT; ++t)
+            acc[t] = BIAS_LAST ? V4{T(0), T(0), T(0), T(0)} : *reinterpret_cast<const V4*>(binit + (size_t)t * 16 * sizeof(T));
         const VA* av = reinterpret_cast<const VA*>(lds + L::OFF_AVEC) + lane;
         if (!(ablate & 1)) {
 #pragma unroll
@@ -109,6 +111,10 @@ struct GruCore {
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = F::mfma(ar[t * 64], h[KT - 1], acc[t]);
         }
+        }
+        if (BIAS_LAST) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] += *reinterpret_cast<const V4*>(binit + (size_t)t * 16 * sizeof(T));
         }
         if (ablate & 2) {      // keep the accumulators alive without the gate arithmetic
 #pragma unroll

@@ -32,7 +32,8 @@ struct PrnnArgs {
     int64_t sample_offset;
     int32_t sampling;            // 1: draw spins, 0: read them from bits
     int64_t ntiles;              // flip pass: (N-1) * nsb
-    int32_t ablate;              // diagnostics only (RNNWF_ABLATE): 1 skip MFMAs, 2 skip gate arithmetic, 4 skip head
+    int32_t ablate;              // diagnostics only (RNNWF_ABLATE): 1 skip MFMAs, 2 skip gate arithmetic, 4 skip head;
+                                 // base pass: 8 no checkpoint stores, 16 no flip-base stores, 32 constant uniform
 };
 
 
@@ -58,7 +59,7 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_base_kernel(PrnnArgs a) {
         double cum = 0.0;
         for (int n = 0; n < N; ++n) {
             if (!a.sampling && (n & 31) == 0) word = a.bits[(int64_t)(n >> 5) * a.ns + sc];
-            C::step(lds, sig_in, h, lane);
+            C::template step<true>(lds, sig_in, h, lane);
             T z[1];
             C::head(lds, h, lane, z);
             T lp0, lp1;
@@ -66,7 +67,7 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_base_kernel(PrnnArgs a) {
             int sig;
             if (a.sampling) {
                 // tf.multinomial(log p): class 0 iff u * total < p0
-                const float u = philox_uniform(a.seed, a.step, (uint64_t)(a.sample_offset + sc), n);
+                const float u = (a.ablate & 32) ? 0.5f : philox_uniform(a.seed, a.step, (uint64_t)(a.sample_offset + sc), n);
                 sig = ((T)u < prob0(z[0])) ? 0 : 1;
                 word |= (uint32_t)sig << (n & 31);
                 if (((n & 31) == 31 || n == N - 1) && valid && q == 0) a.bits[(int64_t)(n >> 5) * a.ns + s] = word;
@@ -75,13 +76,13 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_base_kernel(PrnnArgs a) {
                 sig = (word >> (n & 31)) & 1;
             }
             const double lsel = (double)(sig ? lp1 : lp0);
-            if (a.lpq) {
+            if (a.lpq && !(a.ablate & 16)) {
                 const double loth = (double)(sig ? lp0 : lp1);
                 const int64_t row = a.row_of_pos ? a.row_of_pos[n] : n + 1;
                 if (valid && q == 0) a.lpq[row * a.ns + s] = cum + loth;
             }
             cum += lsel;
-            if (a.hck && n < N - 1) {
+            if (a.hck && n < N - 1 && !(a.ablate & 8)) {
                 T* dst = reinterpret_cast<T*>(a.hck) + (((int64_t)n * a.nsb + sb) * KT) * 64 + lane;
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) dst[kt * 64] = h[kt];
@@ -140,6 +141,147 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_flip_kernel(PrnnArgs a) {
             const int64_t row = a.row_of_pos ? a.row_of_pos[i] : i + 1;
             a.lpq[row * a.ns + s] += lp;
         }
+    }
+}
+
+// prnn_base_coop_kernel : the base pass when there are fewer 16-chain blocks than SIMDs (config 2: 625 blocks, 1024
+// SIMDs).  There the one-wave-per-block kernel is pure latency: N sequential steps of ~130 dependent-issue MFMAs on
+// 60 % of the SIMDs.  Here NFULL + 1 waves share one block of 16 chains: wave m < NFULL computes the three gate tiles
+// of units 16m..16m+15 (39 MFMAs at 50 units), the last wave the mixed tile of the remainder units (13 MFMAs) AND the
+// head, the sampling decision and the log-probability bookkeeping.  Per site:
+//     all waves  : products of their tiles with the state (no bias yet: the input spin is still being drawn)
+//     barrier B  : the input spin of this site is published              (skipped at site 0)
+//     all waves  : + bias / one-hot rows, gates, publish the new values of their units
+//     barrier A  : the new state is complete; every wave reads it (it is everybody's next B operand)
+//     last wave  : head, draw / read the spin, publish it, log-probabilities
+// The arithmetic per unit is the instruction sequence of prnn_base_kernel (GruCore::step<BIAS_LAST>), so both kernels
+// agree bit for bit, draws included - a batch and its shards may take different kernels.
+template <int NFULL>
+__global__ void __launch_bounds__((NFULL + 1) * 64) prnn_base_coop_kernel(PrnnArgs a) {
+    using C = GruCore<float, NFULL, 1>;
+    using L = typename C::L;
+    using V4 = typename C::V4;
+    constexpr int KT = C::KT, NG = C::NG;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    C::stage(lds, a.wimg);
+    float* xbuf = reinterpret_cast<float*>(lds + L::BYTES);            // [2][KT][64] new state, then [2][64] int spins
+    int* sbuf = reinterpret_cast<int*>(xbuf + 2 * KT * 64);
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int m = threadIdx.x >> 6;                                     // this wave's unit block (NFULL: remainder units)
+    const bool full = m < NFULL;
+    const int N = a.N;
+    const V4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int64_t sb = blockIdx.x; sb < a.nsb; sb += gridDim.x) {
+        const int64_t s = sb * kChains + c;
+        const bool valid = s < a.ns;
+        const int64_t sc = valid ? s : a.ns - 1;
+        float h[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) h[kt] = 0.0f;
+        float own[4] = {0.0f, 0.0f, 0.0f, 0.0f};                        // this wave's units of the current state
+        uint32_t word = 0;
+        double cum = 0.0;
+        for (int n = 0; n < N; ++n) {
+            asm volatile("" ::: "memory");
+            float* xb = xbuf + (size_t)(n & 1) * KT * 64 + lane;
+            const V4* av = reinterpret_cast<const V4*>(lds + L::OFF_AVEC) + lane;
+            const float* ar = reinterpret_cast<const float*>(lds + L::OFF_AREM) + lane;
+            V4 accr = zero4, accu = zero4, accq = zero4;                // remainder wave: accr only
+            const int tr = full ? m : 3 * NFULL, tu = NFULL + m, tq = 2 * NFULL + m;
+            if (full) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const V4 fr = av[(tr * NG + g) * 64], fu = av[(tu * NG + g) * 64], fq = av[(tq * NG + g) * 64];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        accr = __builtin_amdgcn_mfma_f32_16x16x4f32(fr[j], h[g * 4 + j], accr, 0, 0, 0);
+                        accu = __builtin_amdgcn_mfma_f32_16x16x4f32(fu[j], h[g * 4 + j], accu, 0, 0, 0);
+                        accq = __builtin_amdgcn_mfma_f32_16x16x4f32(fq[j], h[g * 4 + j], accq, 0, 0, 0);
+                    }
+                }
+                accr = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[tr * 64], h[KT - 1], accr, 0, 0, 0);
+                accu = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[tu * 64], h[KT - 1], accu, 0, 0, 0);
+                accq = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[tq * 64], h[KT - 1], accq, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const V4 f = av[(tr * NG + g) * 64];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) accr = __builtin_amdgcn_mfma_f32_16x16x4f32(f[j], h[g * 4 + j], accr, 0, 0, 0);
+                }
+                accr = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[tr * 64], h[KT - 1], accr, 0, 0, 0);
+            }
+            int sig_in = -1;
+            if (n > 0) {
+                __syncthreads();                                        // barrier B: spin of site n-1 is published
+                sig_in = sbuf[((n - 1) & 1) * 64 + lane];
+            }
+            const char* binit = lds + L::OFF_BINIT + (size_t)(sig_in + 1) * L::SZ_BINIT_VARIANT + (size_t)q * 16;
+            const char* xcp = lds + L::OFF_XC + (size_t)(sig_in + 1) * L::SZ_XC_VARIANT + (size_t)q * 16;
+            if (full) {
+                accr += *reinterpret_cast<const V4*>(binit + (size_t)tr * 64);
+                accu += *reinterpret_cast<const V4*>(binit + (size_t)tu * 64);
+                accq += *reinterpret_cast<const V4*>(binit + (size_t)tq * 64);
+                const V4 xc = *reinterpret_cast<const V4*>(xcp + (size_t)m * 64);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float rg = Act<float>::sigmoid_scaled(accr[r]);
+                    const float ug = Act<float>::sigmoid_scaled(accu[r]);
+                    const float cc = Act<float>::tanh_scaled(xc[r] + rg * accq[r]);
+                    own[r] = cc + ug * (own[r] - cc);
+                    xb[(4 * m + r) * 64] = own[r];
+                }
+            } else {
+                accr += *reinterpret_cast<const V4*>(binit + (size_t)tr * 64);
+                const float xc = *reinterpret_cast<const float*>(xcp + (size_t)NFULL * 64);
+                const float rg = Act<float>::sigmoid_scaled(accr[0]);
+                const float ug = Act<float>::sigmoid_scaled(accr[1]);
+                const float cc = Act<float>::tanh_scaled(xc + rg * accr[2]);
+                own[0] = cc + ug * (own[0] - cc);
+                xb[(KT - 1) * 64] = own[0];
+            }
+            if (a.hck && n < N - 1 && !(a.ablate & 8)) {
+                float* dst = reinterpret_cast<float*>(a.hck) + (((int64_t)n * a.nsb + sb) * KT) * 64 + lane;
+                if (full) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[(4 * m + r) * 64] = own[r];
+                } else {
+                    dst[(KT - 1) * 64] = own[0];
+                }
+            }
+            __syncthreads();                                            // barrier A: the new state is complete
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) h[kt] = xb[kt * 64];
+            if (!full) {                                                // head + spin + bookkeeping: remainder wave only
+                if (!a.sampling && (n & 31) == 0) word = a.bits[(int64_t)(n >> 5) * a.ns + sc];
+                float zz[1];
+                C::head(lds, h, lane, zz);
+                const float z = zz[0];
+                float lp0, lp1;
+                log_softmax2(z, lp0, lp1);
+                int sig;
+                if (a.sampling) {
+                    const float u = (a.ablate & 32) ? 0.5f : philox_uniform(a.seed, a.step, (uint64_t)(a.sample_offset + sc), n);
+                    sig = (u < prob0(z)) ? 0 : 1;
+                    word |= (uint32_t)sig << (n & 31);
+                    if (((n & 31) == 31 || n == N - 1) && valid && q == 0) a.bits[(int64_t)(n >> 5) * a.ns + s] = word;
+                    if ((n & 31) == 31) word = 0;
+                } else {
+                    sig = (word >> (n & 31)) & 1;
+                }
+                sbuf[(n & 1) * 64 + lane] = sig;
+                if (a.lpq && !(a.ablate & 16)) {
+                    const int64_t row = a.row_of_pos ? a.row_of_pos[n] : n + 1;
+                    if (valid && q == 0) a.lpq[row * a.ns + s] = cum + (double)(sig ? lp0 : lp1);
+                }
+                cum += (double)(sig ? lp1 : lp0);
+            }
+        }
+        if (!full && valid && q == 0) {
+            if (a.lpq) a.lpq[s] = cum;
+            if (a.out_lp) a.out_lp[s] = cum;
+        }
+        __syncthreads();          // the next block of chains starts writing the buffers again
     }
 }
 

@@ -290,8 +290,7 @@ int rnnwf::mdrnn_tfim_eloc(rnnwf_handle* h, const int32_t* samples, int64_t ns, 
     h->last_ns = 0;
     Maps m;
     if (int rc = get_maps(h, &m)) return rc;
-    if (int rc = ensure(h, h->coupl, (size_t)N * 8)) return rc;
-    RNNWF_HIP(h, hipMemcpyAsync(h->coupl.p, Jz, (size_t)N * 8, hipMemcpyHostToDevice, h->stream));
+    if (int rc = upload_couplings(h, Jz, (size_t)N)) return rc;
     const int64_t chunk = max_chains_per_pass(h);
     for (int64_t off = 0; off < ns; off += chunk) {
         const int64_t nb = std::min(chunk, ns - off);
@@ -316,8 +315,7 @@ int rnnwf::mdrnn_vmc_step(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t s
         return h->fail(RNNWF_ERR_NOMEM, "rnnwf_vmc_step: %lld samples exceed the hidden-state budget; split the batch",
                        (long long)ns);
     if (int rc = ensure(h, h->bits, (size_t)W * ns * 4)) return rc;
-    if (int rc = ensure(h, h->coupl, (size_t)N * 8)) return rc;
-    RNNWF_HIP(h, hipMemcpyAsync(h->coupl.p, couplings, (size_t)N * 8, hipMemcpyHostToDevice, h->stream));
+    if (int rc = upload_couplings(h, couplings, (size_t)N)) return rc;
     if (int rc = eloc_on_device(h, ns, m, true, seed, step, offset, (const double*)h->coupl.p, couplings[N])) return rc;
     if (out_samples) if (int rc = unpack_and_download(h, h->bits, ns, out_samples, m.pos_of_site)) return rc;
     if (out_eloc) RNNWF_HIP(h, hipMemcpyAsync(out_eloc, h->eloc.p, (size_t)ns * 8, hipMemcpyDeviceToHost, h->stream));

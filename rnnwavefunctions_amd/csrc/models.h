@@ -55,6 +55,8 @@ void grad_invalidate(rnnwf_handle* h);
 // bytes of per-site hidden states one pass may hold; RNNWF_STATE_BUDGET_MB overrides the default (tests use it to
 // drive the multi-pass path at small sizes)
 size_t state_budget_bytes(size_t dflt);
+// h->coupl <- n doubles; skipped when they are what the device already holds
+int upload_couplings(rnnwf_handle* h, const double* src, size_t n);
 
 }  // namespace rnnwf
 

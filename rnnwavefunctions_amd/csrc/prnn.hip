@@ -2,6 +2,7 @@
 // sample / log_probability / fused TFIM local energies / fused VMC step.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "gru_kernels.h"
 #include "ml_kernels.h"
@@ -27,7 +28,27 @@ struct Launch {
         *out = std::max(nb, 1);
         return 0;
     }
+    // fewer 16-chain blocks than SIMDs: the cooperative kernel (NFULL + 1 waves per block) cuts the per-site latency
+    static int base_coop(rnnwf_handle* h, const PrnnArgs& a) {
+        if constexpr (std::is_same<T, float>::value && NFULL <= 4) {
+            static int bpc = 0;
+            const void* fn = (const void*)prnn_base_coop_kernel<NFULL>;
+            const size_t lds = L::BYTES + (size_t)2 * L::KT * 64 * 4 + 2 * 64 * 4;
+            if (!bpc) {
+                RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                RNNWF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, (NFULL + 1) * 64, lds));
+                bpc = std::max(bpc, 1);
+            }
+            const unsigned grid = (unsigned)std::min<int64_t>(a.nsb, (int64_t)bpc * h->cu_count);
+            TimedLaunch tl(h, 0);
+            prnn_base_coop_kernel<NFULL><<<grid, (NFULL + 1) * 64, lds, h->stream>>>(a);
+            RNNWF_HIP(h, hipGetLastError());
+        }
+        return 0;
+    }
     static int base(rnnwf_handle* h, const PrnnArgs& a) {
+        if (std::is_same<T, float>::value && NFULL <= 4 && a.nsb <= (int64_t)4 * h->cu_count && !getenv("RNNWF_NO_COOP"))
+            return base_coop(h, a);
         static int bpc = 0;
         const void* fn = (const void*)prnn_base_kernel<T, NFULL, WAVES>;
         if (!bpc) if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
@@ -200,6 +221,7 @@ PrnnArgs base_args(rnnwf_handle* h, int64_t ns) {
     a.N = h->N;
     a.ns = ns;
     a.nsb = (ns + kChains - 1) / kChains;
+    if (const char* e = getenv("RNNWF_ABLATE_BASE")) a.ablate = atoi(e) & (8 | 16 | 32);   // diagnostics only
     return a;
 }
 
@@ -238,7 +260,7 @@ int eloc_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
     if (Bx != 0.0 && N > 1) {
         a.ntiles = (int64_t)(N - 1) * nsb;
         a.sampling = 0;
-        if (const char* e = getenv("RNNWF_ABLATE")) a.ablate = atoi(e);   // diagnostics only
+        if (const char* e = getenv("RNNWF_ABLATE")) a.ablate |= atoi(e) & 7;   // diagnostics only
         if (h->engine_split) {
             if (int rc = launch_flip_split(h, a)) return rc;
             h->work[1] += (double)((ns + 31) / 32) * N * (N - 1) / 2.0 * split_mfma_flops_per_step(h);
@@ -366,8 +388,7 @@ int rnnwf::prnn_tfim_eloc(rnnwf_handle* h, const int32_t* samples, int64_t ns, i
                           double Bx, double* eloc, double* log_probs) {
     const int N = h->N;
     h->last_ns = 0;
-    if (int rc = ensure(h, h->coupl, (size_t)N * 8)) return rc;
-    RNNWF_HIP(h, hipMemcpyAsync(h->coupl.p, Jz, (size_t)N * 8, hipMemcpyHostToDevice, h->stream));
+    if (int rc = upload_couplings(h, Jz, (size_t)N)) return rc;
     const int64_t chunk = max_chains_per_pass(h);
     for (int64_t off = 0; off < ns; off += chunk) {
         const int64_t nb = std::min(chunk, ns - off);
@@ -392,8 +413,7 @@ int rnnwf::prnn_vmc_step(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t st
         return h->fail(RNNWF_ERR_NOMEM, "rnnwf_vmc_step: %lld samples exceed the checkpoint budget; split the batch",
                        (long long)ns);
     if (int rc = ensure(h, h->bits, (size_t)W * ns * 4)) return rc;
-    if (int rc = ensure(h, h->coupl, (size_t)N * 8)) return rc;
-    RNNWF_HIP(h, hipMemcpyAsync(h->coupl.p, couplings, (size_t)N * 8, hipMemcpyHostToDevice, h->stream));
+    if (int rc = upload_couplings(h, couplings, (size_t)N)) return rc;
     const double Bx = couplings[N];
     const int Nx = h->model == RNNWF_MODEL_GRU1D_F64 ? h->Nx : 1;
     const int Ny = h->model == RNNWF_MODEL_GRU1D_F64 ? h->Ny : N;

@@ -73,6 +73,14 @@ size_t rnnwf::state_budget_bytes(size_t dflt) {
     return dflt;
 }
 
+int rnnwf::upload_couplings(rnnwf_handle* h, const double* src, size_t n) {
+    if (h->coupl.p && h->coupl_host.size() == n && std::equal(src, src + n, h->coupl_host.begin())) return 0;
+    if (int rc = ensure(h, h->coupl, n * 8)) return rc;
+    h->coupl_host.assign(src, src + n);
+    RNNWF_HIP(h, hipMemcpyAsync(h->coupl.p, h->coupl_host.data(), n * 8, hipMemcpyHostToDevice, h->stream));
+    return 0;
+}
+
 static int pick_nfull(int H, bool f64, bool mdrnn) {
     const int cand[] = {1, 2, 3, 4, 6};
     for (int nf : cand) {
@@ -312,8 +320,8 @@ int rnnwf::run_moments(rnnwf_handle* h, const void* eloc_dev, int64_t ns, bool c
 int rnnwf::run_tfim_eloc(rnnwf_handle* h, const uint32_t* bits, const double* lpq, int64_t ns, int Nx, int Ny,
                          const int32_t* pos_of_site_dev, const double* Jz_dev, double Bx, double* eloc_dev) {
     TimedLaunch tl(h, 2);
-    tfim_eloc_kernel<<<(unsigned)((ns + 255) / 256), 256, 0, h->stream>>>(bits, lpq, ns, Nx, Ny, pos_of_site_dev, Jz_dev,
-                                                                          Bx, eloc_dev);
+    tfim_eloc_kernel<<<(unsigned)((ns + kElocSamples - 1) / kElocSamples), kElocSamples * kElocGroups, 0, h->stream>>>(
+        bits, lpq, ns, Nx, Ny, pos_of_site_dev, Jz_dev, Bx, eloc_dev);
     RNNWF_HIP(h, hipGetLastError());
     return 0;
 }

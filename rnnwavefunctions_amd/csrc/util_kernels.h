@@ -37,30 +37,46 @@ __global__ void unpack_bits_kernel(const uint32_t* __restrict__ bits, int64_t B,
 // E_loc of the transverse-field Ising model on an Nx x Ny open lattice (1D chain: Nx = 1):
 //   1DTFIM/TrainingRNN_1DTFIM.py:31-38,70-74 ; 2DTFIM_2DRNN/Training2DRNN_2DTFIM.py:33-49,78-81.
 // Site (i, j) = flat k = i*Ny + j sits at chain position pos_of_site[k]; Jz is (Nx, Ny) row-major.
-__global__ void tfim_eloc_kernel(const uint32_t* __restrict__ bits, const double* __restrict__ lpq, int64_t ns,
-                                 int Nx, int Ny, const int32_t* __restrict__ pos_of_site,
-                                 const double* __restrict__ Jz, double Bx, double* __restrict__ eloc) {
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= ns) return;
+// Block = 32 samples x 8 site groups: group g sums the off-diagonal terms of sites g, g+8, ... (one f64 exp each),
+// group 0 also the bond terms; the eight partial sums are added in fixed order (reproducible).
+constexpr int kElocSamples = 32, kElocGroups = 8;
+__global__ void __launch_bounds__(kElocSamples * kElocGroups)
+tfim_eloc_kernel(const uint32_t* __restrict__ bits, const double* __restrict__ lpq, int64_t ns, int Nx, int Ny,
+                 const int32_t* __restrict__ pos_of_site, const double* __restrict__ Jz, double Bx,
+                 double* __restrict__ eloc) {
+    __shared__ double part[kElocGroups][kElocSamples];
+    const int ls = threadIdx.x % kElocSamples, g = threadIdx.x / kElocSamples;
+    const int64_t s = (int64_t)blockIdx.x * kElocSamples + ls;
+    const bool valid = s < ns;
+    const int64_t sc = valid ? s : ns - 1;
     auto spin = [&](int k) {
         const int p = pos_of_site ? pos_of_site[k] : k;
-        return (int)((bits[(int64_t)(p >> 5) * ns + s] >> (p & 31)) & 1);
+        return (int)((bits[(int64_t)(p >> 5) * ns + sc] >> (p & 31)) & 1);
     };
     double e = 0.0;
-    for (int i = 0; i + 1 < Nx; ++i)
-        for (int j = 0; j < Ny; ++j)
-            e += (spin(i * Ny + j) == spin((i + 1) * Ny + j) ? 1.0 : -1.0) * (-Jz[i * Ny + j]);
-    for (int j = 0; j + 1 < Ny; ++j)
-        for (int i = 0; i < Nx; ++i)
-            e += (spin(i * Ny + j) == spin(i * Ny + j + 1) ? 1.0 : -1.0) * (-Jz[i * Ny + j]);
+    if (g == 0) {
+        for (int i = 0; i + 1 < Nx; ++i)
+            for (int j = 0; j < Ny; ++j)
+                e += (spin(i * Ny + j) == spin((i + 1) * Ny + j) ? 1.0 : -1.0) * (-Jz[i * Ny + j]);
+        for (int j = 0; j + 1 < Ny; ++j)
+            for (int i = 0; i < Nx; ++i)
+                e += (spin(i * Ny + j) == spin(i * Ny + j + 1) ? 1.0 : -1.0) * (-Jz[i * Ny + j]);
+    }
     if (Bx != 0.0) {
         const int N = Nx * Ny;
-        const double l0 = 0.5 * lpq[s];
+        const double l0 = 0.5 * lpq[sc];
         double acc = 0.0;
-        for (int k = 0; k < N; ++k) acc += exp(0.5 * lpq[(int64_t)(k + 1) * ns + s] - l0);
+        for (int k = g; k < N; k += kElocGroups) acc += exp(0.5 * lpq[(int64_t)(k + 1) * ns + sc] - l0);
         e += -Bx * acc;
     }
-    eloc[s] = e;
+    part[g][ls] = e;
+    __syncthreads();
+    if (g == 0 && valid) {
+        double t = part[0][ls];
+#pragma unroll
+        for (int k = 1; k < kElocGroups; ++k) t += part[k][ls];
+        eloc[s] = t;
+    }
 }
 
 // moments[0..3] = { sum Re E, sum (Re E)^2, n, sum Im E }; one workgroup, fixed order -> reproducible.

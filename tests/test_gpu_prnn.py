@@ -404,3 +404,22 @@ def test_log_prob_beyond_one_device_chunk():
     idx = np.random.RandomState(1).randint(0, 16, B)
     lp = wf.log_prob(cfgs[idx])
     assert np.array_equal(lp, wf.log_prob(cfgs)[idx])
+
+
+@pytest.mark.parametrize("N,H,ns", [(20, 10, 100), (33, 36, 333), (80, 50, 1000), (12, 64, 50), (7, 20, 16)])
+def test_cooperative_base_pass_is_bit_identical(N, H, ns, monkeypatch):
+    """Small batches run the base pass with NFULL+1 waves per 16-chain block (prnn_base_coop_kernel); a batch and its
+    shards may therefore take different kernels, so the two must agree in every bit, draws included."""
+    from rnnwavefunctions_amd import _lib
+    prm = trained_like(H, seed=N)
+    wf = make_wf(_lib.MODEL_GRU1D, N, H, prm)
+    s1, lg1 = wf.sample(ns, seed=9, step=1, return_log=True)
+    lp1 = wf.log_prob(s1)
+    e1 = wf.tfim_eloc(s1, np.ones(N), 1.0)
+    monkeypatch.setenv("RNNWF_NO_COOP", "1")
+    s2, lg2 = wf.sample(ns, seed=9, step=1, return_log=True)
+    lp2 = wf.log_prob(s1)
+    e2 = wf.tfim_eloc(s1, np.ones(N), 1.0)
+    monkeypatch.delenv("RNNWF_NO_COOP")
+    assert np.array_equal(s1, s2) and np.array_equal(lg1, lg2)
+    assert np.array_equal(lp1, lp2) and np.array_equal(e1, e2)
