@@ -66,12 +66,12 @@ struct CLaunch {
     } while (0)
 
 // ---- bf16x3 engine for the swap pass (num_units <= 68) ---------------------------------------------------
-template <int NF32, int RJ, int WAVES>
+template <int NF32, int RJ, int WAVES, int MODE>
 struct CSLaunch {
-    using L = SplitLayout<NF32, RJ, 3>;
+    using L = SplitLayout<NF32, RJ, 3, MODE>;
     static int swap(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles, int kt16) {
         static int bpc = 0;
-        const void* fn = (const void*)crnn_swap_split_kernel<NF32, RJ, WAVES>;
+        const void* fn = (const void*)crnn_swap_split_kernel<NF32, RJ, WAVES, MODE>;
         if (!bpc) {
             RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES));
             RNNWF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, WAVES * 64, L::BYTES));
@@ -80,21 +80,22 @@ struct CSLaunch {
         const int64_t need = (max_tiles + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
         TimedLaunch tl(h, 1);
-        crnn_swap_split_kernel<NF32, RJ, WAVES><<<grid, WAVES * 64, L::BYTES, h->stream>>>(a, h->wsplit.p, kt16);
+        crnn_swap_split_kernel<NF32, RJ, WAVES, MODE><<<grid, WAVES * 64, L::BYTES, h->stream>>>(a, h->wsplit.p, kt16);
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }
-    static std::vector<char> pack(const rnnwf_handle* h) { return pack_split_image<NF32, RJ, 3>(h); }
-    static double mfma_flops_per_step() { return (double)L::NT * 6 * L::NQ * 32768.0; }
+    static std::vector<char> pack(const rnnwf_handle* h) { return pack_split_image<NF32, RJ, 3, MODE>(h); }
+    static double mfma_flops_per_step() { return (double)L::NT * L::KS * 32768.0; }
 };
 
 #define CSPLIT_DISPATCH(h, EXPR)                                     \
     do {                                                             \
         switch ((h)->NFULL) {                                        \
-            case 1: { using K = CSLaunch<0, 10, 4>; EXPR; }          \
-            case 2: { using K = CSLaunch<1, 2, 4>; EXPR; }           \
-            case 3: { using K = CSLaunch<1, 10, 4>; EXPR; }          \
-            case 4: { using K = CSLaunch<2, 2, 4>; EXPR; }           \
+            case 1: { using K = CSLaunch<0, 10, 4, 1>; EXPR; }       \
+            case 2: { using K = CSLaunch<1, 2, 4, 1>; EXPR; }        \
+            case 3: if ((h)->H <= 50) { using K = CSLaunch<1, 9, 4, 2>; EXPR; } \
+                    else { using K = CSLaunch<1, 10, 4, 0>; EXPR; }  \
+            case 4: { using K = CSLaunch<2, 2, 4, 0>; EXPR; }        \
         }                                                            \
     } while (0)
 

@@ -7,9 +7,9 @@ namespace rnnwf {
 
 // J1-J2 swap pass on the bf16x3 engine: same items / outputs as crnn_swap_kernel, 32 items per wave tile
 // (the tile table must have been scanned with tile_items = 32).
-template <int NF32, int RJ, int WAVES>
+template <int NF32, int RJ, int WAVES, int MODE>
 __global__ void __launch_bounds__(WAVES * 64, (3 * NF32 + (3 * RJ + 15) / 16) <= 5 ? 2 : 1) crnn_swap_split_kernel(CrnnArgs a, const void* wsplit, int kt16) {
-    using C = SplitCore<NF32, RJ, 3>;
+    using C = SplitCore<NF32, RJ, 3, MODE>;
     using L = typename C::L;
     constexpr int NU = C::NU, NR = C::NR;
     extern __shared__ __attribute__((aligned(16))) char lds[];

@@ -29,9 +29,9 @@ inline void split3(double w, uint16_t (&p)[3]) {
     }
 }
 
-template <int NF32, int RJ, int NOUT = 1>
+template <int NF32, int RJ, int NOUT = 1, int MODE = 0>
 std::vector<char> pack_split_image(const rnnwf_handle* h) {
-    using L = SplitLayout<NF32, RJ, NOUT>;
+    using L = SplitLayout<NF32, RJ, NOUT, MODE>;
     const int H = h->H;
     std::vector<char> img(L::BYTES, 0);
     const std::string pre = kGruPre;
@@ -55,18 +55,56 @@ std::vector<char> pack_split_image(const rnnwf_handle* h) {
                 uo = L::unit_of(16 * (T / 3) + rho, hh_row);
             } else {
                 const int s = 16 * (T - 3 * NF32) + rho;
-                if (s < 3 * RJ) { g = s / RJ; uo = 32 * NF32 + hh_row * RJ + s % RJ; }
+                if (s < 3 * RJ) { g = s / RJ; uo = L::unit_of(16 * NF32 + s % RJ, hh_row); }
             }
             if (g < 0 || uo >= H) continue;
+            auto weight = [&](int ui) -> double {          // (scaled) recurrent weight from unit ui into row (g, uo)
+                if (ui >= H) return 0.0;
+                return g == 0 ? sg * Wg[(size_t)(2 + ui) * 2 * H + uo]
+                     : g == 1 ? sg * Wg[(size_t)(2 + ui) * 2 * H + H + uo]
+                              : sc * Wch[(size_t)ui * H + uo];
+            };
+            if constexpr (MODE != 0) {
+                // accumulator start value of this row: bias + one-hot input row (the same for both K halves)
+                if (hhk == 0) {
+                    float* CI = reinterpret_cast<float*>(img.data() + L::OFF_CI);
+                    for (int sgm = 0; sgm < 2; ++sgm) {
+                        const double v = g == 0 ? sg * (bg[uo] + Wg[(size_t)sgm * 2 * H + uo])
+                                       : g == 1 ? sg * (bg[H + uo] + Wg[(size_t)sgm * 2 * H + H + uo]) : sc * bch[uo];
+                        CI[(((size_t)sgm * L::NT + T) * 2 + hh_row) * 16 + rho] = (float)v;
+                    }
+                }
+            }
+            if constexpr (MODE == 1) {
+                // one chain over the concatenated K axis: lane half hhk's flat register list, product by product
+                constexpr int ORD[6][2] = {{2, 0}, {1, 1}, {0, 2}, {1, 0}, {0, 1}, {0, 0}};
+                for (int ks = 0; ks < L::KS; ++ks)
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int fe = 8 * ks + jj, f = fe / 2;
+                        if (f >= 6 * L::NRM) continue;
+                        const int o = f / L::NRM, e = 2 * (f % L::NRM) + (fe & 1);
+                        uint16_t p[3];
+                        split3(weight(L::unit_of(e, hhk)), p);
+                        A[(((size_t)ks * L::NT + T) * 64 + lane) * 8 + jj] = p[ORD[o][0]];
+                    }
+                continue;
+            }
+            if constexpr (MODE == 2) {
+                // special unit of K half hhk: parts {w1, w1, w1, w2, w2, w3} against the B entries {h1, h2, h3, h1, h2, h1}
+                uint16_t p[3];
+                split3(weight(L::unit_of(L::NU - 1, hhk)), p);
+                uint16_t* ASP = reinterpret_cast<uint16_t*>(img.data() + L::OFF_ASP);
+                const int part[6] = {0, 0, 0, 1, 1, 2};
+                for (int jj = 0; jj < 6; ++jj) ASP[((size_t)T * 64 + lane) * 8 + jj] = p[part[jj]];
+            }
             for (int x = 0; x < L::NQ; ++x)
                 for (int jj = 0; jj < 8; ++jj) {
                     const int e = 8 * x + jj;
                     double w = 0.0;
-                    if (e < L::NU) {
-                        const int ui = L::unit_of(e, hhk);
-                        if (ui < H) w = g == 0 ? sg * Wg[(size_t)(2 + ui) * 2 * H + uo]
-                                      : g == 1 ? sg * Wg[(size_t)(2 + ui) * 2 * H + H + uo]
-                                               : sc * Wch[(size_t)ui * H + uo];
+                    if (e < L::NUA) {
+                        w = weight(L::unit_of(e, hhk));
+                    } else if (MODE != 0) {
+                        w = 0.0;
                     } else if (e == L::NU && hhk == 0) {                    // bias (+ input row of spin 0)
                         w = g == 0 ? sg * (bg[uo] + Wg[uo]) : g == 1 ? sg * (bg[H + uo] + Wg[H + uo]) : sc * bch[uo];
                     } else if (e == L::NU + 1 && hhk == 0) {                // input row difference, times sigma

@@ -155,12 +155,12 @@ struct MLaunchL {
     } while (0)
 
 // ---- bf16x3 engine for the flip pass (f32 models, num_units <= 68) ---------------------------------------
-template <int NF32, int RJ, int WAVES>
+template <int NF32, int RJ, int WAVES, int MODE>
 struct SLaunch {
-    using L = SplitLayout<NF32, RJ>;
+    using L = SplitLayout<NF32, RJ, 1, MODE>;
     static int flip(rnnwf_handle* h, const PrnnArgs& a, int kt16) {
         static int bpc = 0;
-        const void* fn = (const void*)prnn_flip_split_kernel<NF32, RJ, WAVES>;
+        const void* fn = (const void*)prnn_flip_split_kernel<NF32, RJ, WAVES, MODE>;
         if (!bpc) {
             RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES));
             RNNWF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, WAVES * 64, L::BYTES));
@@ -170,21 +170,22 @@ struct SLaunch {
         const int64_t need = (ntiles + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
         TimedLaunch tl(h, 1);
-        prnn_flip_split_kernel<NF32, RJ, WAVES><<<grid, WAVES * 64, L::BYTES, h->stream>>>(a, h->wsplit.p, kt16);
+        prnn_flip_split_kernel<NF32, RJ, WAVES, MODE><<<grid, WAVES * 64, L::BYTES, h->stream>>>(a, h->wsplit.p, kt16);
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }
-    static std::vector<char> pack(const rnnwf_handle* h) { return pack_split_image<NF32, RJ>(h); }
-    static double mfma_flops_per_step() { return (double)L::NT * 6 * L::NQ * 32768.0; }   // per 32-chain wave-step
+    static std::vector<char> pack(const rnnwf_handle* h) { return pack_split_image<NF32, RJ, 1, MODE>(h); }
+    static double mfma_flops_per_step() { return (double)L::NT * L::KS * 32768.0; }   // per 32-chain wave-step
 };
 
 #define SPLIT_DISPATCH(h, EXPR)                                      \
     do {                                                             \
         switch ((h)->NFULL) {                                        \
-            case 1: { using K = SLaunch<0, 10, 4>; EXPR; }           \
-            case 2: { using K = SLaunch<1, 2, 4>; EXPR; }            \
-            case 3: { using K = SLaunch<1, 10, 4>; EXPR; }           \
-            case 4: { using K = SLaunch<2, 2, 4>; EXPR; }            \
+            case 1: { using K = SLaunch<0, 10, 4, 1>; EXPR; }        \
+            case 2: { using K = SLaunch<1, 2, 4, 1>; EXPR; }         \
+            case 3: if ((h)->H <= 50) { using K = SLaunch<1, 9, 4, 2>; EXPR; } \
+                    else { using K = SLaunch<1, 10, 4, 0>; EXPR; }   \
+            case 4: { using K = SLaunch<2, 2, 4, 0>; EXPR; }         \
         }                                                            \
     } while (0)
 

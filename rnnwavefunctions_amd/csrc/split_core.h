@@ -19,6 +19,19 @@
 // consecutive K entries 8x .. 8x+7 of quad x), so the new state is re-split in registers and fed straight back.
 // Gate rows: full block t -> tiles 3t + {r, u, c}; remainder units -> NMIX "mixed" tiles, slot g RJ + j.
 // Two extra K entries per part carry the bias (entry NU, value 1) and the one-hot input (entry NU+1, value sigma).
+//
+// Layout modes (MODE):
+//  0  classic: every part of every product padded to whole k-steps, bias / input as two extra K entries (above).
+//  1  flat K-packing (num_units <= 36): the six products are ONE chain over a concatenated K axis - a lane's 3 x NU/2
+//     packed state registers, product by product, cut into k-steps of four registers without per-product padding;
+//     one A fragment per (k-step, tile), packed on the host for exactly that list.
+//  2  aligned + special unit (37 <= num_units <= 50, the headline width): each lane half owns 24 "aligned" units whose
+//     three parts are exactly three k-steps each (no padding at all: 18 k-steps for the six products) plus ONE special
+//     unit (48 + hh) whose six products {w1 h1, w1 h2, w1 h3, w2 h1, w2 h2, w3 h1} fill six of the eight K entries of
+//     a 19th k-step.  95 MFMAs per 32-chain wave-step instead of 120; A fragments stay shared between products
+//     (image 50 KB instead of 60 KB).
+// Modes 1 and 2 take bias and one-hot input off the K axis: they are the accumulators' initial value, read from a
+// 1.3 KB table [sigma][tile][lane half][16] (rows differ, chains do not).
 #pragma once
 #include <type_traits>
 
@@ -30,26 +43,37 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int NF32_, int RJ_, int NOUT_ = 1>
+template <int NF32_, int RJ_, int NOUT_ = 1, int MODE_ = 0>
 struct SplitLayout {
     static constexpr int NOUT = NOUT_;                  // head rows: 1 (pRNN logit difference), 3 (cRNN: + 2 phase logits)
-    static constexpr int NF32 = NF32_, RJ = RJ_;
+    static constexpr int NF32 = NF32_, RJ = RJ_, MODE = MODE_;
     static constexpr int NMIX = (3 * RJ + 15) / 16;
     static constexpr int NT = 3 * NF32 + NMIX;          // 32-row output tiles
-    static constexpr int NU = 16 * NF32 + RJ;           // hidden units owned by one lane
-    static constexpr int NE = NU + 2;                   // + bias entry + input entry
-    static constexpr int NQ = (NE + 7) / 8;             // bf16x8 quads per part
-    static constexpr int NR = 4 * NQ;                   // packed 32-bit registers per part
+    static constexpr int NU = 16 * NF32 + RJ;           // hidden units owned by one lane (mode 2: the last one is special)
+    static constexpr int NUA = MODE == 2 ? NU - 1 : NU; // units that travel in the regular packed registers
+    static constexpr int NE = MODE == 0 ? NU + 2 : NUA; // mode 0: + bias entry + input entry
+    static constexpr int NQ = (NE + 7) / 8;             // bf16x8 quads per part (modes 0, 2)
+    static constexpr int NRM = MODE == 1 ? NU / 2 : 4 * NQ;     // packed 32-bit registers per part
+    static constexpr int NR = MODE == 2 ? NRM + 1 : NRM;        // declared per part: mode 2 keeps the special k-step's B registers in slot NRM
+    static constexpr int KS = MODE == 1 ? (6 * NRM + 3) / 4 : MODE == 2 ? 6 * NQ + 1 : 6 * NQ;   // k-steps (MFMAs per tile)
     static constexpr int NUP = ((NU + 3) / 4) * 4;
     static constexpr int HP = 32 * NF32 + 2 * RJ;       // padded hidden size
-    static constexpr size_t OFF_A = 0;                                         // [NT][3][NQ][64] x 16 B
-    static constexpr size_t OFF_XC = OFF_A + (size_t)NT * 3 * NQ * 64 * 16;    // [2 sigma][2 hh][NUP] f32 (scaled)
+    static_assert(MODE != 2 || (NUA % 8 == 0), "mode 2: the aligned units fill whole k-steps");
+    static_assert(MODE != 1 || (NU % 2 == 0), "mode 1: units are packed in pairs");
+    // A image: mode 0 [NT][3][NQ][64] x 16 B; mode 1 [KS][NT][64] x 16 B; mode 2 [NT][3][NQ][64] then [NT][64] (special)
+    static constexpr size_t OFF_A = 0;
+    static constexpr size_t SZ_A = MODE == 1 ? (size_t)KS * NT * 64 * 16 : (size_t)NT * (3 * NQ + (MODE == 2 ? 1 : 0)) * 64 * 16;
+    static constexpr size_t OFF_ASP = (size_t)NT * 3 * NQ * 64 * 16;           // mode 2: special fragments
+    static constexpr size_t OFF_CI = OFF_A + SZ_A;                             // modes 1, 2: [2 sigma][NT][2 hh][16] f32
+    static constexpr size_t OFF_XC = OFF_CI + (MODE != 0 ? (size_t)2 * NT * 2 * 16 * 4 : 0);   // [2 sigma][2 hh][NUP] f32 (scaled)
     static constexpr size_t OFF_WD = OFF_XC + (size_t)2 * 2 * NUP * 4;         // [2 hh][NUP][NOUT] f32 head weights
     static constexpr size_t OFF_BD = OFF_WD + (size_t)2 * NUP * NOUT * 4;      // [4] f32 head biases (padded)
     static constexpr size_t BYTES = OFF_BD + 16;
     // unit owned by entry e of lane half hh
     static constexpr int unit_of(int e, int hh) {
-        return e < 16 * NF32 ? 32 * (e / 16) + ((e % 16) & 3) + 8 * ((e % 16) >> 2) + 4 * hh : 32 * NF32 + hh * RJ + (e - 16 * NF32);
+        if (e < 16 * NF32) return 32 * (e / 16) + ((e % 16) & 3) + 8 * ((e % 16) >> 2) + 4 * hh;
+        if (MODE == 2) return e < NU - 1 ? 32 * NF32 + hh * (RJ - 1) + (e - 16 * NF32) : 32 * NF32 + 2 * (RJ - 1) + hh;
+        return 32 * NF32 + hh * RJ + (e - 16 * NF32);
     }
 };
 
@@ -60,10 +84,10 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
     return r;
 }
 
-template <int NF32, int RJ, int NOUT = 1>
+template <int NF32, int RJ, int NOUT = 1, int MODE = 0>
 struct SplitCore {
-    using L = SplitLayout<NF32, RJ, NOUT>;
-    static constexpr int NT = L::NT, NU = L::NU, NQ = L::NQ, NR = L::NR;
+    using L = SplitLayout<NF32, RJ, NOUT, MODE>;
+    static constexpr int NT = L::NT, NU = L::NU, NUA = L::NUA, NQ = L::NQ, NR = L::NR, NRM = L::NRM, KS = L::KS;
 
     static __device__ __forceinline__ void stage(char* lds, const void* wimg) {
         const uint4* src = reinterpret_cast<const uint4*>(wimg);
@@ -75,11 +99,11 @@ struct SplitCore {
     // h (this lane's NU units) -> three bf16 parts packed two per register; entries NU (bias, 1.0) and NU+1 (input
     // spin) are appended to part 1.  Every step of the split is exact: r = x - bf16(x) is representable.
     static __device__ __forceinline__ void split(const float (&h)[NU], int sig, unsigned (&R)[3][NR]) {
-        float v[2 * NR];
+        float v[2 * NRM];
 #pragma unroll
-        for (int e = 0; e < 2 * NR; ++e) v[e] = e < NU ? h[e] : 0.0f;
+        for (int e = 0; e < 2 * NRM; ++e) v[e] = e < NUA ? h[e] : 0.0f;
 #pragma unroll
-        for (int i = 0; i < NR; ++i) {
+        for (int i = 0; i < NRM; ++i) {
             const unsigned p1 = cvt_pk_bf16(v[2 * i], v[2 * i + 1]);
             const float r0 = v[2 * i] - __uint_as_float(p1 << 16);
             const float r1 = v[2 * i + 1] - __uint_as_float(p1 & 0xffff0000u);
@@ -90,11 +114,26 @@ struct SplitCore {
             R[1][i] = p2;
             R[2][i] = cvt_pk_bf16(s0, s1);
         }
-        // bias / input entries (bf16 1.0 = 0x3F80)
-        constexpr int eb = NU, es = NU + 1;
-        const unsigned one = 0x3F80u, sg = sig ? 0x3F80u : 0u;
-        R[0][eb / 2] |= (eb & 1) ? (one << 16) : one;
-        R[0][es / 2] |= (es & 1) ? (sg << 16) : sg;
+        if constexpr (MODE == 0) {
+            // bias / input entries (bf16 1.0 = 0x3F80)
+            constexpr int eb = NU, es = NU + 1;
+            const unsigned one = 0x3F80u, sg = sig ? 0x3F80u : 0u;
+            R[0][eb / 2] |= (eb & 1) ? (one << 16) : one;
+            R[0][es / 2] |= (es & 1) ? (sg << 16) : sg;
+        }
+        if constexpr (MODE == 2) {
+            // the special unit: its parts, duplicated into both halves of a register, then the B registers of the
+            // special k-step in the K order {h1, h2, h3, h1, h2, h1} (A side: {w1, w1, w1, w2, w2, w3}), 2 entries each
+            const float x = h[NU - 1];
+            const unsigned q1 = cvt_pk_bf16(x, x);
+            const float r = x - __uint_as_float(q1 << 16);
+            const unsigned q2 = cvt_pk_bf16(r, r);
+            const float t = r - __uint_as_float(q2 << 16);
+            const unsigned q3 = cvt_pk_bf16(t, t);
+            R[0][NRM] = (q1 & 0xffffu) | (q2 & 0xffff0000u);      // h1 | h2 << 16
+            R[1][NRM] = (q3 & 0xffffu) | (q1 & 0xffff0000u);      // h3 | h1 << 16
+            R[2][NRM] = (q2 & 0xffffu) | (q1 & 0xffff0000u);      // h2 | h1 << 16
+        }
     }
 
     // One GRU step for 32 chains: R (split old state + bias/input entries) and hold (old state) in, new state out.
@@ -134,29 +173,46 @@ struct SplitCore {
         // between the second pass's MFMAs: the bf16 matrix pipe lets ~2 VALU ops per MFMA issue for free (measured,
         // profiles/r01_c_microbench_*), unlike the f32-input MFMA.
         constexpr int ORD[6][2] = {{2, 0}, {1, 1}, {0, 2}, {1, 0}, {0, 1}, {0, 0}};
-        constexpr int NK = 6 * NQ;
+        constexpr int NK = KS;
         constexpr int TF = 3 * NF32;                       // full tiles [0, TF), mixed tiles [TF, NT)
+        // modes 1, 2: bias + one-hot input rows are the accumulators' initial value (loaded per pass: short live ranges)
+        const f32x16* ci = reinterpret_cast<const f32x16*>(lds + L::OFF_CI) + (size_t)sig * NT * 2 + hh;
+        // fragment address and B registers of k-step k
+        auto a_index = [&](int t, int k) {
+            if constexpr (MODE == 1) return (k * NT + t) * 64;
+            else return k < 6 * NQ ? ((t * 3 + ORD[k / NQ][0]) * NQ + k % NQ) * 64 : (NT * 3 * NQ + t) * 64;   // mode 2: special
+        };
+        auto b_reg = [&](int k, int j) -> unsigned {
+            if constexpr (MODE == 1) {
+                const int f = 4 * k + j;                   // flat register list: product by product, NRM registers each
+                return f < 6 * NRM ? R[ORD[f / NRM][1]][f % NRM] : 0u;
+            } else {
+                if (k < 6 * NQ) return R[ORD[k / NQ][1]][4 * (k % NQ) + j];
+                return j < 3 ? R[j][NRM] : 0u;             // mode 2: the special k-step
+            }
+        };
         auto pass = [&](auto lo_c, auto hi_c, auto fill) {
             constexpr int T0 = decltype(lo_c)::value, T1 = decltype(hi_c)::value;
             if constexpr (T1 > T0) {
                 u32x4 cur[T1 - T0], nxt[T1 - T0];
+                if constexpr (MODE != 0) {
 #pragma unroll
-                for (int t = T0; t < T1; ++t) cur[t - T0] = av[((t * 3 + ORD[0][0]) * NQ + 0) * 64];
+                    for (int t = T0; t < T1; ++t) acc[t] = ci[t * 2];
+                }
+#pragma unroll
+                for (int t = T0; t < T1; ++t) cur[t - T0] = av[a_index(t, 0)];
 #pragma unroll
                 for (int k = 0; k < NK; ++k) {
-                    const int o = k / NQ, x = k % NQ;
-                    const int p = ORD[o][1];
                     if (k + 1 < NK) {
-                        const int o2 = (k + 1) / NQ, x2 = (k + 1) % NQ, a2 = ORD[o2][0];
 #pragma unroll
-                        for (int t = T0; t < T1; ++t) nxt[t - T0] = av[((t * 3 + a2) * NQ + x2) * 64];
+                        for (int t = T0; t < T1; ++t) nxt[t - T0] = av[a_index(t, k + 1)];
                     }
-                    const u32x4 bq = {R[p][4 * x], R[p][4 * x + 1], R[p][4 * x + 2], R[p][4 * x + 3]};
+                    const u32x4 bq = {b_reg(k, 0), b_reg(k, 1), b_reg(k, 2), b_reg(k, 3)};
                     const bf16x8 b = __builtin_bit_cast(bf16x8, bq);
 #pragma unroll
                     for (int t = T0; t < T1; ++t)
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur[t - T0]), b,
-                                                                         k == 0 ? zero : acc[t], 0, 0, 0);
+                                                                         (MODE == 0 && k == 0) ? zero : acc[t], 0, 0, 0);
                     fill(k);
                     asm volatile("" ::: "memory");
 #pragma unroll

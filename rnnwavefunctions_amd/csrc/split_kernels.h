@@ -7,9 +7,9 @@
 
 namespace rnnwf {
 
-template <int NF32, int RJ, int WAVES>
+template <int NF32, int RJ, int WAVES, int MODE>
 __global__ void __launch_bounds__(WAVES * 64) prnn_flip_split_kernel(PrnnArgs a, const void* wsplit, int kt16) {
-    using C = SplitCore<NF32, RJ>;
+    using C = SplitCore<NF32, RJ, 1, MODE>;
     using L = typename C::L;
     constexpr int NU = C::NU, NR = C::NR;
     extern __shared__ __attribute__((aligned(16))) char lds[];
