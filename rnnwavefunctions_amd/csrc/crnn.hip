@@ -168,6 +168,7 @@ int j1j2_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
     if (int rc = launch_base(h, a)) return rc;
 
     RNNWF_HIP(h, hipMemsetAsync(cnt, 0, (size_t)N * 4, h->stream));
+    RNNWF_HIP(h, hipMemsetAsync(h->lpq.p, 0, (size_t)ns * 2 * N * sizeof(double2), h->stream));   // contrib: inactive bonds contribute 0
     J1J2Args e{};
     e.bits = (const uint32_t*)h->bits.p;
     e.ns = ns; e.N = N;

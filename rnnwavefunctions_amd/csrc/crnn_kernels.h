@@ -148,7 +148,15 @@ __device__ __forceinline__ int spin_of(const uint32_t* bits, int64_t ns, int64_t
     return (int)((bits[(int64_t)(p >> 5) * ns + s] >> (p & 31)) & 1);
 }
 
-// grid.y = bond slot (0..2N-1), one wave per 64 samples
+// first changed site of bond slot `slot` (J1 bond a -> slot a, J2 bond a -> slot N + a)
+__device__ __forceinline__ int lo_of_block(int N, int slot, int periodic) {
+    const int dist = slot < N ? 1 : 2, site = slot < N ? slot : slot - N;
+    const int t = (site + dist) % N;
+    (void)periodic;
+    return site < t ? site : t;
+}
+
+// grid.y = bond slot (0..2N-1), 256 samples per block
 __global__ void __launch_bounds__(256) j1j2_enumerate_kernel(J1J2Args a) {
     const int N = a.N;
     const int slot = blockIdx.y;
@@ -166,14 +174,25 @@ __global__ void __launch_bounds__(256) j1j2_enumerate_kernel(J1J2Args a) {
         hi = site < t ? t : site;
         active = spin_of(a.bits, a.ns, s, lo) != spin_of(a.bits, a.ns, s, hi);
     }
-    if (in_range) a.contrib[s * (2 * N) + slot] = make_double2(0.0, 0.0);
-    // lo is wave-uniform (it depends on the slot only): one atomic per wave, ballot-ranked slots
+    // (contrib is zeroed by one contiguous memset before the launch: per-thread 16-byte stores at a 2N*16-byte
+    //  stride cost 80 of this kernel's 107 us at config 3)
+    // lo depends on the slot only, i.e. it is uniform over the block: ballot-ranked slots inside each wave, the four
+    // waves' counts combined in LDS, ONE atomic per block (same-address atomics serialise at L2: 314 per counter
+    // with one per wave at config 3, 79 now)
+    __shared__ int wave_cnt[4];
+    __shared__ int block_base;
     const unsigned long long mask = __ballot(active);
-    if (mask) {
-        const int lane = threadIdx.x & 63;
-        int base = 0;
-        if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(&a.cnt[lo], __popcll(mask));
-        base = __shfl(base, __ffsll((long long)mask) - 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_cnt[wave] = __popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        block_base = total ? atomicAdd(&a.cnt[lo_of_block(N, slot, a.periodic)], total) : 0;
+    }
+    __syncthreads();
+    {
+        int base = block_base;
+        for (int w = 0; w < wave; ++w) base += wave_cnt[w];
         if (active) {
             const int k = base + __popcll(mask & ((1ull << lane) - 1ull));
             SwapItem it;
