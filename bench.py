@@ -216,7 +216,10 @@ def main():
         dtype = "f64" if wl["kind"] == "tfim2d" else "f32"
         peak = PEAK_TFLOPS[dtype]
         engine = wf.engine_name()
-        kernel = {"tfim1d": "prnn_flip_kernel", "j1j2": "crnn_swap_kernel", "tfim2d": "mdrnn_flip_kernel"}[wl["kind"]]
+        kernel = {"tfim1d": "prnn_flip_split_kernel" if engine == "bf16x3" else "prnn_flip_kernel",
+                  "j1j2": "crnn_swap_split_kernel" if engine == "bf16x3" else "crnn_swap_kernel",
+                  "tfim2d": "mdrnn_flip_kernel"}[wl["kind"]]
+        traffic = load_traffic(args.workload)
         rec = {
             "metric": "samples*sites/sec (autoregressive sample+local_energy), 1D TFIM N=80 nh=50"
                       if args.workload == "cfg2" else "samples*sites/sec (autoregressive sample+local_energy), " + args.workload,
@@ -229,8 +232,10 @@ def main():
                        "engine": engine},
             "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": (load_traffic(args.workload) or {}).get("hbm_bytes_per_launch"),
-                         "traffic_detail": load_traffic(args.workload),
+                         "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
+                         "traffic_detail": traffic,
+                         "hbm_frac_of_8TBps": ((traffic["hbm_bytes_per_launch"] / (flip_ms * 1e-3) / 8e12)
+                                               if traffic and flip_ms > 0 else None),
                          "algorithmic_flops_per_launch": alg_flops_per_launch,
                          "mfma_flops_issued_per_launch": flip["mfma_flops"] / launches,
                          "avg_launch_ms": flip_ms,
