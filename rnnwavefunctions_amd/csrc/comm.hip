@@ -3,7 +3,9 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "models.h"
@@ -26,7 +28,12 @@ struct Rccl {
     std::string err;
     bool load() {
         if (lib) return true;
-        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // The RCCL of the ROCm installation this library's HIP runtime comes from, by absolute path first: a process
+        // that imported PyTorch already holds torch's bundled librccl (built against torch's own bundled HIP runtime),
+        // and a by-name dlopen would hand that one back - two HIP runtimes would then share device pointers.
+        std::string rocm = getenv("ROCM_PATH") ? getenv("ROCM_PATH") : "/opt/rocm";
+        const std::string abs1 = rocm + "/lib/librccl.so.1";
+        const char* names[] = {abs1.c_str(), "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
         for (const char* n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
         if (!lib) { err = std::string("dlopen(librccl.so) failed: ") + dlerror(); return false; }
         get_unique_id = (GetUniqueId_t)dlsym(lib, "ncclGetUniqueId");

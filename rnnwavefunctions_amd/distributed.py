@@ -124,9 +124,13 @@ def init_rccl_from_env(native, dist=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1:
         return rank, world
+    uid = native.comm_unique_id()         # every rank: loads RCCL now (before torch, if torch is not in yet); rank 0's id is used
     if dist is None:
         import torch.distributed as dist
-    box = [native.comm_unique_id() if rank == 0 else None]
+        if not dist.is_initialized():
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            dist.init_process_group(backend="gloo")
+    box = [uid if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
     native.comm_init(box[0], rank, world)
     return rank, world
