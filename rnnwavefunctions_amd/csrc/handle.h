@@ -61,6 +61,9 @@ struct rnnwf_handle {
     // bf16x3 engine (split_core.h): second weight image; engine_split = use it for the flip pass
     rnnwf::DevBuf wsplit;
     bool engine_split = false;
+    bool engine_forced = false;   // RNNWF_ENGINE=bf16x3: no small-batch fallback to the f32-input MFMA
+    int64_t call_ns = 0;          // samples of the whole API call (a call may run several passes: one engine for all)
+    int last_flip_engine = -1;    // engine of the last flip / swap launch (1 bf16x3, 0 f32-input MFMA), -1 none yet
     std::map<std::string, std::vector<double>> grads;
     int64_t last_ns = 0;          // batch of the last rnnwf_vmc_step still resident (bits, hck, eloc)
     bool last_has_ckpt = false;

@@ -238,6 +238,17 @@ int ensure_reverse_map(rnnwf_handle* h) {
     return 0;
 }
 
+// bf16x3 or f32-input MFMA for this flip pass?  The bf16x3 kernel works on 32-chain tiles; when there are not enough
+// of them for two waves per SIMD (config 1: 304 tiles for 1 024 SIMDs) the 16-chain f32 kernel fills the chip better
+// (measured 0.0198 vs 0.0223 ms at config 1).  RNNWF_ENGINE=bf16x3 pins the bf16x3 engine.
+bool use_split(rnnwf_handle* h, int64_t ns_pass) {
+    const int64_t ns = std::max<int64_t>(h->call_ns, ns_pass);     // the whole call decides, not the pass
+    const int64_t tiles32 = (int64_t)(h->N - 1) * ((ns + 31) / 32);
+    const bool split = h->engine_split && (h->engine_forced || tiles32 >= (int64_t)8 * h->cu_count);
+    h->last_flip_engine = split ? 1 : 0;
+    return split;
+}
+
 // Fused local energies of ns chains whose packed spins are already in h->bits (and, for the parity
 // model, reversed in h->bits2): base pass with checkpoints -> flip pass -> assembly.  Leaves E_loc in
 // h->eloc and the log-prob queue in h->lpq.
@@ -262,7 +273,7 @@ int eloc_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
         a.ntiles = (int64_t)(N - 1) * nsb;
         a.sampling = 0;
         if (const char* e = getenv("RNNWF_ABLATE")) a.ablate |= atoi(e) & 7;   // diagnostics only
-        if (h->engine_split) {
+        if (use_split(h, ns)) {
             if (int rc = launch_flip_split(h, a)) return rc;
             h->work[1] += (double)((ns + 31) / 32) * N * (N - 1) / 2.0 * split_mfma_flops_per_step(h);
         } else {
@@ -287,7 +298,7 @@ int eloc_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
         if (int rc = launch_base(h, b)) return rc;
         if (Bx != 0.0 && N > 1) {
             b.ntiles = (int64_t)(N - 1) * nsb;
-            if (h->engine_split) {
+            if (use_split(h, ns)) {
                 if (int rc = launch_flip_split(h, b)) return rc;
                 h->work[1] += (double)((ns + 31) / 32) * N * (N - 1) / 2.0 * split_mfma_flops_per_step(h);
             } else {
@@ -316,6 +327,7 @@ int rnnwf::prnn_pack_image(rnnwf_handle* h, std::vector<char>& img) {
     // f32-input MFMA everywhere); the base pass, sampling and log_probability always run the f32-MFMA kernels
     const char* eng = getenv("RNNWF_ENGINE");
     h->engine_split = !h->f64 && h->NL == 1 && h->NFULL <= 4 && !(eng && std::string(eng) == "f32");
+    h->engine_forced = eng && std::string(eng) == "bf16x3";
     if (h->engine_split) {
         std::vector<char> simg;
         SPLIT_DISPATCH(h, { simg = K::pack(h); break; });
@@ -389,6 +401,7 @@ int rnnwf::prnn_tfim_eloc(rnnwf_handle* h, const int32_t* samples, int64_t ns, i
                           double Bx, double* eloc, double* log_probs) {
     const int N = h->N;
     h->last_ns = 0;
+    h->call_ns = ns;
     if (int rc = upload_couplings(h, Jz, (size_t)N)) return rc;
     const int64_t chunk = max_chains_per_pass(h);
     for (int64_t off = 0; off < ns; off += chunk) {
@@ -413,6 +426,7 @@ int rnnwf::prnn_vmc_step(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t st
     if (ns > max_chains_per_pass(h))
         return h->fail(RNNWF_ERR_NOMEM, "rnnwf_vmc_step: %lld samples exceed the checkpoint budget; split the batch",
                        (long long)ns);
+    h->call_ns = ns;
     if (int rc = ensure(h, h->bits, (size_t)W * ns * 4)) return rc;
     if (int rc = upload_couplings(h, couplings, (size_t)N)) return rc;
     const double Bx = couplings[N];

@@ -459,6 +459,7 @@ extern "C" int rnnwf_timing_get(rnnwf_handle* h, int32_t id, double* total_ms, i
 extern "C" const char* rnnwf_engine_name(const rnnwf_handle* h) {
     if (!h) return "";
     if (h->f64) return "f64mfma";
+    if (h->last_flip_engine >= 0 && h->model != RNNWF_MODEL_CRNN_U1) return h->last_flip_engine ? "bf16x3" : "f32mfma";
     return h->engine_split ? "bf16x3" : "f32mfma";
 }
 

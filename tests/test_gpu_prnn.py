@@ -267,6 +267,7 @@ def test_both_flip_engines_agree_with_the_f64_oracle(N, H, ns, monkeypatch):
         wf = make_wf(_lib.MODEL_GRU1D, N, H, prm)            # the engine is chosen when the parameters are committed
         lp = np.zeros((N + 1) * ns)
         e = wf.tfim_eloc(s, Jz, 1.1, log_probs=lp)
+        assert wf.engine_name() == ("bf16x3" if engine == "bf16x3" else "f32mfma")   # RNNWF_ENGINE pins the engine
         got[engine] = (e, lp)
         err_lp = np.abs(lp - lp64.ravel()).max()
         err_e = np.abs(e / e64 - 1).max()
@@ -274,6 +275,11 @@ def test_both_flip_engines_agree_with_the_f64_oracle(N, H, ns, monkeypatch):
         assert err_lp <= 2e-6 * N + 2e-6
         assert err_e <= 2e-5
     assert np.allclose(got["f32"][0], got["bf16x3"][0], rtol=2e-5)
+    # without RNNWF_ENGINE a batch this small (fewer 32-chain tiles than two waves per SIMD) takes the 16-chain f32 kernel
+    monkeypatch.delenv("RNNWF_ENGINE")
+    wf = make_wf(_lib.MODEL_GRU1D, N, H, prm)
+    e = wf.tfim_eloc(s, Jz, 1.1)
+    assert wf.engine_name() == "f32mfma" and np.array_equal(e, got["f32"][0])
 
 
 # ---- stacked layers (units = [h] * num_layers, 1DTFIM/TrainingRNN_1DTFIM.py:98; MultiRNNCell, RNNwavefunction.py:32) ----
