@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(WAVES * 64, NFULL <= 3 ? 2 : 1) mdrnn_flip_ker
         for (int w = 0; w < 8; ++w) words[w] = w < W ? a.bits[(int64_t)w * a.ns + sc] : 0u;
 #pragma unroll
         for (int w = 0; w < 8; ++w) if (w == (i >> 5)) words[w] ^= 1u << (i & 31);    // the flipped configuration
-        double hh[KT], hv[KT], hn[KT];
+        double hv[KT], hn[KT];
         C::load_state(a.hs + (((int64_t)i * a.nsb + sb) * C::KP) * 128 + 2 * lane, hn);   // state after position i (unchanged)
         // h_v operand of position p: zero (first row), the state just computed (row turn), a base-pass state
         // (pv <= i) or one this chain produced (ring).  (Fetching one step ahead, behind the previous position's
@@ -303,9 +303,11 @@ __global__ void __launch_bounds__(WAVES * 64, NFULL <= 3 ? 2 : 1) mdrnn_flip_ker
         for (int p = i + 1; p < N; ++p) {
             const int pv = a.vert_pos[p];
             const bool first = a.row_first[p] != 0;
-            fetch_v(p);
+            fetch_v(p);                            // (a row turn copies hn into hv here, before hn is cleared)
+            if (first) {                           // no horizontal neighbour: uniform, once per row
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) hh[kt] = first ? 0.0 : hn[kt];
+                for (int kt = 0; kt < KT; ++kt) hn[kt] = 0.0;
+            }
             uint32_t wq = 0;
 #pragma unroll
             for (int w = 0; w < 8; ++w) if (w == ((p - 1) >> 5)) wq = words[w];
@@ -317,7 +319,7 @@ __global__ void __launch_bounds__(WAVES * 64, NFULL <= 3 ? 2 : 1) mdrnn_flip_ker
                 for (int w = 0; w < 8; ++w) if (w == (pv >> 5)) wv = words[w];
                 sig_v = (wv >> (pv & 31)) & 1;
             }
-            C::step(lds, sig_h, sig_v, hh, hv, hn, lane, a.rem);
+            C::step(lds, sig_h, sig_v, hn, hv, hn, lane, a.rem);      // in place: step copies its inputs first
             double lp0 = hn[0], lp1 = hn[1], p0;
             if (!(a.ablate & 4)) C::head(lds, hn, lane, lp0, lp1, p0);
             uint32_t wp = 0;
