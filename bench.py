@@ -59,6 +59,7 @@ def f_cell(wl):
 def make_wavefunction(wl, device):
     from rnnwavefunctions_amd import _lib, params as P
     N, H = wl["N"], wl["H"]
+    scale = 3.0 if wl.get("weights") == "trained" else 1.0    # "trained-like" = kernels x 3
     if wl["kind"] == "j1j2":
         prm = P.init_gru_params([H], seed=111, heads=("wf_dense_ampl", "wf_dense_phase"))
         wf = _lib.NativeWavefunction(_lib.MODEL_CRNN_U1, N, 1, (H,), device=device)
@@ -71,6 +72,8 @@ def make_wavefunction(wl, device):
         prm = P.init_gru_params([H], seed=111)
         wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D, N, 1, (H,), device=device)
         couplings = np.append(np.ones(N), wl["Bx"])
+    if scale != 1.0:
+        prm = P.scale_kernels(prm, scale)
     wf.set_params(prm, scope="RNNwavefunction")
     return wf, prm, couplings
 
@@ -93,9 +96,26 @@ def cpu_baseline(wl, prm, target_seconds=15.0):
     t0 = time.perf_counter()
     cport.ising_local_energies(prm, np.ones(N), wl["Bx"], s, nthreads=threads)
     dt = time.perf_counter() - t0
+    # also at one thread (a smaller sample, ~5 s), with the host's CPU model and the flags
+    ns_1 = int(min(ns_cpu, max(8, rate / threads * 5.0)))
+    t0 = time.perf_counter()
+    cport.ising_local_energies(prm, np.ones(N), wl["Bx"], s[:ns_1], nthreads=1)
+    dt1 = time.perf_counter() - t0
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {"value": ns_cpu * N / dt, "unit": "samples*sites/s", "cores": threads, "kind": "port",
             "sample": "%d of %d samples of the same workload, reference formulation ((N+1)*ns chains from site 0, "
-                      "<=25000-row chunks), C/OpenMP restatement oracle/c/rnnwf_oracle.c, %.1f s" % (ns_cpu, ns_full, dt)}
+                      "<=25000-row chunks), C/OpenMP restatement oracle/c/rnnwf_oracle.c, %.1f s" % (ns_cpu, ns_full, dt),
+            "one_thread": {"value": ns_1 * N / dt1, "samples": ns_1, "seconds": dt1},
+            "cpu_model": model, "nproc": os.cpu_count(),
+            "compiler": "gcc -O3 -march=native -fopenmp -fno-math-errno -ffp-contract=off (oracle/cport.py)"}
 
 
 def alt_engine_run(wl, couplings, warmup, steps):
@@ -141,6 +161,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--numsamples", type=int, default=0, help="per-GPU batch override")
+    ap.add_argument("--weights", default="init", choices=("init", "trained"),
+                    help="init: glorot-uniform as initialised; trained: kernels x 3 (sharper conditionals)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-engine", action="store_true", help="skip the extra f32-input-MFMA timing")
     args = ap.parse_args()
@@ -153,6 +175,7 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.numsamples:
         wl["ns"] = args.numsamples
+    wl["weights"] = args.weights
 
     # Load order matters: the product library (and RCCL, which it dlopens) come first so that the HIP runtime
     # in this process is /opt/rocm's; torch (which bundles its own copies) is imported afterwards and only for
@@ -228,7 +251,8 @@ def main():
             "dtype": dtype, "data": "synthetic",
             "config": {"workload": wl["desc"], "numsamples_per_gpu": ns, "global_numsamples": ns * world,
                        "sites": N, "num_units": wl["H"], "parallelism": "dp%d (sample shards, 1 RCCL all-reduce/step)" % world,
-                       "weights": "glorot-uniform RandomState(111), gate bias 1", "mean_E": mean_e, "var_E": var_e,
+                       "weights": "glorot-uniform RandomState(111), gate bias 1" + (", kernels x 3 (trained-like)" if args.weights == "trained" else ""),
+                       "mean_E": mean_e, "var_E": var_e,
                        "engine": engine},
             "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak,
