@@ -187,8 +187,10 @@ struct SplitCore {
                 const int f = 4 * k + j;                   // flat register list: product by product, NRM registers each
                 return f < 6 * NRM ? R[ORD[f / NRM][1]][f % NRM] : 0u;
             } else {
-                if (k < 6 * NQ) return R[ORD[k / NQ][1]][4 * (k % NQ) + j];
-                return j < 3 ? R[j][NRM] : 0u;             // mode 2: the special k-step
+                if constexpr (MODE == 2) {
+                    if (k >= 6 * NQ) return j < 3 ? R[j][NRM] : 0u;     // the special k-step
+                }
+                return R[ORD[k / NQ][1]][4 * (k % NQ) + j];
             }
         };
         auto pass = [&](auto lo_c, auto hi_c, auto fill) {
