@@ -35,6 +35,8 @@ WORKLOADS = {
                  desc="J1J2 cRNN N=40 J2=0.5 U(1) mask num_units=50 numsamples=10000 (BASELINE config 3)"),
     "cfg4": dict(kind="tfim2d", Nx=12, Ny=12, N=144, H=50, ns=10000, Bx=3.0,
                  desc="2DTFIM_2DRNN 12x12 MDRNNcell num_units=50 numsamples=10000, f64 (BASELINE config 4)"),
+    "2d1drnn": dict(kind="tfim2d_gru", Nx=12, Ny=12, N=144, H=50, ns=10000, Bx=3.0,
+                    desc="2DTFIM_1DRNN 12x12 GRU over the raster path num_units=50 numsamples=10000, f64 (not a BASELINE config)"),
     "cfg5": dict(kind="tfim1d", N=200, H=100, ns=32768, Bx=1.0,
                  desc="1DTFIM pRNN N=200 num_units=100 numsamples=32768 per GPU (BASELINE config 5 shard)"),
 }
@@ -64,6 +66,10 @@ def make_wavefunction(wl, device):
         prm = P.init_gru_params([H], seed=111, heads=("wf_dense_ampl", "wf_dense_phase"))
         wf = _lib.NativeWavefunction(_lib.MODEL_CRNN_U1, N, 1, (H,), device=device)
         couplings = np.concatenate([np.ones(N), wl["J2"] * np.ones(N), np.zeros(N), [0.0, 0.0]])
+    elif wl["kind"] == "tfim2d_gru":
+        prm = P.init_gru_params([H], seed=111, dtype=np.float64)
+        wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D_F64, wl["Nx"], wl["Ny"], (H,), device=device)
+        couplings = np.append(np.ones(N), wl["Bx"])
     elif wl["kind"] == "tfim2d":
         prm = P.init_mdrnn_params(H, seed=111)
         wf = _lib.NativeWavefunction(_lib.MODEL_MDRNN2D, wl["Nx"], wl["Ny"], (H,), device=device)
@@ -236,12 +242,12 @@ def main():
         alg_flops_per_launch = flip["cell_evals"] / launches * f_cell(wl)
         flip_ms = flip["total_ms"] / launches
         achieved = alg_flops_per_launch / (flip_ms * 1e-3) / 1e12 if flip_ms > 0 else 0.0
-        dtype = "f64" if wl["kind"] == "tfim2d" else "f32"
+        dtype = "f64" if wl["kind"] in ("tfim2d", "tfim2d_gru") else "f32"
         peak = PEAK_TFLOPS[dtype]
         engine = wf.engine_name()
         kernel = {"tfim1d": "prnn_flip_split_kernel" if engine == "bf16x3" else "prnn_flip_kernel",
                   "j1j2": "crnn_swap_split_kernel" if engine == "bf16x3" else "crnn_swap_kernel",
-                  "tfim2d": "mdrnn_flip_kernel"}[wl["kind"]]
+                  "tfim2d": "mdrnn_flip_kernel", "tfim2d_gru": "prnn_flip_kernel<double>"}[wl["kind"]]
         traffic = load_traffic(args.workload)
         rec = {
             "metric": "samples*sites/sec (autoregressive sample+local_energy), 1D TFIM N=80 nh=50"

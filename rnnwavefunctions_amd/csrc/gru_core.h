@@ -30,8 +30,23 @@ template <> struct Act<float> {
 template <> struct Act<double> {
     static constexpr double kGateScale = 1.0;
     static constexpr double kCandScale = 1.0;
-    static __device__ __forceinline__ double sigmoid_scaled(double a) { return 1.0 / (1.0 + exp(-a)); }
-    static __device__ __forceinline__ double tanh_scaled(double p) { return tanh(p); }
+    // f64 without ocml's special-case handling: exp_fast (20 instructions, device.h) and a reciprocal from v_rcp_f64
+    // plus two Newton steps (5 instructions) instead of exp (~40) + IEEE division (~15) and tanh (~60 with branches);
+    // relative error < 1e-15, i.e. the level of the f64 oracle's own libm.  2DTFIM_1DRNN flip pass 58 -> see DESIGN.md.
+    static __device__ __forceinline__ double rcp_fast(double d) {
+        double y = __builtin_amdgcn_rcp(d);
+        double e = __builtin_fma(-d, y, 1.0);
+        y = __builtin_fma(y, e, y);
+        e = __builtin_fma(-d, y, 1.0);
+        return __builtin_fma(y, e, y);
+    }
+    static __device__ __forceinline__ double sigmoid_scaled(double a) {
+        const double x = a > 700.0 ? 700.0 : a;                    // exp_fast clamps the other side
+        return rcp_fast(1.0 + exp_fast(-x));
+    }
+    static __device__ __forceinline__ double tanh_scaled(double p) {
+        return __builtin_fma(2.0, sigmoid_scaled(2.0 * p), -1.0);    // absolute error ~1e-16 (the state update adds, never divides)
+    }
 };
 
 // log-probabilities of a two-way softmax from the logit difference d = z1 - z0:
