@@ -89,6 +89,12 @@ int rnnwf_abi_version(void);
 int rnnwf_set_param(rnnwf_handle* h, const char* tf_name, const void* data, int64_t count, int32_t dtype);
 int rnnwf_get_param(rnnwf_handle* h, const char* tf_name, void* data, int64_t count, int32_t dtype);
 int rnnwf_commit_params(rnnwf_handle* h);
+/* rnnwf_init_params <- sess.run(tf.global_variables_initializer()) (1DTFIM/TrainingRNN_1DTFIM.py:168): glorot/xavier-
+ * uniform kernels, gate bias 1, other biases 0 (MDRNN: all tensors xavier, MDRNNcell.py:21-35), drawn in the order
+ * and with the generator of the Python side (numpy.random.RandomState(seed): MT19937, 53-bit doubles), so C and
+ * Python callers start from identical weights; commits.  TensorFlow's own seeded draws are not reproducible outside
+ * TF ("parity unpinned").  seed must fit 32 bits. */
+int rnnwf_init_params(rnnwf_handle* h, uint64_t seed);
 /* Number of scalar parameters (the count the reference prints, TrainingRNN_1DTFIM.py:127-136). */
 int64_t rnnwf_num_params(const rnnwf_handle* h);
 

@@ -38,6 +38,7 @@ PROTOTYPES = {
     "rnnwf_set_param": (C.c_int, [_P, C.c_char_p, _P, _I64, _I32]),
     "rnnwf_get_param": (C.c_int, [_P, C.c_char_p, _P, _I64, _I32]),
     "rnnwf_commit_params": (C.c_int, [_P]),
+    "rnnwf_init_params": (C.c_int, [_P, C.c_uint64]),
     "rnnwf_num_params": (_I64, [_P]),
     "rnnwf_sample": (C.c_int, [_P, _I64, _U64, _U64, _I64, _I32P, _F64P]),
     "rnnwf_log_prob": (C.c_int, [_P, _I32P, _I64, _F64P]),
@@ -156,6 +157,11 @@ class NativeWavefunction:
                 dt = F64
             self._check(self.lib.rnnwf_set_param(self.h, name.encode(), v.ctypes.data_as(_P), v.size, dt))
         self._check(self.lib.rnnwf_commit_params(self.h))
+
+    def init_params(self, seed):
+        """Glorot-uniform kernels, gate bias 1, other biases 0 - the values of params.init_gru_params /
+        init_mdrnn_params for the same seed, generated inside the library (C callers have no NumPy)."""
+        self._check(self.lib.rnnwf_init_params(self.h, int(seed)))
 
     def get_param(self, name, shape, dtype=np.float64):
         out = np.empty(shape, dtype=dtype)

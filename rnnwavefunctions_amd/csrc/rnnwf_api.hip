@@ -6,6 +6,7 @@
 #include <cstring>
 
 #include "handle.h"
+#include "init_params.h"
 #include "models.h"
 #include "pack.h"
 #include "util_kernels.h"
@@ -229,6 +230,55 @@ extern "C" int64_t rnnwf_num_params(const rnnwf_handle* h) {
     int64_t n = 0;
     if (h) for (auto& kv : h->params) n += (int64_t)kv.second.value.size();
     return n;
+}
+
+extern "C" int rnnwf_init_params(rnnwf_handle* h, uint64_t seed) {
+    if (!h) return RNNWF_ERR_INVALID;
+    if (seed > 0xffffffffull) return h->fail(RNNWF_ERR_INVALID, "rnnwf_init_params: seed must fit 32 bits (numpy.random.RandomState)");
+    NumpyRandomState rng((uint32_t)seed);
+    const int64_t H = h->H;
+    const bool f32 = !h->f64;
+    auto draw = [&](const std::string& name, int64_t rows, int64_t cols, bool vector = false) {
+        glorot_fill(rng, rows, cols, vector, f32, h->params.at(name).value);
+        h->params.at(name).set = true;
+    };
+    auto constant = [&](const std::string& name, double v) {
+        auto& p = h->params.at(name);
+        std::fill(p.value.begin(), p.value.end(), v);
+        p.set = true;
+    };
+    if (h->model == RNNWF_MODEL_MDRNN2D) {                 // params.init_mdrnn_params: every tensor xavier, incl. b
+        draw("Wh_rnn_0", H, H);
+        draw("Uh_rnn_0", 2, H);
+        draw("Wv_rnn_0", H, H);
+        draw("Uv_rnn_0", 2, H);
+        draw("b_rnn_0", 1, H, true);
+        draw("wf_dense/kernel", H, 2);
+        constant("wf_dense/bias", 0.0);
+    } else {                                               // params.init_gru_params
+        int64_t d = 2;
+        for (int l = 0; l < h->NL; ++l) {
+            const std::string pre = "multi_rnn_cell/cell_" + std::to_string(l) + "/cudnn_compatible_gru_cell/";
+            draw(pre + "gates/kernel", d + H, 2 * H);
+            constant(pre + "gates/bias", 1.0);
+            draw(pre + "candidate/input_projection/kernel", d, H);
+            constant(pre + "candidate/input_projection/bias", 0.0);
+            draw(pre + "candidate/hidden_projection/kernel", H, H);
+            constant(pre + "candidate/hidden_projection/bias", 0.0);
+            d = H;
+        }
+        if (h->model == RNNWF_MODEL_CRNN_U1) {
+            draw("wf_dense_ampl/kernel", H, 2);
+            constant("wf_dense_ampl/bias", 0.0);
+            draw("wf_dense_phase/kernel", H, 2);
+            constant("wf_dense_phase/bias", 0.0);
+        } else {
+            draw("wf_dense/kernel", H, 2);
+            constant("wf_dense/bias", 0.0);
+        }
+    }
+    h->committed = false;
+    return rnnwf_commit_params(h);
 }
 
 extern "C" int rnnwf_commit_params(rnnwf_handle* h) {

@@ -85,3 +85,26 @@ def test_2dtfim_1drnn_facade(golden_estimators):
     s = g["g4c_samples"]
     e = Ising2D_local_energies(g["g4c_Jz"], float(g["g4c_Bx"]), Nx, Ny, s, None, t, ph, None, tf.Session())
     assert np.allclose(e, g["g4c_eloc"], rtol=1e-10)
+
+
+def test_init_params_in_the_library_equals_the_python_initialiser():
+    """rnnwf_init_params (C ABI) and params.init_* (Python) share generator, draw order and rounding."""
+    from rnnwavefunctions_amd import _lib
+    from rnnwavefunctions_amd import params as P
+    cases = [(_lib.MODEL_GRU1D, (10, 1), (12,), lambda s: P.init_gru_params([12], seed=s)),
+             (_lib.MODEL_GRU1D, (10, 1), (8, 8), lambda s: P.init_gru_params([8, 8], seed=s)),
+             (_lib.MODEL_CRNN_U1, (10, 1), (9,), lambda s: P.init_gru_params([9], seed=s, heads=("wf_dense_ampl", "wf_dense_phase"))),
+             (_lib.MODEL_GRU1D_F64, (3, 4), (7,), lambda s: P.init_gru_params([7], seed=s, dtype=np.float64)),
+             (_lib.MODEL_MDRNN2D, (3, 3), (6,), lambda s: P.init_mdrnn_params(6, seed=s))]
+    for model, (nx, ny), units, make in cases:
+        wf = _lib.NativeWavefunction(model, nx, ny, units)
+        wf.init_params(111)
+        ref = make(111)
+        assert wf.num_params() == P.count_params(ref)
+        for name, v in ref.items():
+            got = wf.get_param(name[len("RNNwavefunction/"):], v.shape, dtype=np.float64)
+            assert np.array_equal(got, v.astype(np.float64)), name
+        s = wf.sample(8, seed=1, step=0)                       # committed: usable at once
+        assert s.shape[0] == 8
+    with pytest.raises(ValueError, match="32 bits"):
+        wf.init_params(2 ** 33)

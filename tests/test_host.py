@@ -129,3 +129,37 @@ def test_bench_helpers():
     import bench
     assert bench.f_cell_gru(50) == 15800 and bench.f_cell_gru(100) == 61600
     assert bench.WORKLOADS["cfg2"]["N"] == 80 and bench.WORKLOADS["cfg2"]["H"] == 50
+
+
+def test_c_side_initialiser_reproduces_numpy_randomstate(tmp_path):
+    """csrc/init_params.h (MT19937 + genrand_res53 + glorot limits) against numpy.random.RandomState, bit for bit:
+    rnnwf_init_params must give a C caller the weights params.init_gru_params gives a Python caller."""
+    import ctypes as C
+    import subprocess
+    src = tmp_path / "shim.cpp"
+    src.write_text('#include "init_params.h"\n'
+                   'extern "C" void fill(unsigned seed, long rows, long cols, int vec, int f32, int skip, double* out) {\n'
+                   '    rnnwf::NumpyRandomState r(seed);\n'
+                   '    for (int i = 0; i < skip; ++i) r.next_double();\n'
+                   '    std::vector<double> v; rnnwf::glorot_fill(r, rows, cols, vec, f32, v);\n'
+                   '    for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];\n}\n')
+    so = tmp_path / "shim.so"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-I", os.path.join(ROOT, "rnnwavefunctions_amd", "csrc"),
+                    str(src), "-o", str(so)], check=True)
+    lib = C.CDLL(str(so))
+    from rnnwavefunctions_amd import params as P
+    for seed in (0, 111, 2 ** 32 - 1):
+        prm = P.init_gru_params([7], seed=seed)                      # first tensor: gates/kernel [9, 14], float32
+        first = prm["RNNwavefunction/multi_rnn_cell/cell_0/cudnn_compatible_gru_cell/gates/kernel"]
+        out = np.empty(first.size)
+        lib.fill(C.c_uint(seed), C.c_long(9), C.c_long(14), 0, 1, 0, out.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(out.reshape(9, 14).astype(np.float32), first)
+        # second drawn tensor starts 9*14 doubles later in the stream
+        second = prm["RNNwavefunction/multi_rnn_cell/cell_0/cudnn_compatible_gru_cell/candidate/input_projection/kernel"]
+        out2 = np.empty(second.size)
+        lib.fill(C.c_uint(seed), C.c_long(2), C.c_long(7), 0, 1, 9 * 14, out2.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(out2.reshape(2, 7).astype(np.float32), second)
+    b = P.init_mdrnn_params(5, seed=3)["RNNwavefunction/b_rnn_0"]     # 1-D xavier, float64, after 2*(25+10) draws
+    out = np.empty(5)
+    lib.fill(C.c_uint(3), C.c_long(1), C.c_long(5), 1, 0, 2 * (25 + 10), out.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(out, b)
