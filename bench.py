@@ -171,6 +171,10 @@ def main():
                     help="init: glorot-uniform as initialised; trained: kernels x 3 (sharper conditionals)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-engine", action="store_true", help="skip the extra f32-input-MFMA timing")
+    ap.add_argument("--transport", default="rccl", choices=("rccl", "gloo"),
+                    help="all-reduce of the moments: RCCL over xGMI (default) or the launcher's gloo group (rehearsal of "
+                         "the multi-rank control flow on a box whose GPUs cannot host one rank each)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank on device 0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -187,16 +191,21 @@ def main():
     # in this process is /opt/rocm's; torch (which bundles its own copies) is imported afterwards and only for
     # the launcher's CPU-side rendezvous.
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    wf, prm, couplings = make_wavefunction(wl, device=local_rank)
+    wf, prm, couplings = make_wavefunction(wl, device=0 if args.same_device else local_rank)
     dist = None
+    gloo_reduce = None
     if world > 1:
-        uid = wf.comm_unique_id()             # every rank: loads librccl now; only rank 0's id is used
+        uid = wf.comm_unique_id() if args.transport == "rccl" else None   # every rank: loads librccl now; rank 0's id is used
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         import torch.distributed as dist      # launcher plumbing only: gloo rendezvous + barrier on CPU
         dist.init_process_group(backend="gloo")
-        box = [uid if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        wf.comm_init(box[0], rank, world)
+        if args.transport == "rccl":
+            box = [uid if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            wf.comm_init(box[0], rank, world)
+        else:
+            from rnnwavefunctions_amd.distributed import ShardComm
+            gloo_reduce = ShardComm.from_torch().allreduce
 
     ns, N = wl["ns"], wl["N"]
     offset = rank * ns                       # global sample indices of this shard
@@ -204,8 +213,8 @@ def main():
     def step(it):
         out = wf.vmc_step(ns, seed=111, step=it, couplings=couplings, sample_offset=offset)
         m = out["moments"]
-        if world > 1:
-            m = wf.allreduce_moments(m)       # ONE RCCL all-reduce: (sum E, sum E^2, n, sum Im E)
+        if world > 1:                         # ONE all-reduce: (sum E, sum E^2, n, sum Im E)
+            m = gloo_reduce(m) if gloo_reduce else wf.allreduce_moments(m)
         return m
 
     def barrier():
@@ -256,7 +265,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
             "config": {"workload": wl["desc"], "numsamples_per_gpu": ns, "global_numsamples": ns * world,
-                       "sites": N, "num_units": wl["H"], "parallelism": "dp%d (sample shards, 1 RCCL all-reduce/step)" % world,
+                       "sites": N, "num_units": wl["H"], "parallelism": "dp%d (sample shards, 1 %s all-reduce/step)" % (world, "RCCL" if args.transport == "rccl" else "gloo"),
                        "weights": "glorot-uniform RandomState(111), gate bias 1" + (", kernels x 3 (trained-like)" if args.weights == "trained" else ""),
                        "mean_E": mean_e, "var_E": var_e,
                        "engine": engine},
