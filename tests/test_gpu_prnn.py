@@ -430,3 +430,31 @@ def test_cooperative_base_pass_is_bit_identical(N, H, ns, monkeypatch):
     monkeypatch.delenv("RNNWF_NO_COOP")
     assert np.array_equal(s1, s2) and np.array_equal(lg1, lg2)
     assert np.array_equal(lp1, lp2) and np.array_equal(e1, e2)
+
+
+def test_config5_shard_at_full_size():
+    """BASELINE config 5, one GPU's shard (N=200, h=100, 32 768 samples; f32-input MFMA engine): the per-site energy
+    against the oracle on a subset of the same samples, and the size-independent properties - the two half shards
+    drawn with their sample offsets are the full shard (samples AND local energies, bit for bit), the moments are the
+    sums of the local energies."""
+    from rnnwavefunctions_amd import _lib
+    N, H, ns = 200, 100, 32768
+    prm = P.init_gru_params([H], seed=111)
+    wf = make_wf(_lib.MODEL_GRU1D, N, H, prm)
+    Jz = np.ones(N)
+    c = np.append(Jz, 1.0)
+    out = wf.vmc_step(ns, seed=111, step=2, couplings=c, want_samples=True, want_eloc=True)
+    s, e, m = out["samples"], out["eloc"], out["moments"]
+    assert wf.engine_name() == "f32mfma"
+    assert np.all(np.isfinite(e)) and m[2] == ns
+    assert np.isclose(m[0], e.sum(), rtol=1e-12) and np.isclose(m[1], (e * e).sum(), rtol=1e-12)
+    lo = wf.vmc_step(ns // 2, seed=111, step=2, couplings=c, want_samples=True, want_eloc=True)
+    hi = wf.vmc_step(ns // 2, seed=111, step=2, couplings=c, sample_offset=ns // 2, want_samples=True, want_eloc=True)
+    assert np.array_equal(np.concatenate([lo["samples"], hi["samples"]]), s)
+    assert np.array_equal(np.concatenate([lo["eloc"], hi["eloc"]]), e)
+    assert np.allclose(lo["moments"] + hi["moments"], m, rtol=1e-12)
+    sub = np.arange(0, ns, ns // 6)[:6]
+    e_ref = E.ising_local_energies(Jz, 1.0, s[sub], lambda x: M.prnn_log_probability(prm, x))
+    per_site = np.abs(e[sub] - e_ref).max() / N
+    print("cfg5 shard: <E>/N = %.6f, max |E_loc - oracle|/N over 6 samples = %.2e" % (e.mean() / N, per_site))
+    assert per_site < 1e-4
