@@ -27,7 +27,26 @@ struct CLaunch {
         *out = std::max(nb, 1);
         return 0;
     }
+    static int base_coop(rnnwf_handle* h, const CrnnArgs& a) {
+        if constexpr (NFULL <= 4) {
+            static int bpc = 0;
+            const void* fn = (const void*)crnn_base_coop_kernel<NFULL>;
+            const size_t lds = L::BYTES + (size_t)2 * L::KT * 64 * 4 + 2 * 64 * 4;
+            if (!bpc) {
+                RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                RNNWF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, (NFULL + 1) * 64, lds));
+                bpc = std::max(bpc, 1);
+            }
+            const unsigned grid = (unsigned)std::min<int64_t>(a.nsb, (int64_t)bpc * h->cu_count);
+            TimedLaunch tl(h, 0);
+            crnn_base_coop_kernel<NFULL><<<grid, (NFULL + 1) * 64, lds, h->stream>>>(a);
+            RNNWF_HIP(h, hipGetLastError());
+        }
+        return 0;
+    }
     static int base(rnnwf_handle* h, const CrnnArgs& a) {
+        // fewer 16-chain blocks than SIMDs: the cooperative kernel (NFULL + 1 waves per block, bit-identical)
+        if (NFULL <= 4 && a.nsb <= (int64_t)4 * h->cu_count && !getenv("RNNWF_NO_COOP")) return base_coop(h, a);
         static int bpc = 0;
         const void* fn = (const void*)crnn_base_kernel<NFULL, WAVES>;
         if (!bpc) if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;

@@ -12,7 +12,7 @@
 //                         from the checkpoint of site lo, and writes  H_k exp(log psi(s') - log psi(s)).
 //   j1j2_eloc_kernel    : E_loc[s] = diag + sum_k contributions, in the reference's bond order (:277-279).
 #pragma once
-#include "gru_core.h"
+#include "gru_kernels.h"
 
 namespace rnnwf {
 
@@ -54,6 +54,7 @@ struct CrnnArgs {
 // la0/la1: log-amplitudes, w0: probability of spin 0 for the sampler, ph0/ph1: phases.
 __device__ __forceinline__ void crnn_site(const float (&z)[3], int n, int N, int num_up, float& la0, float& la1,
                                           float& w0, float& ph0, float& ph1) {
+#pragma clang fp contract(off)
     float lp0, lp1;
     log_softmax2(z[0], lp0, lp1);
     la0 = 0.5f * lp0;
@@ -93,7 +94,7 @@ __global__ void __launch_bounds__(WAVES * 64) crnn_base_kernel(CrnnArgs a) {
         double re = 0.0, im = 0.0;
         for (int n = 0; n < N; ++n) {
             if (!a.sampling && (n & 31) == 0) word = a.bits[(int64_t)(n >> 5) * a.ns + sc];
-            C::step(lds, sig_in, h, lane);
+            C::template step<true>(lds, sig_in, h, lane);    // bias last: bit-identical to crnn_base_coop_kernel
             float z[3];
             C::head(lds, h, lane, z);
             float la0, la1, w0, ph0, ph1;
@@ -128,6 +129,62 @@ __global__ void __launch_bounds__(WAVES * 64) crnn_base_kernel(CrnnArgs a) {
             if (a.out_logp) a.out_logp[s] = 2.0 * re;
         }
     }
+}
+
+// The same pass with NFULL + 1 waves per block of 16 chains (gru_kernels.h, coop_base_pass): used when there are fewer
+// blocks than SIMDs.  Bit-identical to crnn_base_kernel.
+template <int NFULL>
+__global__ void __launch_bounds__((NFULL + 1) * 64) crnn_base_coop_kernel(CrnnArgs a) {
+    using C = GruCore<float, NFULL, 3>;
+    constexpr int KT = C::KT;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int N = a.N;
+    int64_t s = 0, sc = 0;
+    bool valid = false;
+    uint32_t word = 0;
+    int num_up = 0;
+    double re = 0.0, im = 0.0;
+    coop_base_pass<NFULL, 3>(
+        lds, a.wimg, N, a.nsb, a.hck, 0,
+        [&](int64_t sb) {
+            s = sb * kChains + c;
+            valid = s < a.ns;
+            sc = valid ? s : a.ns - 1;
+            word = 0;
+            num_up = 0;
+            re = im = 0.0;
+        },
+        [&](int n, const float (&h)[KT]) -> int {
+            if (!a.sampling && (n & 31) == 0) word = a.bits[(int64_t)(n >> 5) * a.ns + sc];
+            float z[3];
+            C::head(lds, h, lane, z);
+            float la0, la1, w0, ph0, ph1;
+            crnn_site(z, n, N, num_up, la0, la1, w0, ph0, ph1);
+            int sig;
+            if (a.sampling) {
+                const float u = philox_uniform(a.seed, a.step, (uint64_t)(a.sample_offset + sc), n);
+                sig = (u < w0) ? 0 : 1;
+                word |= (uint32_t)sig << (n & 31);
+                if (((n & 31) == 31 || n == N - 1) && valid && q == 0) a.bits[(int64_t)(n >> 5) * a.ns + s] = word;
+                if ((n & 31) == 31) word = 0;
+            } else {
+                sig = (word >> (n & 31)) & 1;
+            }
+            if (a.cb && valid && q == 0)
+                a.cb[(int64_t)n * a.ns + s] = make_double2(re + (double)(sig ? la0 : la1), im + (double)(sig ? ph0 : ph1));
+            re += (double)(sig ? la1 : la0);
+            im += (double)(sig ? ph1 : ph0);
+            num_up += sig;
+            return sig;
+        },
+        [&](int64_t) {
+            if (valid && q == 0) {
+                if (a.tot) a.tot[s] = make_double2(re, im);
+                if (a.out_amp) a.out_amp[s] = make_float2((float)re, (float)im);
+                if (a.out_logp) a.out_logp[s] = 2.0 * re;
+            }
+        });
 }
 
 // ---- connected configurations -----------------------------------------------------------------------

@@ -16,14 +16,22 @@
 
 namespace rnnwf {
 
+// Kernels that must agree bit for bit (prnn_base_kernel / prnn_base_coop_kernel, crnn_* likewise) share the functions
+// below.  -ffp-contract=fast lets hipcc fuse a*b+c differently in every inlining context, so these functions switch
+// contraction off and spell their FMAs out: the same source then gives the same rounding everywhere.
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 template <typename T> struct Act;
 template <> struct Act<float> {
     static constexpr double kGateScale = -1.44269504088896340736;      // acc = -x log2(e)
     static constexpr double kCandScale = -2.88539008177792681472;      // pre = -2 y log2(e)
     static __device__ __forceinline__ float sigmoid_scaled(float a) {
+#pragma clang fp contract(off)
         return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a));
     }
     static __device__ __forceinline__ float tanh_scaled(float p) {
+#pragma clang fp contract(off)
         return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(p)), -1.0f);
     }
 };
@@ -53,6 +61,7 @@ template <> struct Act<double> {
 //   log p1 = -log(1 + e^-d), log p0 = -log(1 + e^d); evaluated as  -[max(0, -+d)] - log(1 + e^-|d|)
 // (tf.nn.softmax's exp(z - max)/sum followed by log, 1DTFIM/RNNwavefunction.py:109,113-116, in one step).
 __device__ __forceinline__ void log_softmax2(float d, float& lp0, float& lp1) {
+#pragma clang fp contract(off)
     const float ad = fabsf(d);
     const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * ad);
     const float L = 0.693147180559945309f * __builtin_amdgcn_logf(1.0f + e);     // v_log_f32 = log2
@@ -60,15 +69,28 @@ __device__ __forceinline__ void log_softmax2(float d, float& lp0, float& lp1) {
     lp1 = -L - fmaxf(-d, 0.0f);
 }
 __device__ __forceinline__ void log_softmax2(double d, double& lp0, double& lp1) {
+#pragma clang fp contract(off)
     const double L = log1p(exp(-fabs(d)));
     lp0 = -L - fmax(d, 0.0);
     lp1 = -L - fmax(-d, 0.0);
 }
 // p0 = sigmoid(-d) for the sampler (tf.multinomial draws class 0 iff u * (p0 + p1) < p0)
 __device__ __forceinline__ float prob0(float d) {
+#pragma clang fp contract(off)
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(1.44269504088896341f * d));
 }
 __device__ __forceinline__ double prob0(double d) { return 1.0 / (1.0 + exp(d)); }
+
+// new state of one unit from its three accumulators (pre-scaled rows, see Act), the candidate's input term and the
+// old state:  r = sigmoid(a_r), u = sigmoid(a_u), c = tanh(xc + r q), h' = c + u (h - c)
+template <typename T>
+__device__ __forceinline__ T gru_gate(T ar, T au, T aq, T xc, T hold) {
+#pragma clang fp contract(off)
+    const T rg = Act<T>::sigmoid_scaled(ar);
+    const T ug = Act<T>::sigmoid_scaled(au);
+    const T cc = Act<T>::tanh_scaled(fma_(rg, aq, xc));
+    return fma_(ug, hold - cc, cc);
+}
 
 template <typename T, int NFULL, int NOUT>
 struct GruCore {
@@ -141,20 +163,13 @@ struct GruCore {
         for (int m = 0; m < NFULL; ++m) {
             const V4 xc = *reinterpret_cast<const V4*>(x + (size_t)m * 16 * sizeof(T));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const T rg = A::sigmoid_scaled(acc[m][r]);
-                const T ug = A::sigmoid_scaled(acc[NFULL + m][r]);
-                const T cc = A::tanh_scaled(xc[r] + rg * acc[2 * NFULL + m][r]);
-                h[4 * m + r] = cc + ug * (h[4 * m + r] - cc);
-            }
+            for (int r = 0; r < 4; ++r)
+                h[4 * m + r] = gru_gate<T>(acc[m][r], acc[NFULL + m][r], acc[2 * NFULL + m][r], xc[r], h[4 * m + r]);
         }
         {
             const V4 xc = *reinterpret_cast<const V4*>(x + (size_t)NFULL * 16 * sizeof(T));
             const V4 a = acc[NT - 1];
-            const T rg = A::sigmoid_scaled(a[0]);
-            const T ug = A::sigmoid_scaled(a[1]);
-            const T cc = A::tanh_scaled(xc[0] + rg * a[2]);
-            h[KT - 1] = cc + ug * (h[KT - 1] - cc);
+            h[KT - 1] = gru_gate<T>(a[0], a[1], a[2], xc[0], h[KT - 1]);
         }
     }
 
@@ -221,6 +236,7 @@ struct GruCore {
     // logit DIFFERENCE d = z1 - z0 of tf.layers.Dense(2) (1DTFIM/RNNwavefunction.py:33,67,109) - a two-way
     // softmax depends on nothing else; the cRNN adds the two phase logits (rows 1, 2; :42-43).
     static __device__ __forceinline__ void head(const char* lds, const T (&h)[KT], int lane, T (&z)[NOUT]) {
+#pragma clang fp contract(off)
         const int q = lane >> 4;
         asm volatile("" ::: "memory");
         const T* wd = reinterpret_cast<const T*>(lds + L::OFF_WD) + q * L::WD_Q;
@@ -229,7 +245,7 @@ struct GruCore {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-            for (int o = 0; o < NOUT; ++o) z[o] += h[kt] * wd[kt * NOUT + o];
+            for (int o = 0; o < NOUT; ++o) z[o] = fma_(h[kt], wd[kt * NOUT + o], z[o]);
         const T* bd = reinterpret_cast<const T*>(lds + L::OFF_BD);
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) {

@@ -156,31 +156,29 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_flip_kernel(PrnnArgs a) {
 //     last wave  : head, draw / read the spin, publish it, log-probabilities
 // The arithmetic per unit is the instruction sequence of prnn_base_kernel (GruCore::step<BIAS_LAST>), so both kernels
 // agree bit for bit, draws included - a batch and its shards may take different kernels.
-template <int NFULL>
-__global__ void __launch_bounds__((NFULL + 1) * 64) prnn_base_coop_kernel(PrnnArgs a) {
-    using C = GruCore<float, NFULL, 1>;
+// The cooperative site loop shared by the positive and the complex RNN: `begin(sb)` on every wave at the start of a
+// block of 16 chains, `site(n, h) -> spin` on the remainder wave once the state after site n is complete (head, draw,
+// bookkeeping), `end(sb)` on the remainder wave after the last site.
+template <int NFULL, int NOUT, typename Begin, typename Site, typename End>
+__device__ __forceinline__ void coop_base_pass(char* lds, const void* wimg, int N, int64_t nsb, void* hck, int ablate,
+                                               Begin begin, Site site, End end) {
+    using C = GruCore<float, NFULL, NOUT>;
     using L = typename C::L;
     using V4 = typename C::V4;
     constexpr int KT = C::KT, NG = C::NG;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    C::stage(lds, a.wimg);
+    C::stage(lds, wimg);
     float* xbuf = reinterpret_cast<float*>(lds + L::BYTES);            // [2][KT][64] new state, then [2][64] int spins
     int* sbuf = reinterpret_cast<int*>(xbuf + 2 * KT * 64);
-    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int lane = threadIdx.x & 63, q = lane >> 4;
     const int m = threadIdx.x >> 6;                                     // this wave's unit block (NFULL: remainder units)
     const bool full = m < NFULL;
-    const int N = a.N;
     const V4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int64_t sb = blockIdx.x; sb < a.nsb; sb += gridDim.x) {
-        const int64_t s = sb * kChains + c;
-        const bool valid = s < a.ns;
-        const int64_t sc = valid ? s : a.ns - 1;
+    for (int64_t sb = blockIdx.x; sb < nsb; sb += gridDim.x) {
+        begin(sb);
         float h[KT];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) h[kt] = 0.0f;
         float own[4] = {0.0f, 0.0f, 0.0f, 0.0f};                        // this wave's units of the current state
-        uint32_t word = 0;
-        double cum = 0.0;
         for (int n = 0; n < N; ++n) {
             asm volatile("" ::: "memory");
             float* xb = xbuf + (size_t)(n & 1) * KT * 64 + lane;
@@ -225,23 +223,17 @@ __global__ void __launch_bounds__((NFULL + 1) * 64) prnn_base_coop_kernel(PrnnAr
                 const V4 xc = *reinterpret_cast<const V4*>(xcp + (size_t)m * 64);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float rg = Act<float>::sigmoid_scaled(accr[r]);
-                    const float ug = Act<float>::sigmoid_scaled(accu[r]);
-                    const float cc = Act<float>::tanh_scaled(xc[r] + rg * accq[r]);
-                    own[r] = cc + ug * (own[r] - cc);
+                    own[r] = gru_gate<float>(accr[r], accu[r], accq[r], xc[r], own[r]);
                     xb[(4 * m + r) * 64] = own[r];
                 }
             } else {
                 accr += *reinterpret_cast<const V4*>(binit + (size_t)tr * 64);
                 const float xc = *reinterpret_cast<const float*>(xcp + (size_t)NFULL * 64);
-                const float rg = Act<float>::sigmoid_scaled(accr[0]);
-                const float ug = Act<float>::sigmoid_scaled(accr[1]);
-                const float cc = Act<float>::tanh_scaled(xc + rg * accr[2]);
-                own[0] = cc + ug * (own[0] - cc);
+                own[0] = gru_gate<float>(accr[0], accr[1], accr[2], xc, own[0]);
                 xb[(KT - 1) * 64] = own[0];
             }
-            if (a.hck && n < N - 1 && !(a.ablate & 8)) {
-                float* dst = reinterpret_cast<float*>(a.hck) + (((int64_t)n * a.nsb + sb) * KT) * 64 + lane;
+            if (hck && n < N - 1 && !(ablate & 8)) {
+                float* dst = reinterpret_cast<float*>(hck) + (((int64_t)n * nsb + sb) * KT) * 64 + lane;
                 if (full) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dst[(4 * m + r) * 64] = own[r];
@@ -252,37 +244,63 @@ __global__ void __launch_bounds__((NFULL + 1) * 64) prnn_base_coop_kernel(PrnnAr
             __syncthreads();                                            // barrier A: the new state is complete
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) h[kt] = xb[kt * 64];
-            if (!full) {                                                // head + spin + bookkeeping: remainder wave only
-                if (!a.sampling && (n & 31) == 0) word = a.bits[(int64_t)(n >> 5) * a.ns + sc];
-                float zz[1];
-                C::head(lds, h, lane, zz);
-                const float z = zz[0];
-                float lp0, lp1;
-                log_softmax2(z, lp0, lp1);
-                int sig;
-                if (a.sampling) {
-                    const float u = (a.ablate & 32) ? 0.5f : philox_uniform(a.seed, a.step, (uint64_t)(a.sample_offset + sc), n);
-                    sig = (u < prob0(z)) ? 0 : 1;
-                    word |= (uint32_t)sig << (n & 31);
-                    if (((n & 31) == 31 || n == N - 1) && valid && q == 0) a.bits[(int64_t)(n >> 5) * a.ns + s] = word;
-                    if ((n & 31) == 31) word = 0;
-                } else {
-                    sig = (word >> (n & 31)) & 1;
-                }
-                sbuf[(n & 1) * 64 + lane] = sig;
-                if (a.lpq && !(a.ablate & 16)) {
-                    const int64_t row = a.row_of_pos ? a.row_of_pos[n] : n + 1;
-                    if (valid && q == 0) a.lpq[row * a.ns + s] = cum + (double)(sig ? lp0 : lp1);
-                }
-                cum += (double)(sig ? lp1 : lp0);
-            }
+            if (!full) sbuf[(n & 1) * 64 + lane] = site(n, h);          // head + spin + bookkeeping: remainder wave only
         }
-        if (!full && valid && q == 0) {
-            if (a.lpq) a.lpq[s] = cum;
-            if (a.out_lp) a.out_lp[s] = cum;
-        }
+        if (!full) end(sb);
         __syncthreads();          // the next block of chains starts writing the buffers again
     }
+}
+
+template <int NFULL>
+__global__ void __launch_bounds__((NFULL + 1) * 64) prnn_base_coop_kernel(PrnnArgs a) {
+    using C = GruCore<float, NFULL, 1>;
+    constexpr int KT = C::KT;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int N = a.N;
+    int64_t s = 0, sc = 0;
+    bool valid = false;
+    uint32_t word = 0;
+    double cum = 0.0;
+    coop_base_pass<NFULL, 1>(
+        lds, a.wimg, N, a.nsb, a.hck, a.ablate,
+        [&](int64_t sb) {
+            s = sb * kChains + c;
+            valid = s < a.ns;
+            sc = valid ? s : a.ns - 1;
+            word = 0;
+            cum = 0.0;
+        },
+        [&](int n, const float (&h)[KT]) -> int {
+            if (!a.sampling && (n & 31) == 0) word = a.bits[(int64_t)(n >> 5) * a.ns + sc];
+            float zz[1];
+            C::head(lds, h, lane, zz);
+            const float z = zz[0];
+            float lp0, lp1;
+            log_softmax2(z, lp0, lp1);
+            int sig;
+            if (a.sampling) {
+                const float u = (a.ablate & 32) ? 0.5f : philox_uniform(a.seed, a.step, (uint64_t)(a.sample_offset + sc), n);
+                sig = (u < prob0(z)) ? 0 : 1;
+                word |= (uint32_t)sig << (n & 31);
+                if (((n & 31) == 31 || n == N - 1) && valid && q == 0) a.bits[(int64_t)(n >> 5) * a.ns + s] = word;
+                if ((n & 31) == 31) word = 0;
+            } else {
+                sig = (word >> (n & 31)) & 1;
+            }
+            if (a.lpq && !(a.ablate & 16)) {
+                const int64_t row = a.row_of_pos ? a.row_of_pos[n] : n + 1;
+                if (valid && q == 0) a.lpq[row * a.ns + s] = cum + (double)(sig ? lp0 : lp1);
+            }
+            cum += (double)(sig ? lp1 : lp0);
+            return sig;
+        },
+        [&](int64_t) {
+            if (valid && q == 0) {
+                if (a.lpq) a.lpq[s] = cum;
+                if (a.out_lp) a.out_lp[s] = cum;
+            }
+        });
 }
 
 }  // namespace rnnwf

@@ -175,3 +175,22 @@ def test_config3_properties():
     assert per_site < 1e-5
     _, ncon = wf.j1j2_eloc(s, np.ones(N), 0.5 * np.ones(N), np.zeros(N))
     assert 30 * ns < ncon < 50 * ns
+
+
+@pytest.mark.parametrize("N,H,ns", [(10, 11, 50), (40, 50, 333), (34, 20, 70), (16, 64, 33)])
+def test_cooperative_base_pass_is_bit_identical(N, H, ns, monkeypatch):
+    """crnn_base_coop_kernel (small batches) vs crnn_base_kernel: samples, log-amplitudes and J1-J2 local energies."""
+    prm = trained_like(H, seed=N)
+    wf = make_wf(N, H, prm)
+    J1, J2, Bz = np.ones(N), 0.5 * np.ones(N), np.zeros(N)
+    s1 = wf.sample(ns, seed=4, step=1)
+    a1 = wf.log_amp(s1)
+    e1, n1 = wf.j1j2_eloc(s1, J1, J2, Bz)
+    monkeypatch.setenv("RNNWF_NO_COOP", "1")
+    s2 = wf.sample(ns, seed=4, step=1)
+    a2 = wf.log_amp(s1)
+    e2, n2 = wf.j1j2_eloc(s1, J1, J2, Bz)
+    monkeypatch.delenv("RNNWF_NO_COOP")
+    assert np.array_equal(s1, s2) and np.array_equal(a1, a2)
+    assert n1 == n2 and np.array_equal(e1, e2)
+    assert np.all(s1.sum(axis=1) == N // 2)
