@@ -80,7 +80,7 @@ struct CLaunch {
             case 2: { using K = CLaunch<2, 4>; EXPR; }          \
             case 3: { using K = CLaunch<3, 4>; EXPR; }          \
             case 4: { using K = CLaunch<4, 4>; EXPR; }          \
-            case 6: { using K = CLaunch<6, 12>; EXPR; }         \
+            case 6: { using K = CLaunch<6, 8>; EXPR; }         \
         }                                                       \
     } while (0)
 

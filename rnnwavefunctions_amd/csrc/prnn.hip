@@ -142,7 +142,7 @@ struct MLaunchL {
                 case 2: { using K = Launch<float, 2, 4>; EXPR; }                            \
                 case 3: { using K = Launch<float, 3, 4>; EXPR; }                            \
                 case 4: { using K = Launch<float, 4, 4>; EXPR; }                            \
-                case 6: { using K = Launch<float, 6, 12>; EXPR; }                           \
+                case 6: { using K = Launch<float, 6, 8>; EXPR; }                            \
             }                                                                               \
         } else {                                                                            \
             switch ((h)->NFULL) {                                                           \
