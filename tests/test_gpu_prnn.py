@@ -458,3 +458,19 @@ def test_config5_shard_at_full_size():
     per_site = np.abs(e[sub] - e_ref).max() / N
     print("cfg5 shard: <E>/N = %.6f, max |E_loc - oracle|/N over 6 samples = %.2e" % (e.mean() / N, per_site))
     assert per_site < 1e-4
+
+
+def test_thousand_site_chain():
+    """The longest chain the reference's tables mention (DMRG E0 for N=1000, Tutorial_1DTFIM.ipynb cell 24): 32 words of
+    packed spins per sample, 999 checkpoints, half a million flip tiles."""
+    from rnnwavefunctions_amd import _lib
+    N, H, ns = 1000, 50, 96
+    prm = P.init_gru_params([H], seed=111)
+    wf = make_wf(_lib.MODEL_GRU1D, N, H, prm)
+    out = wf.vmc_step(ns, seed=1, step=0, couplings=np.append(np.ones(N), 1.0), want_samples=True, want_eloc=True)
+    s, e = out["samples"], out["eloc"]
+    assert s.shape == (ns, N) and np.all(np.isfinite(e))
+    sub = [0, ns - 1]
+    e_ref = E.ising_local_energies(np.ones(N), 1.0, s[sub], lambda x: M.prnn_log_probability(prm, x))
+    assert np.abs(e[sub] - e_ref).max() / N < 1e-5
+    assert np.array_equal(wf.sample(ns, seed=1, step=0), s)
