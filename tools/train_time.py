@@ -6,7 +6,8 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rnnwavefunctions_amd import _lib, params as P                      # noqa: E402
 from rnnwavefunctions_amd.training import Adam, cost_gradient           # noqa: E402
 
