@@ -29,7 +29,7 @@ struct CLaunch {
     }
     static int base_coop(rnnwf_handle* h, const CrnnArgs& a) {
         if constexpr (NFULL <= 4) {
-            static int bpc = 0;
+            static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
             const void* fn = (const void*)crnn_base_coop_kernel<NFULL>;
             const size_t lds = L::BYTES + (size_t)2 * L::KT * 64 * 4 + 2 * 64 * 4;
             if (!bpc) {
@@ -47,7 +47,7 @@ struct CLaunch {
     static int base(rnnwf_handle* h, const CrnnArgs& a) {
         // fewer 16-chain blocks than SIMDs: the cooperative kernel (NFULL + 1 waves per block, bit-identical)
         if (NFULL <= 4 && a.nsb <= (int64_t)4 * h->cu_count && !getenv("RNNWF_NO_COOP")) return base_coop(h, a);
-        static int bpc = 0;
+        static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
         const void* fn = (const void*)crnn_base_kernel<NFULL, WAVES>;
         if (!bpc) if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
         const int64_t need = (a.nsb + WAVES - 1) / WAVES;
@@ -58,7 +58,7 @@ struct CLaunch {
         return 0;
     }
     static int swap(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles) {
-        static int bpc = 0;
+        static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
         const void* fn = (const void*)crnn_swap_kernel<NFULL, WAVES>;
         if (!bpc) if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
         // the tile count lives on the device: launch the persistent grid, bounded by the worst case
@@ -89,7 +89,7 @@ template <int NF32, int RJ, int WAVES, int MODE>
 struct CSLaunch {
     using L = SplitLayout<NF32, RJ, 3, MODE>;
     static int swap(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles, int kt16) {
-        static int bpc = 0;
+        static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
         const void* fn = (const void*)crnn_swap_split_kernel<NF32, RJ, WAVES, MODE>;
         if (!bpc) {
             RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES));

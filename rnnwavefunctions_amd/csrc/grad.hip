@@ -48,7 +48,7 @@ struct GLaunch {
     }
 
     static int run(rnnwf_handle* h, GradArgs a, int64_t R, void* dW) {
-        static int bpc = 0;
+        static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
         const void* fn = (const void*)gru_bwd_kernel<T, NFULL, WAVES, NOUT>;
         const size_t lds = LDS;
         if (lds > 160 * 1024)
@@ -222,7 +222,7 @@ struct MLGrad {
 
     template <bool TOP>
     static int upper_pass(rnnwf_handle* h, const UpperGradArgs& a) {
-        static int bpc = 0;
+        static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
         const void* fn = (const void*)gru_upper_bwd_kernel<NFULL, WAVES, TOP>;
         const size_t lds = U::BYTES + GU::BWD_BYTES + (TOP ? GU::HEAD_BYTES : 0);
         if (lds > 160 * 1024) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: stacked-layer images (%zu B) exceed the 160 KB LDS", lds);

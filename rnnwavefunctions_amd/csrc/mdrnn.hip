@@ -25,7 +25,7 @@ struct MLaunch {
         return 0;
     }
     static int base(rnnwf_handle* h, const MdArgs& a) {
-        static int bpc = 0;
+        static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
         const void* fn = (const void*)mdrnn_base_kernel<NFULL, WAVES>;
         if (!bpc) if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
         const int64_t need = (a.nsb + WAVES - 1) / WAVES;
@@ -36,7 +36,7 @@ struct MLaunch {
         return 0;
     }
     static int flip_grid(rnnwf_handle* h, int64_t ntiles, unsigned* grid) {
-        static int bpc = 0;
+        static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
         const void* fn = (const void*)mdrnn_flip_kernel<NFULL, WAVES>;
         if (!bpc) if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
         const int64_t need = (ntiles + WAVES - 1) / WAVES;
@@ -370,7 +370,7 @@ struct MGrad {
     }
 
     static int run(rnnwf_handle* h, MdGradArgs a, int64_t R, double* dW) {
-        static int bpc = 0;
+        static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
         const void* fn = (const void*)mdrnn_bwd_kernel<NFULL, WAVES>;
         if (!bpc) {
             RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::BYTES));

@@ -31,7 +31,7 @@ struct Launch {
     // fewer 16-chain blocks than SIMDs: the cooperative kernel (NFULL + 1 waves per block) cuts the per-site latency
     static int base_coop(rnnwf_handle* h, const PrnnArgs& a) {
         if constexpr (std::is_same<T, float>::value && NFULL <= 4) {
-            static int bpc = 0;
+            static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
             const void* fn = (const void*)prnn_base_coop_kernel<NFULL>;
             const size_t lds = L::BYTES + (size_t)2 * L::KT * 64 * 4 + 2 * 64 * 4;
             if (!bpc) {
@@ -49,7 +49,7 @@ struct Launch {
     static int base(rnnwf_handle* h, const PrnnArgs& a) {
         if (std::is_same<T, float>::value && NFULL <= 4 && a.nsb <= (int64_t)4 * h->cu_count && !getenv("RNNWF_NO_COOP"))
             return base_coop(h, a);
-        static int bpc = 0;
+        static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
         const void* fn = (const void*)prnn_base_kernel<T, NFULL, WAVES>;
         if (!bpc) if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
         const int64_t need = (a.nsb + WAVES - 1) / WAVES;
@@ -60,7 +60,7 @@ struct Launch {
         return 0;
     }
     static int flip(rnnwf_handle* h, const PrnnArgs& a) {
-        static int bpc = 0;
+        static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
         const void* fn = (const void*)prnn_flip_kernel<T, NFULL, WAVES>;
         if (!bpc) if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
         const int64_t need = (a.ntiles + WAVES - 1) / WAVES;
@@ -87,7 +87,7 @@ struct MLaunchL {
         return 0;
     }
     static int base(rnnwf_handle* h, const PrnnArgs& a) {
-        static int bpc = 0;
+        static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
         const void* fn = (const void*)prnn_ml_base_kernel<NFULL, NL, WAVES>;
         if (!bpc) if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
         const int64_t need = (a.nsb + WAVES - 1) / WAVES;
@@ -98,7 +98,7 @@ struct MLaunchL {
         return 0;
     }
     static int flip(rnnwf_handle* h, const PrnnArgs& a) {
-        static int bpc = 0;
+        static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
         const void* fn = (const void*)prnn_ml_flip_kernel<NFULL, NL, WAVES>;
         if (!bpc) if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
         const int64_t need = (a.ntiles + WAVES - 1) / WAVES;
@@ -159,7 +159,7 @@ template <int NF32, int RJ, int WAVES, int MODE>
 struct SLaunch {
     using L = SplitLayout<NF32, RJ, 1, MODE>;
     static int flip(rnnwf_handle* h, const PrnnArgs& a, int kt16) {
-        static int bpc = 0;
+        static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
         const void* fn = (const void*)prnn_flip_split_kernel<NF32, RJ, WAVES, MODE>;
         if (!bpc) {
             RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES));
