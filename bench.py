@@ -40,8 +40,19 @@ WORKLOADS = {
     "cfg5": dict(kind="tfim1d", N=200, H=100, ns=32768, Bx=1.0,
                  desc="1DTFIM pRNN N=200 num_units=100 numsamples=32768 per GPU (BASELINE config 5 shard)"),
 }
-# /opt/skills/guides/MI355X_MICROARCH.md: dense f32 MFMA = f32 vector peak; f64 matrix = f64 vector peak
-PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}
+# /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA = f32 vector peak; f64 matrix = f64 vector peak; bf16 MFMA
+# dense 2 500 TF/s.  The bf16x3 engine spends SIX bf16 products per f32 product (csrc/split_core.h), so the roof of
+# that pipe in f32-equivalent flops is 2 500 / 6 TF/s: `roofline.peak` is always the pipe the named kernel issues on.
+PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6, "bf16": 2500.0}
+BF16X3_PRODUCTS = 6
+
+
+def engine_peak(engine, dtype):
+    """(peak TFLOP/s in the units `achieved` is counted in, description) of the pipe the dominant kernel runs on."""
+    if engine == "bf16x3":
+        return PEAK_TFLOPS["bf16"] / BF16X3_PRODUCTS, ("bf16 MFMA pipe (2500 TF/s dense) in f32-equivalent flops: the bf16x3 engine "
+                                                       "issues 6 bf16 products per f32 product, so peak = 2500/6 TF/s")
+    return PEAK_TFLOPS[dtype], "dense %s-input MFMA peak" % dtype
 
 
 def f_cell_gru(h):
@@ -147,17 +158,40 @@ def alt_engine_run(wl, couplings, warmup, steps):
     launches = max(k["launches"], 1)
     ach = k["cell_evals"] / launches * f_cell(wl) / (k["total_ms"] / launches * 1e-3) / 1e12
     return {"engine": wf.engine_name(), "value": ns * N / dt, "ms_per_step": dt * 1e3, "steps": steps,
-            "roofline_frac": ach / PEAK_TFLOPS["f32"], "avg_launch_ms": k["total_ms"] / launches, "mean_E": m[0] / m[2]}
+            "roofline_frac": ach / PEAK_TFLOPS["f32"], "roofline_peak": PEAK_TFLOPS["f32"],
+            "avg_launch_ms": k["total_ms"] / launches, "mean_E": m[0] / m[2]}
+
+
+TRAFFIC_FILE = os.path.join("profiles", "pmc_traffic.json")
 
 
 def load_traffic(workload):
-    """HBM bytes per flip-kernel launch measured with rocprofv3 --pmc (separate pass), if recorded."""
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    """HBM bytes per flip-kernel launch from an EARLIER rocprofv3 --pmc run (FETCH_SIZE and WRITE_SIZE need separate
+    passes and cannot be read from inside this process); the record says which build it belongs to, and the bench
+    line labels it as replayed."""
     try:
-        with open(p) as f:
+        with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
             return json.load(f).get(workload)
     except (OSError, ValueError):
         return None
+
+
+def sharded_cfg5(wf_factory, rank, world, reduce_moments, barrier, steps=2):
+    """North-star config 5 (N=200, 100 units, 32 768 samples per GPU) on the ranks of this job: `steps` timed VMC steps
+    after one warm-up, one RCCL all-reduce of the moments per step."""
+    wl = dict(WORKLOADS["cfg5"])
+    wf, _, couplings = wf_factory(wl)
+    ns, N = wl["ns"], wl["N"]
+
+    def step(it):
+        return reduce_moments(wf, wf.vmc_step(ns, seed=111, step=it, couplings=couplings, sample_offset=rank * ns)["moments"])
+    step(0)
+    barrier(wf)
+    t0 = time.perf_counter()
+    for it in range(steps):
+        m = step(1 + it)
+    barrier(wf)
+    return wl, time.perf_counter() - t0, m
 
 
 def main():
@@ -171,6 +205,8 @@ def main():
                     help="init: glorot-uniform as initialised; trained: kernels x 3 (sharper conditionals)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-engine", action="store_true", help="skip the extra f32-input-MFMA timing")
+    ap.add_argument("--no-cfg5", action="store_true",
+                    help="multi-GPU runs: skip the extra north-star config 5 leg (N=200, 100 units, 32768 samples per GPU)")
     ap.add_argument("--transport", default="rccl", choices=("rccl", "gloo"),
                     help="all-reduce of the moments: RCCL over xGMI (default) or the launcher's gloo group (rehearsal of "
                          "the multi-rank control flow on a box whose GPUs cannot host one rank each)")
@@ -186,62 +222,94 @@ def main():
     if args.numsamples:
         wl["ns"] = args.numsamples
     wl["weights"] = args.weights
+    device = 0 if args.same_device else local_rank
 
     # Load order matters: the product library (and RCCL, which it dlopens) come first so that the HIP runtime
     # in this process is /opt/rocm's; torch (which bundles its own copies) is imported afterwards and only for
     # the launcher's CPU-side rendezvous.
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    wf, prm, couplings = make_wavefunction(wl, device=0 if args.same_device else local_rank)
+    wf, prm, couplings = make_wavefunction(wl, device=device)
     dist = None
     gloo_reduce = None
     if world > 1:
-        uid = wf.comm_unique_id() if args.transport == "rccl" else None   # every rank: loads librccl now; rank 0's id is used
+        if args.transport == "rccl":
+            wf.comm_unique_id()               # every rank: loads librccl now, before torch brings its own copy
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         import torch.distributed as dist      # launcher plumbing only: gloo rendezvous + barrier on CPU
         dist.init_process_group(backend="gloo")
-        if args.transport == "rccl":
-            box = [uid if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            wf.comm_init(box[0], rank, world)
-        else:
+        if args.transport == "gloo":
             from rnnwavefunctions_amd.distributed import ShardComm
             gloo_reduce = ShardComm.from_torch().allreduce
 
+    def init_comm(w):                         # one RCCL communicator per handle: rank 0's unique id travels over gloo
+        if world > 1 and args.transport == "rccl":
+            box = [w.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            w.comm_init(box[0], rank, world)
+
+    def reduce_moments(w, m):                 # ONE all-reduce: (sum E, sum E^2, n, sum Im E)
+        if world == 1:
+            return m
+        return gloo_reduce(m) if gloo_reduce else w.allreduce_moments(m)
+
+    def barrier(w):
+        w.synchronize()
+        if dist is not None:
+            dist.barrier()
+        w.synchronize()
+
+    init_comm(wf)
     ns, N = wl["ns"], wl["N"]
     offset = rank * ns                       # global sample indices of this shard
 
     def step(it):
-        out = wf.vmc_step(ns, seed=111, step=it, couplings=couplings, sample_offset=offset)
-        m = out["moments"]
-        if world > 1:                         # ONE all-reduce: (sum E, sum E^2, n, sum Im E)
-            m = gloo_reduce(m) if gloo_reduce else wf.allreduce_moments(m)
-        return m
-
-    def barrier():
-        wf.synchronize()
-        if dist is not None:
-            dist.barrier()
-        wf.synchronize()
+        return reduce_moments(wf, wf.vmc_step(ns, seed=111, step=it, couplings=couplings, sample_offset=offset)["moments"])
 
     for it in range(args.warmup):
         step(it)
     wf.timing_enable(True)
     wf.timing_reset()
-    barrier()
+    barrier(wf)
     t0 = time.perf_counter()
     for it in range(args.steps):
         m = step(args.warmup + it)
-    barrier()
+    barrier(wf)
     dt = time.perf_counter() - t0
-    if dist is not None:
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
         import torch
-        t = torch.tensor([dt], dtype=torch.float64)
+        t = torch.tensor([x], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
+        return float(t[0])
+
+    dt = max_over_ranks(dt)
+    # what each rank's communicator says about itself (ncclCommCount / ncclCommUserRank) and the GPU it sits on
+    info = wf.comm_info()
+    info["pid_rank"] = rank
+    infos = [info]
+    if dist is not None:
+        infos = [None] * world
+        dist.all_gather_object(infos, info)
 
     flip = wf.timing_get(1)
     base = wf.timing_get(0)
     asm = wf.timing_get(2)
+    cfg5 = None
+    if world > 1 and not args.no_cfg5 and args.workload == "cfg2" and not args.numsamples:
+        def factory(w5):
+            w5["weights"] = args.weights
+            made = make_wavefunction(w5, device=device)
+            init_comm(made[0])
+            return made
+        wl5, dt5, m5 = sharded_cfg5(factory, rank, world, reduce_moments, barrier)
+        dt5 = max_over_ranks(dt5)
+        cfg5 = {"workload": wl5["desc"], "steps": 2, "warmup": 1, "ms_per_step": dt5 / 2 * 1e3,
+                "value": world * wl5["ns"] * wl5["N"] / (dt5 / 2), "unit": "samples*sites/s",
+                "global_numsamples": world * wl5["ns"], "mean_E": m5[0] / m5[2],
+                "note": "north-star config 5 (sharded over the ranks of this job, one RCCL all-reduce per step), "
+                        "reported beside `value`, which stays on the metric's own workload so that it is comparable across N"}
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * ns * N / (dt / args.steps)
@@ -252,12 +320,13 @@ def main():
         flip_ms = flip["total_ms"] / launches
         achieved = alg_flops_per_launch / (flip_ms * 1e-3) / 1e12 if flip_ms > 0 else 0.0
         dtype = "f64" if wl["kind"] in ("tfim2d", "tfim2d_gru") else "f32"
-        peak = PEAK_TFLOPS[dtype]
         engine = wf.engine_name()
+        peak, peak_note = engine_peak(engine, dtype)
         kernel = {"tfim1d": "prnn_flip_split_kernel" if engine == "bf16x3" else "prnn_flip_kernel",
                   "j1j2": "crnn_swap_split_kernel" if engine == "bf16x3" else "crnn_swap_kernel",
                   "tfim2d": "mdrnn_flip_kernel", "tfim2d_gru": "prnn_flip_kernel<double>"}[wl["kind"]]
         traffic = load_traffic(args.workload)
+        issued = flip["mfma_flops"] / launches
         rec = {
             "metric": "samples*sites/sec (autoregressive sample+local_energy), 1D TFIM N=80 nh=50"
                       if args.workload == "cfg2" else "samples*sites/sec (autoregressive sample+local_energy), " + args.workload,
@@ -269,24 +338,32 @@ def main():
                        "weights": "glorot-uniform RandomState(111), gate bias 1" + (", kernels x 3 (trained-like)" if args.weights == "trained" else ""),
                        "mean_E": mean_e, "var_E": var_e,
                        "engine": engine},
+            # the communicator's own rank count (ncclCommCount), per rank with its device: N x dp1 cannot pass for dp-N
+            "rccl_nranks": min(i["nranks"] for i in infos) if args.transport == "rccl" else None,
+            "ranks": [{"rank": i["pid_rank"], "comm_rank": i["rank"], "comm_nranks": i["nranks"], "device": i["device"]} for i in infos],
             "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": peak,
-                         "unit": "TFLOP/s", "frac": achieved / peak,
+                         "unit": "TFLOP/s", "frac": achieved / peak, "peak_is": peak_note,
+                         # the same achieved rate against the f32-input MFMA roof (what an f32 formulation could reach);
+                         # above 1 only because the bf16x3 engine left that pipe - informational, never the fraction
+                         "frac_of_f32_mfma_peak": achieved / PEAK_TFLOPS[dtype],
+                         # MFMA flops the kernel actually issued (padding included) over the peak of their pipe
+                         "mfma_issue_frac": (issued / (flip_ms * 1e-3) / 1e12 / (PEAK_TFLOPS["bf16"] if engine == "bf16x3" else PEAK_TFLOPS[dtype]))
+                                            if flip_ms > 0 else None,
                          "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
+                         "traffic_source": ("replayed from %s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, build %s); "
+                                            "not measured by this run" % (TRAFFIC_FILE, (traffic or {}).get("build", "unknown")))
+                                           if traffic else None,
                          "traffic_detail": traffic,
                          "hbm_frac_of_8TBps": ((traffic["hbm_bytes_per_launch"] / (flip_ms * 1e-3) / 8e12)
                                                if traffic and flip_ms > 0 else None),
                          "algorithmic_flops_per_launch": alg_flops_per_launch,
-                         "mfma_flops_issued_per_launch": flip["mfma_flops"] / launches,
+                         "mfma_flops_issued_per_launch": issued,
                          "avg_launch_ms": flip_ms,
-                         "note": ("peak = dense f32-input MFMA peak, the rate of an f32 formulation of this path; the "
-                                  "bf16x3 engine computes the same f32-accurate products on the bf16 matrix core "
-                                  "(six bf16 products per f32 product, bf16 dense peak 2500 TF/s => 417 TF/s "
-                                  "f32-equivalent), so frac is relative to the f32 path's roofline")
-                                 if engine == "bf16x3" else "peak = dense MFMA peak of the arithmetic type",
-                         "frac_of_bf16x6_peak": (achieved / (2500.0 / 6.0)) if engine == "bf16x3" else None,
                          "base_pass_ms": base["total_ms"] / max(base["launches"], 1),
                          "assembly_ms": asm["total_ms"] / max(asm["launches"], 1) * (asm["launches"] / launches)},
         }
+        if cfg5 is not None:
+            rec["cfg5_sharded"] = cfg5
         if engine == "bf16x3" and world == 1 and not args.no_alt_engine:
             rec["f32mfma_engine"] = alt_engine_run(wl, couplings, args.warmup, max(args.steps // 2, 3))
         if not args.no_cpu_baseline and world == 1 and wl["kind"] == "tfim1d":

@@ -191,6 +191,9 @@ int rnnwf_allreduce_grads(rnnwf_handle* h);
 int rnnwf_comm_unique_id(void* id_out);
 int rnnwf_comm_init(rnnwf_handle* h, const void* id, int32_t rank, int32_t nranks);
 int rnnwf_allreduce_moments(rnnwf_handle* h, double* moments, int32_t count);
+/* The communicator's own answer (ncclCommCount, ncclCommUserRank) and the handle's device ordinal; 1 / 0 when no
+ * communicator exists.  Reports print it, so that N one-rank runs cannot be mistaken for one N-rank run.    */
+int rnnwf_comm_info(rnnwf_handle* h, int32_t* nranks, int32_t* rank, int32_t* device);
 int rnnwf_comm_destroy(rnnwf_handle* h);
 
 /* ---- measurement ------------------------------------------------------------------------------

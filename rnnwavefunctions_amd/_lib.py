@@ -53,6 +53,7 @@ PROTOTYPES = {
     "rnnwf_comm_unique_id": (C.c_int, [_P]),
     "rnnwf_comm_init": (C.c_int, [_P, _P, _I32, _I32]),
     "rnnwf_allreduce_moments": (C.c_int, [_P, _F64P, _I32]),
+    "rnnwf_comm_info": (C.c_int, [_P, _P, _P, _P]),
     "rnnwf_comm_destroy": (C.c_int, [_P]),
     "rnnwf_timing_enable": (C.c_int, [_P, _I32]),
     "rnnwf_timing_reset": (C.c_int, [_P]),
@@ -280,6 +281,12 @@ class NativeWavefunction:
 
     def comm_init(self, unique_id, rank, nranks):
         self._check(self.lib.rnnwf_comm_init(self.h, C.c_char_p(unique_id), rank, nranks))
+
+    def comm_info(self):
+        """What the RCCL communicator itself reports (ncclCommCount / ncclCommUserRank) plus the handle's device."""
+        n, r, d = _I32(0), _I32(0), _I32(0)
+        self._check(self.lib.rnnwf_comm_info(self.h, C.byref(n), C.byref(r), C.byref(d)))
+        return {"nranks": n.value, "rank": r.value, "device": d.value}
 
     def allreduce_moments(self, moments):
         m, mp = _f64(np.array(moments, dtype=np.float64))

@@ -17,6 +17,8 @@ typedef int (*CommInitRank_t)(void**, int, ncclUniqueId_, int);
 typedef int (*AllReduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef int (*CommDestroy_t)(void*);
 typedef const char* (*GetErrorString_t)(int);
+typedef int (*CommCount_t)(void*, int*);
+typedef int (*CommUserRank_t)(void*, int*);
 
 struct Rccl {
     void* lib = nullptr;
@@ -25,6 +27,8 @@ struct Rccl {
     AllReduce_t all_reduce = nullptr;
     CommDestroy_t comm_destroy = nullptr;
     GetErrorString_t error_string = nullptr;
+    CommCount_t comm_count = nullptr;
+    CommUserRank_t comm_user_rank = nullptr;
     std::string err;
     bool load() {
         if (lib) return true;
@@ -41,6 +45,8 @@ struct Rccl {
         all_reduce = (AllReduce_t)dlsym(lib, "ncclAllReduce");
         comm_destroy = (CommDestroy_t)dlsym(lib, "ncclCommDestroy");
         error_string = (GetErrorString_t)dlsym(lib, "ncclGetErrorString");
+        comm_count = (CommCount_t)dlsym(lib, "ncclCommCount");
+        comm_user_rank = (CommUserRank_t)dlsym(lib, "ncclCommUserRank");
         if (!get_unique_id || !comm_init_rank || !all_reduce || !comm_destroy) { err = "librccl.so lacks the nccl* symbols"; return false; }
         return true;
     }
@@ -74,6 +80,23 @@ extern "C" int rnnwf_comm_init(rnnwf_handle* h, const void* id, int32_t rank, in
     }
     h->rank = rank;
     h->nranks = nranks;
+    return RNNWF_OK;
+}
+
+// What the communicator itself says (ncclCommCount / ncclCommUserRank), not what the caller passed to rnnwf_comm_init:
+// bench.py prints it so that N independent 1-rank runs cannot pass for one N-rank run.
+extern "C" int rnnwf_comm_info(rnnwf_handle* h, int32_t* nranks, int32_t* rank, int32_t* device) {
+    if (!h) return RNNWF_ERR_INVALID;
+    int n = 1, r = 0;
+    if (h->comm) {
+        if (!g_rccl.comm_count || !g_rccl.comm_user_rank) return h->fail(RNNWF_ERR_COMM, "librccl.so lacks ncclCommCount / ncclCommUserRank");
+        int rc = g_rccl.comm_count(h->comm, &n);
+        if (rc == 0) rc = g_rccl.comm_user_rank(h->comm, &r);
+        if (rc != 0) return h->fail(RNNWF_ERR_COMM, "ncclCommCount failed: %s", g_rccl.error_string ? g_rccl.error_string(rc) : "?");
+    }
+    if (nranks) *nranks = n;
+    if (rank) *rank = r;
+    if (device) *device = h->cfg.device;
     return RNNWF_OK;
 }
 

@@ -20,23 +20,13 @@ constexpr int64_t kChunk = (int64_t)1 << 20;
 template <int NFULL, int WAVES>
 struct CLaunch {
     using L = GruLayout<float, NFULL, 3>;
-    static int blocks_per_cu(rnnwf_handle* h, const void* fn, int* out) {
-        RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES));
-        int nb = 0;
-        RNNWF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, WAVES * 64, L::BYTES));
-        *out = std::max(nb, 1);
-        return 0;
-    }
+    static int blocks_per_cu(rnnwf_handle* h, const void* fn, int* out) { return rnnwf::blocks_per_cu(h, fn, WAVES * 64, L::BYTES, out); }
     static int base_coop(rnnwf_handle* h, const CrnnArgs& a) {
         if constexpr (NFULL <= 4) {
-            static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
             const void* fn = (const void*)crnn_base_coop_kernel<NFULL>;
             const size_t lds = L::BYTES + (size_t)2 * L::KT * 64 * 4 + 2 * 64 * 4;
-            if (!bpc) {
-                RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                RNNWF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, (NFULL + 1) * 64, lds));
-                bpc = std::max(bpc, 1);
-            }
+            int bpc = 0;
+            if (int rc = rnnwf::blocks_per_cu(h, fn, (NFULL + 1) * 64, lds, &bpc)) return rc;
             const unsigned grid = (unsigned)std::min<int64_t>(a.nsb, (int64_t)bpc * h->cu_count);
             TimedLaunch tl(h, 0);
             crnn_base_coop_kernel<NFULL><<<grid, (NFULL + 1) * 64, lds, h->stream>>>(a);
@@ -46,10 +36,10 @@ struct CLaunch {
     }
     static int base(rnnwf_handle* h, const CrnnArgs& a) {
         // fewer 16-chain blocks than SIMDs: the cooperative kernel (NFULL + 1 waves per block, bit-identical)
-        if (NFULL <= 4 && a.nsb <= (int64_t)4 * h->cu_count && !getenv("RNNWF_NO_COOP")) return base_coop(h, a);
-        static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
+        if (NFULL <= 4 && a.nsb <= (int64_t)4 * h->cu_count && !h->knobs.no_coop) return base_coop(h, a);
         const void* fn = (const void*)crnn_base_kernel<NFULL, WAVES>;
-        if (!bpc) if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
+        int bpc = 0;
+        if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
         const int64_t need = (a.nsb + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
         TimedLaunch tl(h, 0);
@@ -58,9 +48,9 @@ struct CLaunch {
         return 0;
     }
     static int swap(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles) {
-        static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
         const void* fn = (const void*)crnn_swap_kernel<NFULL, WAVES>;
-        if (!bpc) if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
+        int bpc = 0;
+        if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
         // the tile count lives on the device: launch the persistent grid, bounded by the worst case
         const int64_t need = (max_tiles + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
@@ -89,13 +79,9 @@ template <int NF32, int RJ, int WAVES, int MODE>
 struct CSLaunch {
     using L = SplitLayout<NF32, RJ, 3, MODE>;
     static int swap(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles, int kt16) {
-        static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
         const void* fn = (const void*)crnn_swap_split_kernel<NF32, RJ, WAVES, MODE>;
-        if (!bpc) {
-            RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES));
-            RNNWF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, WAVES * 64, L::BYTES));
-            bpc = std::max(bpc, 1);
-        }
+        int bpc = 0;
+        if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, L::BYTES, &bpc)) return rc;
         const int64_t need = (max_tiles + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
         TimedLaunch tl(h, 1);
@@ -152,7 +138,7 @@ CrnnArgs base_args(rnnwf_handle* h, int64_t ns) {
 
 int64_t max_chains_per_pass(rnnwf_handle* h) {
     const size_t per_block = (size_t)std::max(h->N - 1, 1) * hck_bytes_per_block(h);
-    return std::max<int64_t>(1, (int64_t)(state_budget_bytes(kHckBudget) / per_block)) * kChains;
+    return std::max<int64_t>(1, (int64_t)(state_budget_bytes(h, kHckBudget) / per_block)) * kChains;
 }
 
 // J1-J2 local energies of the ns chains whose packed spins are in h->bits (drawn here when `sampling`).
@@ -239,8 +225,7 @@ int64_t collect_totals(rnnwf_handle* h, int64_t ns) {
 
 int rnnwf::crnn_pack_image(rnnwf_handle* h, std::vector<char>& img) {
     // swap-pass engine: bf16x3 on the matrix core up to 68 units (RNNWF_ENGINE=f32: f32-input MFMA everywhere)
-    const char* eng = getenv("RNNWF_ENGINE");
-    h->engine_split = h->NFULL <= 4 && !(eng && std::string(eng) == "f32");
+    h->engine_split = h->NFULL <= 4 && h->knobs.engine != 1;
     if (h->engine_split) {
         std::vector<char> simg;
         CSPLIT_DISPATCH(h, { simg = K::pack(h); break; });

@@ -48,16 +48,12 @@ struct GLaunch {
     }
 
     static int run(rnnwf_handle* h, GradArgs a, int64_t R, void* dW) {
-        static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
         const void* fn = (const void*)gru_bwd_kernel<T, NFULL, WAVES, NOUT>;
         const size_t lds = LDS;
         if (lds > 160 * 1024)
             return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: forward + backward weight images (%zu B) exceed the 160 KB LDS", lds);
-        if (!bpc) {
-            RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            RNNWF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, WAVES * 64, lds));
-            bpc = std::max(bpc, 1);
-        }
+        int bpc = 0;
+        if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, lds, &bpc)) return rc;
         const int64_t need = (a.nsb + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
         gru_bwd_kernel<T, NFULL, WAVES, NOUT><<<grid, WAVES * 64, lds, h->stream>>>(a);
@@ -222,15 +218,11 @@ struct MLGrad {
 
     template <bool TOP>
     static int upper_pass(rnnwf_handle* h, const UpperGradArgs& a) {
-        static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
         const void* fn = (const void*)gru_upper_bwd_kernel<NFULL, WAVES, TOP>;
         const size_t lds = U::BYTES + GU::BWD_BYTES + (TOP ? GU::HEAD_BYTES : 0);
         if (lds > 160 * 1024) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: stacked-layer images (%zu B) exceed the 160 KB LDS", lds);
-        if (!bpc) {
-            RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            RNNWF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, WAVES * 64, lds));
-            bpc = std::max(bpc, 1);
-        }
+        int bpc = 0;
+        if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, lds, &bpc)) return rc;
         const int64_t need = (a.nsb + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
         gru_upper_bwd_kernel<NFULL, WAVES, TOP><<<grid, WAVES * 64, lds, h->stream>>>(a);

@@ -127,7 +127,7 @@ struct GruCore {
         for (int t = 0; t < NT; ++t)
             acc[t] = BIAS_LAST ? V4{T(0), T(0), T(0), T(0)} : *reinterpret_cast<const V4*>(binit + (size_t)t * 16 * sizeof(T));
         const VA* av = reinterpret_cast<const VA*>(lds + L::OFF_AVEC) + lane;
-        if (!(ablate & 1)) {
+        if (!RNNWF_ABLATED(ablate, 1)) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
 #pragma unroll
@@ -153,7 +153,7 @@ struct GruCore {
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] += *reinterpret_cast<const V4*>(binit + (size_t)t * 16 * sizeof(T));
         }
-        if (ablate & 2) {      // keep the accumulators alive without the gate arithmetic
+        if (RNNWF_ABLATED(ablate, 2)) {      // keep the accumulators alive without the gate arithmetic
 #pragma unroll
             for (int t = 0; t < NT; ++t) asm volatile("" :: "v"(acc[t]));
             return;

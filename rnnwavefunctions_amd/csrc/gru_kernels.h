@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_base_kernel(PrnnArgs a) {
             int sig;
             if (a.sampling) {
                 // tf.multinomial(log p): class 0 iff u * total < p0
-                const float u = (a.ablate & 32) ? 0.5f : philox_uniform(a.seed, a.step, (uint64_t)(a.sample_offset + sc), n);
+                const float u = RNNWF_ABLATED(a.ablate, 32) ? 0.5f : philox_uniform(a.seed, a.step, (uint64_t)(a.sample_offset + sc), n);
                 sig = ((T)u < prob0(z[0])) ? 0 : 1;
                 word |= (uint32_t)sig << (n & 31);
                 if (((n & 31) == 31 || n == N - 1) && valid && q == 0) a.bits[(int64_t)(n >> 5) * a.ns + s] = word;
@@ -76,13 +76,13 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_base_kernel(PrnnArgs a) {
                 sig = (word >> (n & 31)) & 1;
             }
             const double lsel = (double)(sig ? lp1 : lp0);
-            if (a.lpq && !(a.ablate & 16)) {
+            if (a.lpq && !RNNWF_ABLATED(a.ablate, 16)) {
                 const double loth = (double)(sig ? lp0 : lp1);
                 const int64_t row = a.row_of_pos ? a.row_of_pos[n] : n + 1;
                 if (valid && q == 0) a.lpq[row * a.ns + s] = cum + loth;
             }
             cum += lsel;
-            if (a.hck && n < N - 1 && !(a.ablate & 8)) {
+            if (a.hck && n < N - 1 && !RNNWF_ABLATED(a.ablate, 8)) {
                 T* dst = reinterpret_cast<T*>(a.hck) + (((int64_t)n * a.nsb + sb) * KT) * 64 + lane;
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) dst[kt * 64] = h[kt];
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_flip_kernel(PrnnArgs a) {
         for (int n = i + 1; n < N; ++n) {
             const int sig = spin(n);
             C::step(lds, sig_in, h, lane, a.ablate);
-            if (!(a.ablate & 4)) {
+            if (!RNNWF_ABLATED(a.ablate, 4)) {
                 T z[1];
                 C::head(lds, h, lane, z);
                 T lp0, lp1;
@@ -232,7 +232,7 @@ __device__ __forceinline__ void coop_base_pass(char* lds, const void* wimg, int 
                 own[0] = gru_gate<float>(accr[0], accr[1], accr[2], xc, own[0]);
                 xb[(KT - 1) * 64] = own[0];
             }
-            if (hck && n < N - 1 && !(ablate & 8)) {
+            if (hck && n < N - 1 && !RNNWF_ABLATED(ablate, 8)) {
                 float* dst = reinterpret_cast<float*>(hck) + (((int64_t)n * nsb + sb) * KT) * 64 + lane;
                 if (full) {
 #pragma unroll
@@ -280,7 +280,7 @@ __global__ void __launch_bounds__((NFULL + 1) * 64) prnn_base_coop_kernel(PrnnAr
             log_softmax2(z, lp0, lp1);
             int sig;
             if (a.sampling) {
-                const float u = (a.ablate & 32) ? 0.5f : philox_uniform(a.seed, a.step, (uint64_t)(a.sample_offset + sc), n);
+                const float u = RNNWF_ABLATED(a.ablate, 32) ? 0.5f : philox_uniform(a.seed, a.step, (uint64_t)(a.sample_offset + sc), n);
                 sig = (u < prob0(z)) ? 0 : 1;
                 word |= (uint32_t)sig << (n & 31);
                 if (((n & 31) == 31 || n == N - 1) && valid && q == 0) a.bits[(int64_t)(n >> 5) * a.ns + s] = word;
@@ -288,7 +288,7 @@ __global__ void __launch_bounds__((NFULL + 1) * 64) prnn_base_coop_kernel(PrnnAr
             } else {
                 sig = (word >> (n & 31)) & 1;
             }
-            if (a.lpq && !(a.ablate & 16)) {
+            if (a.lpq && !RNNWF_ABLATED(a.ablate, 16)) {
                 const int64_t row = a.row_of_pos ? a.row_of_pos[n] : n + 1;
                 if (valid && q == 0) a.lpq[row * a.ns + s] = cum + (double)(sig ? lp0 : lp1);
             }

@@ -25,6 +25,14 @@ struct KernelTimer {
     int64_t launches = 0;
 };
 
+// Environment switches, read ONCE in rnnwf_create (never on the per-step path).
+struct Knobs {
+    int engine = 0;               // RNNWF_ENGINE: 0 default, 1 "f32" (f32-input MFMA everywhere), 2 "bf16x3" (pinned)
+    bool no_coop = false;         // RNNWF_NO_COOP=1: base pass always on the one-wave-per-block kernel
+    size_t state_budget = 0;      // RNNWF_STATE_BUDGET_MB << 20 (0: the family's default)
+    int ablate = 0, ablate_base = 0;   // RNNWF_ABLATE / RNNWF_ABLATE_BASE: only in -DRNNWF_DIAGNOSTICS builds (tools/)
+};
+
 struct ParamSpec {
     std::vector<int64_t> shape;
     std::vector<double> value;  // stored in f64, converted to the model type when packed
@@ -73,6 +81,11 @@ struct rnnwf_handle {
     rnnwf::KernelTimer timers[3];
     double work[2] = {0.0, 0.0};
 
+    rnnwf::Knobs knobs;
+    // resident blocks per CU of each kernel this handle has launched (the dynamic-LDS attribute is per device and the
+    // handle is single-threaded by contract, so the cache lives here: handles on other host threads share nothing)
+    std::map<const void*, int> occupancy;
+
     void* comm = nullptr;  // ncclComm_t
     int rank = 0, nranks = 1;
 
@@ -105,6 +118,20 @@ inline int ensure(rnnwf_handle* h, DevBuf& b, size_t bytes) {
     hipError_t e = hipMalloc(&b.p, want);
     if (e != hipSuccess) return h->fail(RNNWF_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
     b.cap = want;
+    return 0;
+}
+
+// Resident blocks per CU of kernel `fn` at `threads` per block and `lds` dynamic bytes; raises the kernel's
+// dynamic-LDS limit on first use.  Cached per handle.
+inline int blocks_per_cu(rnnwf_handle* h, const void* fn, int threads, size_t lds, int* out) {
+    auto it = h->occupancy.find(fn);
+    if (it != h->occupancy.end()) { *out = it->second; return 0; }
+    RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int nb = 0;
+    RNNWF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, lds));
+    nb = nb < 1 ? 1 : nb;
+    h->occupancy[fn] = nb;
+    *out = nb;
     return 0;
 }
 

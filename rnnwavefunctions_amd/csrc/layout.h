@@ -12,6 +12,13 @@
 //   tile 3*NFULL ("mixed")  : register r = gate r of unit 16 NFULL + q  (r = 3 unused)
 // K-steps: KT = 4 NFULL + 1 (k = 4 kt + q).
 #pragma once
+// Timing-only ablation paths (skip MFMAs / gates / head / stores: WRONG numbers) exist only in -DRNNWF_DIAGNOSTICS
+// builds made by tools/; in the release library the conditions are compile-time false.
+#ifdef RNNWF_DIAGNOSTICS
+#define RNNWF_ABLATED(mask, bit) (((mask) & (bit)) != 0)
+#else
+#define RNNWF_ABLATED(mask, bit) false
+#endif
 #include <cstddef>
 #include <cstdint>
 

@@ -17,17 +17,11 @@ constexpr size_t kHsBudget = (size_t)24 << 30;   // bytes of per-site hidden sta
 template <int NFULL, int WAVES>
 struct MLaunch {
     using L = MdLayout<NFULL>;
-    static int blocks_per_cu(rnnwf_handle* h, const void* fn, int* out) {
-        RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES));
-        int nb = 0;
-        RNNWF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, WAVES * 64, L::BYTES));
-        *out = std::max(nb, 1);
-        return 0;
-    }
+    static int blocks_per_cu(rnnwf_handle* h, const void* fn, int* out) { return rnnwf::blocks_per_cu(h, fn, WAVES * 64, L::BYTES, out); }
     static int base(rnnwf_handle* h, const MdArgs& a) {
-        static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
         const void* fn = (const void*)mdrnn_base_kernel<NFULL, WAVES>;
-        if (!bpc) if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
+        int bpc = 0;
+        if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
         const int64_t need = (a.nsb + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
         TimedLaunch tl(h, 0);
@@ -36,9 +30,9 @@ struct MLaunch {
         return 0;
     }
     static int flip_grid(rnnwf_handle* h, int64_t ntiles, unsigned* grid) {
-        static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
         const void* fn = (const void*)mdrnn_flip_kernel<NFULL, WAVES>;
-        if (!bpc) if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
+        int bpc = 0;
+        if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
         const int64_t need = (ntiles + WAVES - 1) / WAVES;
         *grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
         return 0;
@@ -49,7 +43,7 @@ struct MLaunch {
         const size_t ring_bytes = (size_t)grid * WAVES * 2 * a.Nx * ((L::KT + 1) / 2) * 64 * 16;
         if (int rc = ensure(h, h->rowbuf, ring_bytes)) return rc;
         a.ring = (double*)h->rowbuf.p;
-        if (const char* e = getenv("RNNWF_ABLATE")) a.ablate = atoi(e);   // diagnostics only
+        a.ablate = h->knobs.ablate;   // 0 unless a -DRNNWF_DIAGNOSTICS build read RNNWF_ABLATE
         TimedLaunch tl(h, 1);
         mdrnn_flip_kernel<NFULL, WAVES><<<grid, WAVES * 64, L::BYTES, h->stream>>>(a);
         RNNWF_HIP(h, hipGetLastError());
@@ -186,7 +180,7 @@ int get_maps(rnnwf_handle* h, Maps* m) {
 
 int64_t max_chains_per_pass(rnnwf_handle* h) {
     const size_t per_block = (size_t)h->N * hs_bytes_per_block(h);
-    return std::max<int64_t>(1, (int64_t)(state_budget_bytes(kHsBudget) / per_block)) * kChains;
+    return std::max<int64_t>(1, (int64_t)(state_budget_bytes(h, kHsBudget) / per_block)) * kChains;
 }
 
 MdArgs base_args(rnnwf_handle* h, int64_t ns, const Maps& m) {
@@ -370,13 +364,9 @@ struct MGrad {
     }
 
     static int run(rnnwf_handle* h, MdGradArgs a, int64_t R, double* dW) {
-        static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
         const void* fn = (const void*)mdrnn_bwd_kernel<NFULL, WAVES>;
-        if (!bpc) {
-            RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::BYTES));
-            RNNWF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, WAVES * 64, G::BYTES));
-            bpc = std::max(bpc, 1);
-        }
+        int bpc = 0;
+        if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, G::BYTES, &bpc)) return rc;
         const int64_t need = (a.nsb + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
         if (int rc = ensure(h, h->rowbuf, (size_t)grid * WAVES * 2 * a.Nx * G::KT * 64 * 8)) return rc;

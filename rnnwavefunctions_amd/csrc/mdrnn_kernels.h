@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(WAVES * 64, NFULL <= 3 ? 2 : 1) mdrnn_flip_ker
             } else if (pv == p - 1) {
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) hv[kt] = hn[kt];
-            } else if (a.ablate & 2) {
+            } else if (RNNWF_ABLATED(a.ablate, 2)) {
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) hv[kt] = hn[kt] * 0.5;
             } else if (pv <= i) {
@@ -321,13 +321,13 @@ __global__ void __launch_bounds__(WAVES * 64, NFULL <= 3 ? 2 : 1) mdrnn_flip_ker
             }
             C::step(lds, sig_h, sig_v, hn, hv, hn, lane, a.rem);      // in place: step copies its inputs first
             double lp0 = hn[0], lp1 = hn[1], p0;
-            if (!(a.ablate & 4)) C::head(lds, hn, lane, lp0, lp1, p0);
+            if (!RNNWF_ABLATED(a.ablate, 4)) C::head(lds, hn, lane, lp0, lp1, p0);
             uint32_t wp = 0;
 #pragma unroll
             for (int w = 0; w < 8; ++w) if (w == (p >> 5)) wp = words[w];
             lp += ((wp >> (p & 31)) & 1) ? lp1 : lp0;
             // the last row has no vertical successor: nothing reads its states
-            if (p < N - a.Nx && !(a.ablate & 1)) C::store_state(ring + (int64_t)(p % R) * C::KP * 128, hn);
+            if (p < N - a.Nx && !RNNWF_ABLATED(a.ablate, 1)) C::store_state(ring + (int64_t)(p % R) * C::KP * 128, hn);
         }
         if (valid && q == 0) a.lpq[(int64_t)a.row_of_pos[i] * a.ns + s] += lp;
     }

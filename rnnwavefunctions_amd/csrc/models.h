@@ -52,9 +52,9 @@ int mdrnn_vmc_step(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t step, in
 // ---- gradient (grad.hip) ---------------------------------------------------------------------------
 int mdrnn_vmc_gradient(rnnwf_handle* h, double mean_energy, double norm);
 void grad_invalidate(rnnwf_handle* h);
-// bytes of per-site hidden states one pass may hold; RNNWF_STATE_BUDGET_MB overrides the default (tests use it to
-// drive the multi-pass path at small sizes)
-size_t state_budget_bytes(size_t dflt);
+// bytes of per-site hidden states one pass may hold; RNNWF_STATE_BUDGET_MB (read at rnnwf_create) overrides the
+// default (tests use it to drive the multi-pass path at small sizes)
+size_t state_budget_bytes(const rnnwf_handle* h, size_t dflt);
 // h->coupl <- n doubles; skipped when they are what the device already holds
 int upload_couplings(rnnwf_handle* h, const double* src, size_t n);
 

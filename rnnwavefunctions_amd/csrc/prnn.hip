@@ -21,24 +21,14 @@ constexpr int64_t kLogProbChunk = (int64_t)1 << 20;
 template <typename T, int NFULL, int WAVES>
 struct Launch {
     using L = GruLayout<T, NFULL, 1>;
-    static int blocks_per_cu(rnnwf_handle* h, const void* fn, int* out) {
-        RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES));
-        int nb = 0;
-        RNNWF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, WAVES * 64, L::BYTES));
-        *out = std::max(nb, 1);
-        return 0;
-    }
+    static int blocks_per_cu(rnnwf_handle* h, const void* fn, int* out) { return rnnwf::blocks_per_cu(h, fn, WAVES * 64, L::BYTES, out); }
     // fewer 16-chain blocks than SIMDs: the cooperative kernel (NFULL + 1 waves per block) cuts the per-site latency
     static int base_coop(rnnwf_handle* h, const PrnnArgs& a) {
         if constexpr (std::is_same<T, float>::value && NFULL <= 4) {
-            static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
             const void* fn = (const void*)prnn_base_coop_kernel<NFULL>;
             const size_t lds = L::BYTES + (size_t)2 * L::KT * 64 * 4 + 2 * 64 * 4;
-            if (!bpc) {
-                RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                RNNWF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, (NFULL + 1) * 64, lds));
-                bpc = std::max(bpc, 1);
-            }
+            int bpc = 0;
+            if (int rc = rnnwf::blocks_per_cu(h, fn, (NFULL + 1) * 64, lds, &bpc)) return rc;
             const unsigned grid = (unsigned)std::min<int64_t>(a.nsb, (int64_t)bpc * h->cu_count);
             TimedLaunch tl(h, 0);
             prnn_base_coop_kernel<NFULL><<<grid, (NFULL + 1) * 64, lds, h->stream>>>(a);
@@ -47,11 +37,11 @@ struct Launch {
         return 0;
     }
     static int base(rnnwf_handle* h, const PrnnArgs& a) {
-        if (std::is_same<T, float>::value && NFULL <= 4 && a.nsb <= (int64_t)4 * h->cu_count && !getenv("RNNWF_NO_COOP"))
+        if (std::is_same<T, float>::value && NFULL <= 4 && a.nsb <= (int64_t)4 * h->cu_count && !h->knobs.no_coop)
             return base_coop(h, a);
-        static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
         const void* fn = (const void*)prnn_base_kernel<T, NFULL, WAVES>;
-        if (!bpc) if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
+        int bpc = 0;
+        if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
         const int64_t need = (a.nsb + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
         TimedLaunch tl(h, 0);
@@ -60,9 +50,9 @@ struct Launch {
         return 0;
     }
     static int flip(rnnwf_handle* h, const PrnnArgs& a) {
-        static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
         const void* fn = (const void*)prnn_flip_kernel<T, NFULL, WAVES>;
-        if (!bpc) if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
+        int bpc = 0;
+        if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
         const int64_t need = (a.ntiles + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
         TimedLaunch tl(h, 1);
@@ -79,17 +69,11 @@ struct Launch {
 template <int NFULL, int NL, int WAVES>
 struct MLaunchL {
     using M = MlCore<NFULL, NL>;
-    static int blocks_per_cu(rnnwf_handle* h, const void* fn, int* out) {
-        RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)M::BYTES));
-        int nb = 0;
-        RNNWF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, WAVES * 64, M::BYTES));
-        *out = std::max(nb, 1);
-        return 0;
-    }
+    static int blocks_per_cu(rnnwf_handle* h, const void* fn, int* out) { return rnnwf::blocks_per_cu(h, fn, WAVES * 64, M::BYTES, out); }
     static int base(rnnwf_handle* h, const PrnnArgs& a) {
-        static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
         const void* fn = (const void*)prnn_ml_base_kernel<NFULL, NL, WAVES>;
-        if (!bpc) if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
+        int bpc = 0;
+        if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
         const int64_t need = (a.nsb + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
         TimedLaunch tl(h, 0);
@@ -98,9 +82,9 @@ struct MLaunchL {
         return 0;
     }
     static int flip(rnnwf_handle* h, const PrnnArgs& a) {
-        static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
         const void* fn = (const void*)prnn_ml_flip_kernel<NFULL, NL, WAVES>;
-        if (!bpc) if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
+        int bpc = 0;
+        if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
         const int64_t need = (a.ntiles + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
         TimedLaunch tl(h, 1);
@@ -159,13 +143,9 @@ template <int NF32, int RJ, int WAVES, int MODE>
 struct SLaunch {
     using L = SplitLayout<NF32, RJ, 1, MODE>;
     static int flip(rnnwf_handle* h, const PrnnArgs& a, int kt16) {
-        static int bpc_by_device[64] = {}; int& bpc = bpc_by_device[h->cfg.device & 63];   // per device: the LDS attribute is set per device
         const void* fn = (const void*)prnn_flip_split_kernel<NF32, RJ, WAVES, MODE>;
-        if (!bpc) {
-            RNNWF_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES));
-            RNNWF_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, fn, WAVES * 64, L::BYTES));
-            bpc = std::max(bpc, 1);
-        }
+        int bpc = 0;
+        if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, L::BYTES, &bpc)) return rc;
         const int64_t ntiles = (int64_t)(a.N - 1) * ((a.ns + 31) / 32);
         const int64_t need = (ntiles + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
@@ -222,7 +202,7 @@ PrnnArgs base_args(rnnwf_handle* h, int64_t ns) {
     a.N = h->N;
     a.ns = ns;
     a.nsb = (ns + kChains - 1) / kChains;
-    if (const char* e = getenv("RNNWF_ABLATE_BASE")) a.ablate = atoi(e) & (8 | 16 | 32);   // diagnostics only
+    a.ablate = h->knobs.ablate_base & (8 | 16 | 32);   // 0 unless a -DRNNWF_DIAGNOSTICS build read RNNWF_ABLATE_BASE
     return a;
 }
 
@@ -272,7 +252,7 @@ int eloc_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
     if (Bx != 0.0 && N > 1) {
         a.ntiles = (int64_t)(N - 1) * nsb;
         a.sampling = 0;
-        if (const char* e = getenv("RNNWF_ABLATE")) a.ablate |= atoi(e) & 7;   // diagnostics only
+        a.ablate |= h->knobs.ablate & 7;   // 0 unless a -DRNNWF_DIAGNOSTICS build read RNNWF_ABLATE
         if (use_split(h, ns)) {
             if (int rc = launch_flip_split(h, a)) return rc;
             h->work[1] += (double)((ns + 31) / 32) * N * (N - 1) / 2.0 * split_mfma_flops_per_step(h);
@@ -316,7 +296,7 @@ int eloc_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
 
 int64_t max_chains_per_pass(rnnwf_handle* h) {
     const size_t per_block = (size_t)(h->NL > 1 ? h->N : std::max(h->N - 1, 1)) * hck_bytes_per_block(h);
-    const int64_t blocks = std::max<int64_t>(1, (int64_t)(state_budget_bytes(kHckBudget) / per_block));
+    const int64_t blocks = std::max<int64_t>(1, (int64_t)(state_budget_bytes(h, kHckBudget) / per_block));
     return blocks * kChains;
 }
 
@@ -325,9 +305,8 @@ int64_t max_chains_per_pass(rnnwf_handle* h) {
 int rnnwf::prnn_pack_image(rnnwf_handle* h, std::vector<char>& img) {
     // flip-pass engine: bf16x3 on the matrix core for the f32 models up to 68 units (RNNWF_ENGINE=f32 keeps the
     // f32-input MFMA everywhere); the base pass, sampling and log_probability always run the f32-MFMA kernels
-    const char* eng = getenv("RNNWF_ENGINE");
-    h->engine_split = !h->f64 && h->NL == 1 && h->NFULL <= 4 && !(eng && std::string(eng) == "f32");
-    h->engine_forced = eng && std::string(eng) == "bf16x3";
+    h->engine_split = !h->f64 && h->NL == 1 && h->NFULL <= 4 && h->knobs.engine != 1;
+    h->engine_forced = h->knobs.engine == 2;
     if (h->engine_split) {
         std::vector<char> simg;
         SPLIT_DISPATCH(h, { simg = K::pack(h); break; });

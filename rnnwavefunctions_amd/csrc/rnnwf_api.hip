@@ -66,12 +66,22 @@ static void declare_params(rnnwf_handle* h) {
     }
 }
 
-size_t rnnwf::state_budget_bytes(size_t dflt) {
+size_t rnnwf::state_budget_bytes(const rnnwf_handle* h, size_t dflt) {
+    return h->knobs.state_budget ? h->knobs.state_budget : dflt;
+}
+
+// The environment is consulted here and nowhere else: once per handle, at creation.
+static void read_knobs(Knobs& k) {
+    if (const char* e = getenv("RNNWF_ENGINE")) k.engine = !strcmp(e, "f32") ? 1 : !strcmp(e, "bf16x3") ? 2 : 0;
+    if (const char* e = getenv("RNNWF_NO_COOP")) k.no_coop = atoi(e) != 0;
     if (const char* e = getenv("RNNWF_STATE_BUDGET_MB")) {
         const long long mb = atoll(e);
-        if (mb > 0) return (size_t)mb << 20;
+        if (mb > 0) k.state_budget = (size_t)mb << 20;
     }
-    return dflt;
+#ifdef RNNWF_DIAGNOSTICS      // timing-only switches that produce WRONG numbers: tools/ builds only (rnnwf_backend_name says so)
+    if (const char* e = getenv("RNNWF_ABLATE")) k.ablate = atoi(e);
+    if (const char* e = getenv("RNNWF_ABLATE_BASE")) k.ablate_base = atoi(e);
+#endif
 }
 
 int rnnwf::upload_couplings(rnnwf_handle* h, const double* src, size_t n) {
@@ -95,7 +105,11 @@ static int pick_nfull(int H, bool f64, bool mdrnn) {
 // -------------------------------------------------------------------------------------------------
 // life cycle
 // -------------------------------------------------------------------------------------------------
+#ifdef RNNWF_DIAGNOSTICS
+extern "C" const char* rnnwf_backend_name(void) { return "hip-gfx950-diagnostics"; }
+#else
 extern "C" const char* rnnwf_backend_name(void) { return "hip-gfx950"; }
+#endif
 extern "C" int rnnwf_abi_version(void) { return RNNWF_ABI_VERSION; }
 
 extern "C" const char* rnnwf_last_error(const rnnwf_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
@@ -160,6 +174,7 @@ extern "C" int rnnwf_create(const rnnwf_config* cfg, rnnwf_handle** out) {
     h->cu_count = prop.multiProcessorCount;
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return fail_hip("hipStreamCreate", e);
     if ((e = hipHostMalloc(&h->pinned, 4096, hipHostMallocDefault)) != hipSuccess) return fail_hip("hipHostMalloc", e);
+    read_knobs(h->knobs);
     declare_params(h);
     *out = h;
     return RNNWF_OK;

@@ -186,11 +186,12 @@ def test_cooperative_base_pass_is_bit_identical(N, H, ns, monkeypatch):
     s1 = wf.sample(ns, seed=4, step=1)
     a1 = wf.log_amp(s1)
     e1, n1 = wf.j1j2_eloc(s1, J1, J2, Bz)
-    monkeypatch.setenv("RNNWF_NO_COOP", "1")
+    monkeypatch.setenv("RNNWF_NO_COOP", "1")                 # read once, at rnnwf_create
+    wf = make_wf(N, H, prm)
+    monkeypatch.delenv("RNNWF_NO_COOP")
     s2 = wf.sample(ns, seed=4, step=1)
     a2 = wf.log_amp(s1)
     e2, n2 = wf.j1j2_eloc(s1, J1, J2, Bz)
-    monkeypatch.delenv("RNNWF_NO_COOP")
     assert np.array_equal(s1, s2) and np.array_equal(a1, a2)
     assert n1 == n2 and np.array_equal(e1, e2)
     assert np.all(s1.sum(axis=1) == N // 2)

@@ -264,7 +264,7 @@ def test_both_flip_engines_agree_with_the_f64_oracle(N, H, ns, monkeypatch):
     got = {}
     for engine in ("f32", "bf16x3"):
         monkeypatch.setenv("RNNWF_ENGINE", engine)
-        wf = make_wf(_lib.MODEL_GRU1D, N, H, prm)            # the engine is chosen when the parameters are committed
+        wf = make_wf(_lib.MODEL_GRU1D, N, H, prm)            # the environment is read once, at rnnwf_create
         lp = np.zeros((N + 1) * ns)
         e = wf.tfim_eloc(s, Jz, 1.1, log_probs=lp)
         assert wf.engine_name() == ("bf16x3" if engine == "bf16x3" else "f32mfma")   # RNNWF_ENGINE pins the engine
@@ -362,8 +362,8 @@ def test_stacked_layers_limits_and_facade():
 
 
 def test_multi_pass_estimators_equal_the_single_pass(monkeypatch):
-    """Batches larger than the hidden-state budget run in several passes (RNNWF_STATE_BUDGET_MB shrinks the budget so
-    that this happens at test sizes); results must not depend on the pass boundaries."""
+    """Batches larger than the hidden-state budget run in several passes (RNNWF_STATE_BUDGET_MB, read at rnnwf_create,
+    shrinks the budget so that this happens at test sizes); results must not depend on the pass boundaries."""
     from rnnwavefunctions_amd import _lib
     rng = np.random.RandomState(0)
     N, H, ns = 24, 20, 3000                                   # checkpoints: 23 * 188 * 5 KB = 24 MB
@@ -374,11 +374,12 @@ def test_multi_pass_estimators_equal_the_single_pass(monkeypatch):
         lp1 = np.zeros((N + 1) * ns)
         e1 = wf.tfim_eloc(s, np.ones(N), 1.0, log_probs=lp1)
         monkeypatch.setenv("RNNWF_STATE_BUDGET_MB", "1")
+        wf = make_wf(model, N, H, prm)
+        monkeypatch.delenv("RNNWF_STATE_BUDGET_MB")
         lp2 = np.zeros((N + 1) * ns)
         e2 = wf.tfim_eloc(s, np.ones(N), 1.0, log_probs=lp2)
         with pytest.raises(_lib.RnnwfError, match="split the batch"):
             wf.vmc_step(ns, seed=1, step=0, couplings=np.append(np.ones(N), 1.0))
-        monkeypatch.delenv("RNNWF_STATE_BUDGET_MB")
         assert np.array_equal(e1, e2) and np.array_equal(lp1, lp2)
     # 2D MDRNN and the complex RNN take the same route
     from rnnwavefunctions_amd import params as PP
@@ -387,16 +388,21 @@ def test_multi_pass_estimators_equal_the_single_pass(monkeypatch):
     s2 = rng.randint(0, 2, (2000, 4, 4)).astype(np.int32)
     e1 = wf.tfim_eloc(s2, np.ones((4, 4)), 2.0)
     monkeypatch.setenv("RNNWF_STATE_BUDGET_MB", "1")
-    e2 = wf.tfim_eloc(s2, np.ones((4, 4)), 2.0)
+    wf = _lib.NativeWavefunction(_lib.MODEL_MDRNN2D, 4, 4, (20,))
     monkeypatch.delenv("RNNWF_STATE_BUDGET_MB")
+    wf.set_params(PP.init_mdrnn_params(20, seed=3), scope=SCOPE)
+    e2 = wf.tfim_eloc(s2, np.ones((4, 4)), 2.0)
     assert np.array_equal(e1, e2)
     wfc = _lib.NativeWavefunction(_lib.MODEL_CRNN_U1, 12, 1, (20,))
-    wfc.set_params(trained_like(20, seed=5, heads=("wf_dense_ampl", "wf_dense_phase")), scope=SCOPE)
+    prmc = trained_like(20, seed=5, heads=("wf_dense_ampl", "wf_dense_phase"))
+    wfc.set_params(prmc, scope=SCOPE)
     sc = wfc.sample(3000, seed=2, step=0)
     e1 = wfc.j1j2_eloc(sc, np.ones(12), 0.5 * np.ones(12), np.zeros(12))
     monkeypatch.setenv("RNNWF_STATE_BUDGET_MB", "1")
-    e2 = wfc.j1j2_eloc(sc, np.ones(12), 0.5 * np.ones(12), np.zeros(12))
+    wfc = _lib.NativeWavefunction(_lib.MODEL_CRNN_U1, 12, 1, (20,))
     monkeypatch.delenv("RNNWF_STATE_BUDGET_MB")
+    wfc.set_params(prmc, scope=SCOPE)
+    e2 = wfc.j1j2_eloc(sc, np.ones(12), 0.5 * np.ones(12), np.zeros(12))
     assert e1[1] == e2[1] and np.allclose(e1[0], e2[0], rtol=1e-6, atol=1e-6)
 
 
@@ -423,11 +429,12 @@ def test_cooperative_base_pass_is_bit_identical(N, H, ns, monkeypatch):
     s1, lg1 = wf.sample(ns, seed=9, step=1, return_log=True)
     lp1 = wf.log_prob(s1)
     e1 = wf.tfim_eloc(s1, np.ones(N), 1.0)
-    monkeypatch.setenv("RNNWF_NO_COOP", "1")
+    monkeypatch.setenv("RNNWF_NO_COOP", "1")                 # read once, at rnnwf_create
+    wf = make_wf(_lib.MODEL_GRU1D, N, H, prm)
+    monkeypatch.delenv("RNNWF_NO_COOP")
     s2, lg2 = wf.sample(ns, seed=9, step=1, return_log=True)
     lp2 = wf.log_prob(s1)
     e2 = wf.tfim_eloc(s1, np.ones(N), 1.0)
-    monkeypatch.delenv("RNNWF_NO_COOP")
     assert np.array_equal(s1, s2) and np.array_equal(lg1, lg2)
     assert np.array_equal(lp1, lp2) and np.array_equal(e1, e2)
 
