@@ -28,10 +28,10 @@ def _newest_header():
     return max(os.path.getmtime(h) for h in hs)
 
 
-def _compile(src, extra):
-    obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+def _compile(src, extra, objdir=None):
+    obj = os.path.join(objdir or OBJDIR, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
-    if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), _newest_header()) and not extra:
+    if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), _newest_header()) and (not extra or extra == ["-DRNNWF_DIAGNOSTICS"]):
         return obj, ""
     cmd = [HIPCC] + FLAGS + extra + ["-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -40,23 +40,29 @@ def _compile(src, extra):
     return obj, r.stderr
 
 
-def build(verbose=False, extra_flags=(), jobs=None):
-    os.makedirs(OBJDIR, exist_ok=True)
+def build(verbose=False, extra_flags=(), jobs=None, variant=None):
+    """variant=None: the product library.  variant="diag": librnnwf_hip_diag.so, compiled with -DRNNWF_DIAGNOSTICS
+    (timing-only ablation switches and in-kernel cycle stamps; used by tools/ only, never loaded by the package)."""
     extra = list(extra_flags)
+    objdir, lib = OBJDIR, LIB
+    if variant == "diag":
+        extra.append("-DRNNWF_DIAGNOSTICS")
+        objdir, lib = os.path.join(LIBDIR, "obj_diag"), os.path.join(LIBDIR, "librnnwf_hip_diag.so")
+    os.makedirs(objdir, exist_ok=True)
     with ThreadPoolExecutor(max_workers=jobs or min(len(SOURCES), os.cpu_count() or 4)) as ex:
-        results = list(ex.map(lambda s: _compile(s, extra), SOURCES))
+        results = list(ex.map(lambda s: _compile(s, extra, objdir), SOURCES))
     objs = [o for o, _ in results]
     if verbose:
         for _, log in results:
             if log.strip():
                 print(log, file=sys.stderr)
-    if (not os.path.exists(LIB)) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+    if (not os.path.exists(lib)) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (" ".join(cmd), r.stderr[-4000:]))
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(verbose="-v" in sys.argv))
+    print(build(verbose="-v" in sys.argv, variant="diag" if "--diag" in sys.argv else None))

@@ -34,6 +34,7 @@ struct PrnnArgs {
     int64_t ntiles;              // flip pass: (N-1) * nsb
     int32_t ablate;              // diagnostics only (RNNWF_ABLATE): 1 skip MFMAs, 2 skip gate arithmetic, 4 skip head;
                                  // base pass: 8 no checkpoint stores, 16 no flip-base stores, 32 constant uniform
+    unsigned long long* stamps;  // diagnostics builds only (RNNWF_STAMPS): per wave 8 counters, see prnn_flip_pp_kernel
 };
 
 

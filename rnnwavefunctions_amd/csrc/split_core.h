@@ -240,6 +240,81 @@ struct SplitCore {
         }
     }
 
+    // ---- the step in two segments, for the ping-pong kernels (split_kernels.h: prnn_flip_pp_kernel) -----------------
+    // A SIMD issues one vector instruction per ~4 cycles and an MFMA holds the matrix pipe for 32: run back to back by
+    // one wave, the 95 MFMAs and the ~470 VALU instructions of a step add up (measured: tools/microbench/issue_model,
+    // profiles/r02_issue_model.txt).  Two waves of a SIMD that alternate - one in its MFMA segment while the other
+    // is in its VALU segment, workgroup barrier between segments - overlap the two almost completely.
+    // mfma_seg: accumulators <- bias / one-hot rows + the six products (no VALU work besides the B-register moves).
+    static __device__ __forceinline__ void mfma_seg(const char* lds, int sig, const unsigned (&R)[3][NR], f32x16 (&acc)[NT], int lane) {
+        static_assert(MODE != 0, "ping-pong kernels use the K-packed layouts (bias / input rows in the accumulator table)");
+        const int hh = lane >> 5;
+        asm volatile("" ::: "memory");
+        const u32x4* av = reinterpret_cast<const u32x4*>(lds + L::OFF_A) + lane;
+        constexpr int ORD[6][2] = {{2, 0}, {1, 1}, {0, 2}, {1, 0}, {0, 1}, {0, 0}};
+        constexpr int NK = KS;
+        const f32x16* ci = reinterpret_cast<const f32x16*>(lds + L::OFF_CI) + (size_t)sig * NT * 2 + hh;
+        auto a_index = [&](int t, int k) {
+            if constexpr (MODE == 1) return (k * NT + t) * 64;
+            else return k < 6 * NQ ? ((t * 3 + ORD[k / NQ][0]) * NQ + k % NQ) * 64 : (NT * 3 * NQ + t) * 64;
+        };
+        auto b_reg = [&](int k, int j) -> unsigned {
+            if constexpr (MODE == 1) {
+                const int f = 4 * k + j;
+                return f < 6 * NRM ? R[ORD[f / NRM][1]][f % NRM] : 0u;
+            } else {
+                if constexpr (MODE == 2) {
+                    if (k >= 6 * NQ) return j < 3 ? R[j][NRM] : 0u;
+                }
+                return R[ORD[k / NQ][1]][4 * (k % NQ) + j];
+            }
+        };
+        // all NT tiles per k-step: one B quad per k-step, fragments of k-step k+1 in flight while k-step k multiplies
+        u32x4 cur[NT], nxt[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = ci[t * 2];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) cur[t] = av[a_index(t, 0)];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            if (k + 1 < NK) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) nxt[t] = av[a_index(t, k + 1)];
+            }
+            const u32x4 bq = {b_reg(k, 0), b_reg(k, 1), b_reg(k, 2), b_reg(k, 3)};
+            const bf16x8 b = __builtin_bit_cast(bf16x8, bq);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur[t]), b, acc[t], 0, 0, 0);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int t = 0; t < NT; ++t) cur[t] = nxt[t];
+        }
+    }
+    // gates_seg: new state of this lane's units from the accumulators (pure VALU + the candidate's input table)
+    static __device__ __forceinline__ void gates_seg(const char* lds, int sig, const f32x16 (&acc)[NT], float (&h)[NU], int lane) {
+        const int hh = lane >> 5;
+        const float* xc = reinterpret_cast<const float*>(lds + L::OFF_XC) + (size_t)((sig * 2 + hh) * L::NUP);
+#pragma unroll
+        for (int e = 0; e < NU; ++e) {
+            float ar, au, ac;
+            if (e < 16 * NF32) {
+                ar = acc[3 * (e / 16)][e % 16];
+                au = acc[3 * (e / 16) + 1][e % 16];
+                ac = acc[3 * (e / 16) + 2][e % 16];
+            } else {
+                const int j = e - 16 * NF32;
+                ar = acc[3 * NF32 + (j) / 16][(j) % 16];
+                au = acc[3 * NF32 + (RJ + j) / 16][(RJ + j) % 16];
+                ac = acc[3 * NF32 + (2 * RJ + j) / 16][(2 * RJ + j) % 16];
+            }
+            const float rg = Act<float>::sigmoid_scaled(ar);
+            const float ug = Act<float>::sigmoid_scaled(au);
+            const float cc = Act<float>::tanh_scaled(xc[e] + rg * ac);
+            h[e] = cc + ug * (h[e] - cc);
+        }
+    }
+
     // output head rows (row 0: softmax logit difference), reduced over the two lane halves
     static __device__ __forceinline__ void head(const char* lds, const float (&h)[NU], int lane, float (&z)[NOUT]) {
         const int hh = lane >> 5;

@@ -18,6 +18,7 @@ import numpy as np
 from . import _lib
 from . import distributed as D
 from . import params as P
+from . import tf_checkpoint as T
 
 
 class Adam:
@@ -42,6 +43,32 @@ class Adam:
             params[k] = (params[k].astype(np.float64) - lr_t * self.m[k] / (np.sqrt(self.v[k]) + self.eps)).astype(params[k].dtype)
         return params
 
+    # -- what tf.train.Saver() keeps of the optimizer (TrainingRNN_1DTFIM.py:163-166): slots <var>/Adam, <var>/Adam_1,
+    #    beta1_power / beta2_power (beta^(t+1) after t steps, float32 scalars) and the un-named global step `Variable`
+    def state_tensors(self, params, scope):
+        out = {}
+        for k, v in params.items():
+            out[k + "/Adam"] = self.m.get(k, np.zeros(v.shape)).astype(v.dtype)
+            out[k + "/Adam_1"] = self.v.get(k, np.zeros(v.shape)).astype(v.dtype)
+        out[scope + "/beta1_power"] = np.array(self.b1 ** (self.t + 1), dtype=np.float32)
+        out[scope + "/beta2_power"] = np.array(self.b2 ** (self.t + 1), dtype=np.float32)
+        out["Variable"] = np.array(self.t, dtype=np.int32)
+        return out
+
+    def load_state(self, opt, names):
+        """`opt` as returned by tf_checkpoint.split_saver_variables; slots are matched to `names` by their tail."""
+        tail = lambda k: k.split("/", 1)[-1]
+        m = {tail(k): v for k, v in opt["m"].items()}
+        v2 = {tail(k): v for k, v in opt["v"].items()}
+        for k in names:
+            if tail(k) in m and tail(k) in v2:
+                self.m[k] = np.asarray(m[tail(k)], dtype=np.float64)
+                self.v[k] = np.asarray(v2[tail(k)], dtype=np.float64)
+        if opt.get("global_step") is not None:
+            self.t = int(opt["global_step"])
+        elif opt.get("beta1_power"):
+            self.t = max(int(round(np.log(opt["beta1_power"]) / np.log(self.b1))) - 1, 0)
+
 
 def cost_gradient(native, params, scope, mean_energy, norm, allreduce=False):
     """{scoped tf name: gradient} of the reference cost on the batch of the last vmc_step."""
@@ -51,7 +78,7 @@ def cost_gradient(native, params, scope, mean_energy, norm, allreduce=False):
 
 
 def _train(wf, params, scope, couplings, numsteps, numsamples, seed, lr, lr_of_it, opt, complex_energy, comm, verbose,
-           on_step=None):
+           on_step=None, history=None):
     """The loop all four drivers share (1DTFIM/TrainingRNN_1DTFIM.py:199-227 and its siblings): sample + local
     energies + moments on the GPU, mean/var, print every 10 steps, gradient of the cost, Adam.
 
@@ -60,8 +87,8 @@ def _train(wf, params, scope, couplings, numsteps, numsamples, seed, lr, lr_of_i
     gradient partial sums are all-reduced, and every rank applies the identical Adam step."""
     comm = comm or D.ShardComm()
     offset, count = D.shard_range(numsamples, comm.rank, comm.world)
-    meanEnergy, varEnergy = [], []
-    for it in range(numsteps + 1):
+    meanEnergy, varEnergy = history if history is not None else ([], [])
+    for it in range(len(meanEnergy), numsteps + 1):       # `for it in range(len(meanEnergy),numsteps+1)` (:199): a restored run resumes
         m = wf.vmc_step(count, seed=seed, step=it, couplings=couplings, sample_offset=offset)["moments"]
         s1, s2, n, si = comm.allreduce(m)
         meanE = complex(s1 / n, si / n) if complex_energy else s1 / n
@@ -71,7 +98,7 @@ def _train(wf, params, scope, couplings, numsteps, numsamples, seed, lr, lr_of_i
         if verbose and comm.rank == 0 and it % 10 == 0:
             print("mean(E): {0}, var(E): {1}, #samples {2}, #Step {3} \n\n".format(meanEnergy[-1], varE, numsamples, it))
         if on_step is not None and comm.rank == 0:
-            on_step(it, meanEnergy, varEnergy, params)
+            on_step(it, meanEnergy, varEnergy, params, opt)
         native_reduce = comm.native is not None and comm.world > 1
         grads = cost_gradient(wf, params, scope, meanE, n, allreduce=native_reduce)
         if not native_reduce:
@@ -90,24 +117,64 @@ def _resolve_comm(comm, wf):
     return comm
 
 
-def _saver(save_dir, tag_mean, tag_var, tag_model):
+def _resolve_device(device, comm):
+    """device=None (the drivers' default): GPU 0, or - one process per GPU under `python -m torch.distributed.run`
+    (comm="env") - the launcher's LOCAL_RANK, so that every rank opens its own GPU (RCCL refuses two ranks on one)."""
+    if device is not None:
+        return int(device)
+    return int(os.environ.get("LOCAL_RANK", "0")) if comm == "env" else 0
+
+
+def _fit(wf, params, scope, couplings, numsteps, numsamples, seed, lr, lr_of_it, opt, complex_energy, comm, verbose,
+         save_dir, tags, restore):
+    """_train with the reference's saving cadence and, with restore=True, its restore branch in front."""
+    history = None
+    if restore:
+        if save_dir is None:
+            raise ValueError("restore=True needs save_dir (where the checkpoint and the energy histories live)")
+        params, history = _restore(save_dir, tags[0], tags[1], tags[2], params, opt, scope)
+        wf.set_params(params, scope=scope)
+    return _train(wf, params, scope, couplings, numsteps, numsamples, seed, lr, lr_of_it, opt, complex_energy, comm,
+                  verbose, _saver(save_dir, tags[0], tags[1], tags[2], scope), history)
+
+
+def _saver(save_dir, tag_mean, tag_var, tag_model, scope="RNNwavefunction"):
+    """The reference's saving cadence (:217-227): energies every 10 steps as .npy, the model every 500 steps as a TF
+    checkpoint `<tag_model>.ckpt` (V2 tensor bundle written by tf_checkpoint.py: the model variables under their TF
+    names plus what tf.train.Saver() holds of the optimizer - Adam slots, beta powers, global step)."""
     if save_dir is None:
         return None
 
-    def on_step(it, meanEnergy, varEnergy, params):
+    def on_step(it, meanEnergy, varEnergy, params, opt=None):
+        if it % 500 == 0:
+            extra = opt.state_tensors(params, scope) if opt is not None else {}
+            T.write_checkpoint(os.path.join(save_dir, tag_model + ".ckpt"), dict(params, **extra))
         if it % 10 == 0:
             np.save(os.path.join(save_dir, tag_mean + ".npy"), meanEnergy)
             np.save(os.path.join(save_dir, tag_var + ".npy"), varEnergy)
-        if it % 500 == 0:
-            P.save_npz(os.path.join(save_dir, tag_model + ".npz"), params)
     return on_step
 
 
+def _restore(save_dir, tag_mean, tag_var, tag_model, params, opt, scope):
+    """The reference's restore branch (:172-183, commented out there): model + optimizer from the checkpoint, the
+    energy histories from the .npy files; training then resumes at iteration len(meanEnergy)."""
+    from .wavefunctions import match_checkpoint_names
+    model, ostate = T.split_saver_variables(T.read_checkpoint(os.path.join(save_dir, tag_model + ".ckpt")))
+    params = match_checkpoint_names(params, model, scope)
+    opt.load_state(ostate, list(params))
+    meanEnergy = np.load(os.path.join(save_dir, tag_mean + ".npy")).tolist()
+    varEnergy = np.load(os.path.join(save_dir, tag_var + ".npy")).tolist()
+    # the checkpoint is written every 500 steps, the histories every 10: resume from the checkpoint's step
+    keep = min(opt.t, len(meanEnergy))
+    return params, (meanEnergy[:keep], varEnergy[:keep])
+
+
 def run_1DTFIM(numsteps=10 ** 4, systemsize=20, num_units=50, Bx=1, num_layers=1, numsamples=500, learningrate=5e-3,
-               seed=111, save_dir=None, device=0, verbose=True, comm=None):
+               seed=111, save_dir=None, device=None, verbose=True, comm=None, restore=False):
     """Train the 1D pRNN wave function on the open transverse-field Ising chain; returns (meanEnergy, varEnergy)
-    lists with one entry per iteration, as the reference's run_1DTFIM.  `comm` (distributed.ShardComm) shards the
-    batch over one process per GPU."""
+    lists with one entry per iteration, as the reference's run_1DTFIM.  `comm` (distributed.ShardComm, or "env" under
+    torch.distributed.run) shards the batch over one process per GPU; `save_dir` turns on the reference's saving
+    (energies every 10 steps, TF checkpoint every 500), `restore=True` its restore branch (:172-183)."""
     if not 1 <= num_layers <= 3:
         raise ValueError("num_layers must be 1..3 (stacked layers: num_units <= 52 for 2, <= 36 for 3)")
     N = systemsize
@@ -115,7 +182,7 @@ def run_1DTFIM(numsteps=10 ** 4, systemsize=20, num_units=50, Bx=1, num_layers=1
     Jz = +np.ones(N)
     units = [num_units] * num_layers
     params = P.init_gru_params(units, seed=seed, scope=scope)
-    wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D, N, 1, tuple(units), device=device)
+    wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D, N, 1, tuple(units), device=_resolve_device(device, comm))
     wf.set_params(params, scope=scope)
     comm = _resolve_comm(comm, wf)
     if verbose and (comm is None or comm.rank == 0):
@@ -124,16 +191,17 @@ def run_1DTFIM(numsteps=10 ** 4, systemsize=20, num_units=50, Bx=1, num_layers=1
         print("The number of params is {0}".format(P.count_params(params)))
     ending = "_units" + "".join("_{0}".format(u) for u in units)
     tag = "_N" + str(N) + "_samp" + str(numsamples) + "_Jz" + str(Jz[0]) + "_Bx" + str(Bx) + "_GRURNN_OBC_TFIM" + ending
-    meanEnergy, varEnergy, params = _train(
+    meanEnergy, varEnergy, params = _fit(
         wf, params, scope, np.append(Jz, float(Bx)), numsteps, numsamples, seed, np.float64(learningrate),
-        lambda lr0, it: lr0, Adam(), False, comm, verbose,
-        _saver(save_dir, "meanEnergy" + tag, "varEnergy" + tag, "RNNwavefunction" + tag))
+        lambda lr0, it: lr0, Adam(), False, comm, verbose, save_dir,
+        ("meanEnergy" + tag, "varEnergy" + tag, "RNNwavefunction" + tag), restore)
     run_1DTFIM.last_params = params
     return meanEnergy, varEnergy
 
 
 def run_J1J2(numsteps=10 ** 5, systemsize=20, J1_=1.0, J2_=0.0, Marshall_sign=False, num_units=50, num_layers=1,
-             numsamples=500, learningrate=2.5 * 1e-4, seed=111, save_dir=None, device=0, verbose=True, comm=None):
+             numsamples=500, learningrate=2.5 * 1e-4, seed=111, save_dir=None, device=None, verbose=True, comm=None,
+             restore=False):
     """Train the complex RNN wave function (U(1) zero magnetisation) on the open J1-J2 chain; returns
     (meanEnergy, varEnergy) as the reference's run_J1J2 (meanEnergy complex, varEnergy = var of the real part).
 
@@ -147,7 +215,7 @@ def run_J1J2(numsteps=10 ** 5, systemsize=20, J1_=1.0, J2_=0.0, Marshall_sign=Fa
     lr = np.float64(learningrate)
     units = [num_units] * num_layers
     params = P.init_gru_params(units, seed=seed, scope=scope, heads=("wf_dense_ampl", "wf_dense_phase"))
-    wf = _lib.NativeWavefunction(_lib.MODEL_CRNN_U1, N, 1, tuple(units), device=device)
+    wf = _lib.NativeWavefunction(_lib.MODEL_CRNN_U1, N, 1, tuple(units), device=_resolve_device(device, comm))
     wf.set_params(params, scope=scope)
     comm = _resolve_comm(comm, wf)
     if verbose and (comm is None or comm.rank == 0):
@@ -156,31 +224,31 @@ def run_J1J2(numsteps=10 ** 5, systemsize=20, J1_=1.0, J2_=0.0, Marshall_sign=Fa
     couplings = np.concatenate([J1_ * np.ones(N), J2_ * np.ones(N), np.zeros(N), [periodic, 0.0]])
     ending = "_units" + "".join("_{0}".format(u) for u in units)
     tag = "_N" + str(N) + "_samp" + str(numsamples) + "_lradap" + str(lr) + "_complexGRURNN_J1J2" + str(float(J2_)) + ending + "_zeromag"
-    meanEnergy, varEnergy, params = _train(
+    meanEnergy, varEnergy, params = _fit(
         wf, params, scope, couplings, numsteps, numsamples, seed, lr, lambda lr0, it: lr0,
-        Adam(beta1=0.9, beta2=0.999, epsilon=1e-8), True, comm, verbose,
-        _saver(save_dir, "meanEnergy" + tag, "varEnergy" + tag, "RNNwavefunction" + tag))
+        Adam(beta1=0.9, beta2=0.999, epsilon=1e-8), True, comm, verbose, save_dir,
+        ("meanEnergy" + tag, "varEnergy" + tag, "RNNwavefunction" + tag), restore)
     run_J1J2.last_params = params
     return meanEnergy, varEnergy
 
 
 def _run_2d(model, params, units, Nx, Ny, Bx, numsteps, numsamples, lr, lr_of_it, seed, save_dir, tag, device, verbose,
-            comm):
+            comm, restore=False):
     """Shared part of the two 2D drivers (both: cost of TrainingRNN_1DTFIM.py:156 on float64 wave functions,
     default Adam, learning rate adapted per iteration)."""
     scope = "RNNwavefunction"
-    wf = _lib.NativeWavefunction(model, Nx, Ny, tuple(units), device=device)
+    wf = _lib.NativeWavefunction(model, Nx, Ny, tuple(units), device=_resolve_device(device, comm))
     wf.set_params(params, scope=scope)
     comm = _resolve_comm(comm, wf)
     if verbose and (comm is None or comm.rank == 0):
         print("The number of params is {0}".format(P.count_params(params)))
     couplings = np.append(np.ones(Nx * Ny), float(Bx))          # Jz = +np.ones((Nx, Ny))
-    return _train(wf, params, scope, couplings, numsteps, numsamples, seed, lr, lr_of_it, Adam(), False, comm, verbose,
-                  _saver(save_dir, "meanEnergy_" + tag, "varEnergy_" + tag, "RNNwavefunction_" + tag))
+    return _fit(wf, params, scope, couplings, numsteps, numsamples, seed, lr, lr_of_it, Adam(), False, comm, verbose,
+                save_dir, ("meanEnergy_" + tag, "varEnergy_" + tag, "RNNwavefunction_" + tag), restore)
 
 
 def run_2DTFIM_2DRNN(numsteps=2 * 10 ** 4, systemsize_x=5, systemsize_y=5, Bx=+2, num_units=50, numsamples=500,
-                     learningrate=5e-3, seed=111, save_dir=None, device=0, verbose=True, comm=None):
+                     learningrate=5e-3, seed=111, save_dir=None, device=None, verbose=True, comm=None, restore=False):
     """Train the 2D MDRNN (float64, zig-zag path) on the open square-lattice transverse-field Ising model;
     learning rate  lr (1 + it/5000)^-1  (Training2DRNN_2DTFIM.py:228).  The reference builds Jz from Nx, Ny one
     line before it defines them (:96-99, a NameError as published); here the sizes are read first."""
@@ -191,13 +259,15 @@ def run_2DTFIM_2DRNN(numsteps=2 * 10 ** 4, systemsize_x=5, systemsize_y=5, Bx=+2
     tag = "2DVanillaRNN_" + str(Nx) + "x" + str(Ny) + "_Bx" + str(Bx) + "_lradap" + str(lr) + "_samp" + str(numsamples) + \
         "_units" + "".join("_{0}".format(u) for u in units)
     meanE, varE, params = _run_2d(_lib.MODEL_MDRNN2D, params, units, Nx, Ny, Bx, numsteps, numsamples, lr,
-                                  lambda lr0, it: lr0 * (1 + it / 5000) ** (-1), seed, save_dir, tag, device, verbose, comm)
+                                  lambda lr0, it: lr0 * (1 + it / 5000) ** (-1), seed, save_dir, tag, device, verbose, comm,
+                                  restore)
     run_2DTFIM_2DRNN.last_params = params
     return meanE, varE
 
 
 def run_2DTFIM_1DRNN(numsteps=2 * 10 ** 4, systemsize_x=5, systemsize_y=5, Bx=+2, num_units=50, num_layers=1,
-                     numsamples=500, learningrate=1e-3, seed=333, save_dir=None, device=0, verbose=True, comm=None):
+                     numsamples=500, learningrate=1e-3, seed=333, save_dir=None, device=None, verbose=True, comm=None,
+                     restore=False):
     """Train the float64 1D GRU wave function over the raster path of the square lattice; learning rate
     1 / (1/lr + it/10)  (Training1DRNN_2DTFIM.py:231).  The reference seeds numpy / TF with `seed` but builds the
     wave function with its class default seed 111 (:104); the initial weights here follow the latter."""
@@ -210,6 +280,7 @@ def run_2DTFIM_1DRNN(numsteps=2 * 10 ** 4, systemsize_x=5, systemsize_y=5, Bx=+2
     tag = "GRURNN_" + str(Nx) + "x" + str(Ny) + "_Bx" + str(Bx) + "_lradap" + str(lr) + "_samp" + str(numsamples) + \
         "_units" + "".join("_{0}".format(u) for u in units)
     meanE, varE, params = _run_2d(_lib.MODEL_GRU1D_F64, params, units, Nx, Ny, Bx, numsteps, numsamples, lr,
-                                  lambda lr0, it: 1.0 / ((1.0 / lr0) + it / 10), seed, save_dir, tag, device, verbose, comm)
+                                  lambda lr0, it: 1.0 / ((1.0 / lr0) + it / 10), seed, save_dir, tag, device, verbose, comm,
+                                  restore)
     run_2DTFIM_1DRNN.last_params = params
     return meanE, varE

@@ -5,6 +5,7 @@ import numpy as np
 
 from . import _lib
 from . import params as P
+from . import tf_checkpoint as T
 from .compat import EvalOp, Graph, Placeholder, SampleOp, is_gru_cell
 
 
@@ -32,11 +33,24 @@ class _NativeWF:
     def get_params(self):
         return OrderedDict((k, v.copy()) for k, v in self.params.items())
 
-    def save(self, path):
-        P.save_npz(path, self.params)
+    def save(self, path, extra=None):
+        """tf.train.Saver.save stand-in (1DTFIM/TrainingRNN_1DTFIM.py:219): `path` ending in .npz -> NumPy archive
+        keyed by the TF variable names; anything else is a TF checkpoint prefix (V2 tensor bundle: <path>.index +
+        <path>.data-00000-of-00001, tf_checkpoint.py).  `extra`: further variables of the Saver (optimizer slots, step)."""
+        if str(path).endswith(".npz"):
+            P.save_npz(path, self.params)
+        else:
+            T.write_checkpoint(str(path), dict(self.params, **(extra or {})))
 
     def restore(self, path):
-        self.set_params(P.load_npz(path))
+        """tf.train.Saver.restore stand-in (:172-183): loads this model's variables from a .npz or a TF checkpoint
+        prefix; optimizer slots / step counters in the file are returned (tf_checkpoint.split_saver_variables), not used."""
+        if str(path).endswith(".npz"):
+            self.set_params(P.load_npz(path))
+            return None
+        model, opt = T.split_saver_variables(T.read_checkpoint(str(path)))
+        self.set_params(match_checkpoint_names(self.params, model, self.scope))
+        return opt
 
     def num_params(self):
         return self._native.num_params()
@@ -61,6 +75,30 @@ class _NativeWF:
         if isinstance(samples, Placeholder):
             return EvalOp(self, samples, kind)
         return self._evaluate(np.asarray(samples), kind)
+
+
+def match_checkpoint_names(params, tensors, scope):
+    """{our name: checkpoint array} for every parameter: exact name, or the same variable under another scope prefix
+    (a checkpoint written with scope='RNNwavefunction' restores into scope='myscope').  Shapes and dtypes must agree."""
+    out = OrderedDict()
+    by_tail = {}
+    for name, a in tensors.items():
+        by_tail.setdefault(name.split("/", 1)[-1], []).append((name, a))
+    for k, v in params.items():
+        if k in tensors:
+            a = tensors[k]
+        else:
+            cands = by_tail.get(k[len(scope) + 1:] if k.startswith(scope + "/") else k, [])
+            if len(cands) != 1:
+                raise KeyError("checkpoint has %s variable named like %r (have: %s)"
+                               % ("no" if not cands else "more than one", k, sorted(tensors)[:6]))
+            a = cands[0][1]
+        if tuple(a.shape) != tuple(v.shape):
+            raise ValueError("%s: checkpoint shape %s, model shape %s" % (k, a.shape, v.shape))
+        if a.dtype != v.dtype:
+            raise ValueError("%s: checkpoint dtype %s, model dtype %s" % (k, a.dtype, v.dtype))
+        out[k] = a
+    return out
 
 
 class GRUWavefunction1D(_NativeWF):
