@@ -17,6 +17,10 @@ SOURCES = ["rnnwf_api.hip", "prnn.hip", "crnn.hip", "mdrnn.hip", "grad.hip", "co
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
          "-ffp-contract=fast",
+         # no SLP packing of adjacent f32 adds / fmas into v_pk_*_f32: packed-f32 (and v_dot2) instructions execute on
+         # the matrix pipe's side and stall behind bf16 MFMAs - their own wave's AND the SIMD partner's (measured:
+         # tools/microbench/issue_model, a VALU segment with packed ops beside an MFMA partner 5 170 vs 3 337 cycles)
+         "-fno-slp-vectorize",
          # keep MFMA accumulators in VGPRs: no v_accvgpr_read/write around the gate arithmetic and 4 waves/SIMD
          # at num_units=50 (the option exists for every target of this clang, so the host pass accepts it too)
          "-mllvm", "-amdgpu-mfma-vgpr-form"]
@@ -31,7 +35,7 @@ def _newest_header():
 def _compile(src, extra, objdir=None):
     obj = os.path.join(objdir or OBJDIR, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
-    if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), _newest_header()) and (not extra or extra == ["-DRNNWF_DIAGNOSTICS"]):
+    if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), _newest_header()) and (not extra or objdir):
         return obj, ""
     cmd = [HIPCC] + FLAGS + extra + ["-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -48,6 +52,8 @@ def build(verbose=False, extra_flags=(), jobs=None, variant=None):
     if variant == "diag":
         extra.append("-DRNNWF_DIAGNOSTICS")
         objdir, lib = os.path.join(LIBDIR, "obj_diag"), os.path.join(LIBDIR, "librnnwf_hip_diag.so")
+    elif variant:                      # ad-hoc A/B builds of tools/: extra_flags into lib/librnnwf_hip_<variant>.so
+        objdir, lib = os.path.join(LIBDIR, "obj_" + variant), os.path.join(LIBDIR, "librnnwf_hip_%s.so" % variant)
     os.makedirs(objdir, exist_ok=True)
     with ThreadPoolExecutor(max_workers=jobs or min(len(SOURCES), os.cpu_count() or 4)) as ex:
         results = list(ex.map(lambda s: _compile(s, extra, objdir), SOURCES))

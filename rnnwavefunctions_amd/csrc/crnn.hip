@@ -89,6 +89,23 @@ struct CSLaunch {
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }
+    // ping-pong form (8 waves per workgroup, alternating MFMA / VALU segments): K-packed layout MODE 2 only
+    static int swap_pp(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles, int kt16) {
+        if constexpr (MODE == 2) {
+            const void* fn = (const void*)crnn_swap_pp_kernel<NF32, RJ>;
+            if (L::HP > 4 * kt16) return h->fail(RNNWF_ERR_INVALID, "bf16x3 layout wider than the checkpoint rows (%d > %d)", L::HP, 4 * kt16);
+            int bpc = 0;
+            if (int rc = rnnwf::blocks_per_cu(h, fn, 512, L::BYTES, &bpc)) return rc;
+            const int64_t need = (max_tiles + 7) / 8;
+            const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
+            TimedLaunch tl(h, 1);
+            crnn_swap_pp_kernel<NF32, RJ><<<grid, 512, L::BYTES, h->stream>>>(a, h->wsplit.p, kt16);
+            RNNWF_HIP(h, hipGetLastError());
+            return 0;
+        } else {
+            return swap(h, a, max_tiles, kt16);
+        }
+    }
     static std::vector<char> pack(const rnnwf_handle* h) { return pack_split_image<NF32, RJ, 3, MODE>(h); }
     static double mfma_flops_per_step() { return (double)L::NT * L::KS * 32768.0; }
 };
@@ -106,7 +123,8 @@ struct CSLaunch {
 
 int launch_swap_split(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles) {
     const int kt16 = 4 * h->NFULL + 1;
-    CSPLIT_DISPATCH(h, return K::swap(h, a, max_tiles, kt16));
+    if (h->knobs.engine == 3) { CSPLIT_DISPATCH(h, return K::swap(h, a, max_tiles, kt16)); }      // RNNWF_ENGINE=bf16x3-serial: A/B only
+    else { CSPLIT_DISPATCH(h, return K::swap_pp(h, a, max_tiles, kt16)); }
     return h->fail(RNNWF_ERR_INVALID, "no bf16x3 cRNN kernel for NFULL=%d", h->NFULL);
 }
 double csplit_mfma_flops_per_step(rnnwf_handle* h) {

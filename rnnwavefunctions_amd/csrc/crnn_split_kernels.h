@@ -2,6 +2,7 @@
 #pragma once
 #include "crnn_kernels.h"
 #include "split_core.h"
+#include "split_pp.h"
 
 namespace rnnwf {
 
@@ -73,6 +74,138 @@ __global__ void __launch_bounds__(WAVES * 64, (3 * NF32 + (3 * RJ + 15) / 16) <=
             a.contrib[s * (2 * N) + it.slot] = make_double2(mag * cos(dim), mag * sin(dim));
         }
     }
+}
+
+// Ping-pong form (see prnn_flip_pp_kernel in split_kernels.h for the scheme): 8 waves per workgroup, two per SIMD, MFMA
+// segment of one wave beside the VALU segment of the other, K-packed layout MODE 2 (37..50 units).  Tiles come from
+// the device-side table (tile_start[lo] = first 32-item tile of first-changed site lo, longest chains first); the walk
+// is the same snake, so the waves of a workgroup carry the same number of steps within a few.
+template <int NF32, int RJ>
+__global__ void __launch_bounds__(512) crnn_swap_pp_kernel(CrnnArgs a, const void* wsplit, int kt16) {
+    using PP = SplitPP<NF32, RJ, 3>;
+    using C = typename PP::C;
+    using L = typename C::L;
+    constexpr int NU = C::NU, NT = C::NT, NB = PP::NB, WAVES = 8;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    __shared__ int max_steps;
+    if (threadIdx.x == 0) max_steps = 0;
+    C::stage(lds, wsplit);
+    const int lane = threadIdx.x & 63, c = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool late = wave >= 4;
+    const int64_t gw = (int64_t)blockIdx.x * WAVES + wave;
+    const int64_t nw = (int64_t)gridDim.x * WAVES;
+    const int N = a.N;
+    const int64_t ntiles = a.tile_start[N];
+    const float* hck = reinterpret_cast<const float*>(a.hck);
+    auto tile_of = [&](int64_t r) -> int64_t { return r * nw + ((r & 1) ? nw - 1 - gw : gw); };
+    auto lo_of = [&](int64_t t) -> int {
+        int l = 0, r = N;
+        while (r - l > 1) {
+            const int mid = (l + r) >> 1;
+            if (a.tile_start[mid] <= t) l = mid; else r = mid;
+        }
+        return l;
+    };
+    {
+        int mine = 0;
+        for (int64_t r = 0; r * nw < ntiles; ++r) {
+            const int64_t t = tile_of(r);
+            if (t < ntiles) mine += N - 1 - lo_of(t);
+        }
+        if (lane == 0) atomicMax(&max_steps, mine);
+        __syncthreads();
+    }
+    const int iters = max_steps;
+
+    int64_t round = 0, tile = tile_of(0);
+    bool active = tile < ntiles;
+    int lo = 0, n = 0, sig_in = 0, num_up = 0, s = 0;
+    bool valid = false;
+    SwapItem it{};
+    uint32_t word = 0;
+    double re = 0.0, im = 0.0;
+    float h[NU];
+    u32x4 B[NB];
+    f32x16 acc[NT];
+    auto next_tile = [&]() {
+        for (;;) {
+            ++round;
+            if (round * nw >= ntiles) { active = false; return; }
+            tile = tile_of(round);
+            if (tile < ntiles) { active = true; return; }
+        }
+    };
+    auto begin_tile = [&]() {
+        lo = lo_of(tile);
+        const int k = (int)(tile - a.tile_start[lo]) * 32 + c;
+        valid = k < a.cnt[lo];
+        it = a.items[(int64_t)lo * a.cap + (valid ? k : 0)];
+        s = it.s;
+        const float* src = hck + (((int64_t)lo * a.nsb + (s >> 4)) * kt16) * 64 + (s & 15);
+        auto off = [](int u) { return (u >> 2) * 64 + ((u & 3) << 4); };
+#pragma unroll
+        for (int e = 0; e < NU; ++e) {
+            const int u0 = L::unit_of(e, 0), u1 = L::unit_of(e, 1);
+            const int d = off(u1) - off(u0);
+            h[e] = (src + (hh ? d : 0))[off(u0)];              // HP <= 4 kt16: host-checked
+        }
+        num_up = 0;
+        for (int w = 0; w < (lo >> 5); ++w) num_up += __popc(a.bits[(int64_t)w * a.ns + s]);
+        word = a.bits[(int64_t)(lo >> 5) * a.ns + s];
+        num_up += __popc(word & ((1u << (lo & 31)) - 1u));
+        sig_in = 1 - (int)((word >> (lo & 31)) & 1);
+        num_up += sig_in;
+        n = lo + 1;
+        if ((n & 31) == 0 && n < N) word = a.bits[(int64_t)(n >> 5) * a.ns + s];
+        re = 0.0; im = 0.0;
+    };
+    if (active) {
+        begin_tile();
+        PP::preload(lds, sig_in, lane, acc);
+        PP::split(h, B);
+    }
+    if (late) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+    for (int itn = 0; itn < iters; ++itn) {
+        if (active) PP::mfma_seg(lds, B, acc, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (active) {
+            PP::gates(lds, sig_in, acc, h, lane);
+            float z[3];
+            PP::head(lds, h, lane, z);
+            float la0, la1, w0, ph0, ph1;
+            crnn_site(z, n, N, num_up, la0, la1, w0, ph0, ph1);
+            const int sig = (int)((word >> (n & 31)) & 1) ^ (n == it.hi ? 1 : 0);
+            re += (double)(sig ? la1 : la0);
+            im += (double)(sig ? ph1 : ph0);
+            num_up += sig;
+            sig_in = sig;
+            ++n;
+            if (n == N) {
+                if (valid && hh == 0) {
+                    const double2 b = a.cb[(int64_t)lo * a.ns + s];
+                    const double2 t = a.tot[s];
+                    const double dre = b.x + re - t.x, dim = b.y + im - t.y;
+                    const double mag = exp(dre) * (double)it.coef;
+                    a.contrib[(int64_t)s * (2 * N) + it.slot] = make_double2(mag * cos(dim), mag * sin(dim));
+                }
+                next_tile();
+                if (active) begin_tile();
+            } else if ((n & 31) == 0) {
+                word = a.bits[(int64_t)(n >> 5) * a.ns + s];
+            }
+            if (active) {
+                PP::preload(lds, sig_in, lane, acc);
+                PP::split(h, B);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!late) __builtin_amdgcn_s_barrier();
 }
 
 }  // namespace rnnwf

@@ -77,11 +77,16 @@ struct SplitLayout {
     }
 };
 
-// x -> packed (bf16(x0), bf16(x1)) with round-to-nearest-even, as one v_cvt_pk_bf16_f32
+// x -> packed (bf16(x0), bf16(x1)) with round-to-nearest-even: ONE v_cvt_pk_bf16_f32, emitted by the compiler from the
+// vector conversion.  It must NOT be inline asm: hipcc's hazard recognizer does not count an asm block as a VALU
+// instruction, so an MFMA reading the packed register right behind it got no wait states and multiplied STALE
+// operands on some lanes (found in round 2: with a different instruction order the 20-unit cRNN swap kernel returned
+// 53 distinct values for 64 copies of one configuration; tools/dbg_crnn_multipass.py).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 
 template <int NF32, int RJ, int NOUT = 1, int MODE = 0>

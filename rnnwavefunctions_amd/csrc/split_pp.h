@@ -175,19 +175,23 @@ struct SplitPP {
     // head rows on the new state: four independent partial sums per row, halves joined with v_permlane32_swap
     static __device__ __forceinline__ void head(const char* lds, const float (&h)[NU], int lane, float (&z)[NOUT]) {
         const float* wd = reinterpret_cast<const float*>(lds + L::OFF_WD) + (lane >> 5) * L::NUP * NOUT;
-        float w[NU * NOUT];
-#pragma unroll
-        for (int i = 0; i < NU * NOUT; ++i) w[i] = wd[i];
-        RNNWF_STAGE();
         float part[NOUT][4];
 #pragma unroll
         for (int o = 0; o < NOUT; ++o)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) part[o][c] = h[c] * w[c * NOUT + o];
+            for (int c = 0; c < 4; ++c) part[o][c] = 0.0f;
+        constexpr int CH = NOUT == 1 ? NU : 8;               // units per chunk of head weights held in registers
 #pragma unroll
-        for (int e = 4; e < NU; ++e)
+        for (int e0 = 0; e0 < NU; e0 += CH) {
+            constexpr int dummy = 0; (void)dummy;
+            float w[CH * NOUT];
 #pragma unroll
-            for (int o = 0; o < NOUT; ++o) part[o][e & 3] = fmaf(h[e], w[e * NOUT + o], part[o][e & 3]);
+            for (int i = 0; i < CH * NOUT; ++i) w[i] = e0 * NOUT + i < NU * NOUT ? wd[e0 * NOUT + i] : 0.0f;
+#pragma unroll
+            for (int e = e0; e < e0 + CH && e < NU; ++e)
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) part[o][e & 3] = fmaf(h[e], w[(e - e0) * NOUT + o], part[o][e & 3]);
+        }
         const float* bd = reinterpret_cast<const float*>(lds + L::OFF_BD);
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) {
