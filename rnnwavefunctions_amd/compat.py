@@ -15,12 +15,27 @@ import numpy as np
 int32, int64, float32, float64, complex64 = np.int32, np.int64, np.float32, np.float64, np.complex64
 
 
+_graph_stack = []
+
+
 class Graph:
-    """tf.Graph stand-in: only ``as_default()`` is used by the reference (RNNwavefunction.py:28,49)."""
+    """tf.Graph stand-in: ``as_default()`` (RNNwavefunction.py:28,49) and the list of wave functions built in it, which
+    is what ``tf.trainable_variables()`` / ``tf.global_variables_initializer()`` refer to inside the context."""
+
+    def __init__(self):
+        self.wavefunctions = []
 
     @contextlib.contextmanager
     def as_default(self):
-        yield self
+        _graph_stack.append(self)
+        try:
+            yield self
+        finally:
+            _graph_stack.pop()
+
+
+def get_default_graph():
+    return _graph_stack[-1] if _graph_stack else None
 
 
 class Placeholder:
@@ -103,6 +118,15 @@ class Session:
             return type(fetches)(self.run(f, feed) for f in fetches)
         if isinstance(fetches, Op):
             return fetches._run(feed)
+        if isinstance(fetches, VariableRef):
+            return fetches.value().copy()
+        if isinstance(fetches, str):                  # a variable name, as `sess.run(variables_names)` passes (:130)
+            for wf in (self.graph.wavefunctions if self.graph is not None else []):
+                if fetches.rsplit(":", 1)[0] in wf.params:
+                    return wf.params[fetches.rsplit(":", 1)[0]].copy()
+            raise TypeError("Session.run: %r is neither an op of this package nor the name of a variable in this session's graph" % fetches)
+        if isinstance(fetches, Variable):
+            return fetches.value
         if fetches is None:
             return None
         raise TypeError("Session.run: cannot evaluate %r (only ops created by rnnwavefunctions_amd wave "
@@ -126,8 +150,152 @@ class CudnnCompatibleGRUCell:
         self.num_units = num_units
 
 
+class _Namespace:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+# tf.contrib.cudnn_rnn.CudnnCompatibleGRUCell, the cell every run script of the reference passes
+# (1DTFIM/TrainingRNN_1DTFIM.py:103, J1J2/TrainingRNN_J1J2.py:153, 2DTFIM_1DRNN/Training1DRNN_2DTFIM.py:104)
+contrib = _Namespace(cudnn_rnn=_Namespace(CudnnCompatibleGRUCell=CudnnCompatibleGRUCell),
+                     rnn=_Namespace(GRUCell=CudnnCompatibleGRUCell))
+AUTO_REUSE = "AUTO_REUSE"
+
+
+@contextlib.contextmanager
+def variable_scope(name_or_scope=None, reuse=None, **kwargs):
+    """tf.variable_scope(wf.scope, reuse=tf.AUTO_REUSE) (TrainingRNN_1DTFIM.py:147,185): parameters live in the wave
+    function object, there is nothing to scope."""
+    yield name_or_scope
+
+
+def reset_default_graph():
+    del _graph_stack[:]
+
+
+def set_random_seed(seed):
+    """tf.set_random_seed (:85).  The native sampler is seeded per wave function (its `seed` argument); kept so that
+    the call site runs."""
+
+
+class Variable:
+    """tf.Variable(0, trainable=False): the global step of the reference's learning-rate schedule (:110)."""
+
+    def __init__(self, initial_value=0, trainable=True, name=None, dtype=None):
+        self.value = np.asarray(initial_value, dtype=dtype)
+        self.trainable = trainable
+        self.name = (name or "Variable") + ":0"
+
+
+class VariableRef:
+    """One TF-named parameter of a wave function, as tf.trainable_variables() lists it (:125-136)."""
+
+    def __init__(self, wf, key):
+        self.wf, self.key = wf, key
+        self.name = key + ":0"
+
+    def value(self):
+        return self.wf.params[self.key]
+
+
+def trainable_variables():
+    g = get_default_graph()
+    if g is None:
+        raise RuntimeError("tf.trainable_variables(): call it inside `with wf.graph.as_default():`")
+    return [VariableRef(wf, k) for wf in g.wavefunctions for k in wf.params]
+
+
+def reshape(tensor, shape):
+    return np.reshape(np.asarray(tensor), shape)
+
+
+class _NoOp(Op):
+    def __init__(self):
+        Op.__init__(self, None)
+
+    def _run(self, feed):
+        return None
+
+
+def global_variables_initializer():
+    """Parameters are initialised when the wave function is built (params.init_*): running this op does nothing."""
+    return _NoOp()
+
+
+def variables_initializer(var_list=None):
+    return _NoOp()
+
+
+class _Logging:
+    ERROR, WARN, INFO, DEBUG = 40, 30, 20, 10
+
+    @staticmethod
+    def set_verbosity(level):
+        pass
+
+
+logging = _Logging()
+
+
+class _LearningRate:
+    """tf.train.exponential_decay(lr, global_step, decay_steps, decay_rate, staircase) (:112)."""
+
+    def __init__(self, learning_rate, global_step, decay_steps, decay_rate, staircase=False):
+        self.lr, self.step, self.decay_steps, self.decay_rate, self.staircase = learning_rate, global_step, decay_steps, decay_rate, staircase
+
+    def value(self, feed):
+        lr = feed[self.lr] if isinstance(self.lr, Placeholder) else self.lr
+        t = float(np.asarray(self.step.value if isinstance(self.step, Variable) else self.step))
+        e = t / self.decay_steps
+        return float(lr) * self.decay_rate ** (np.floor(e) if self.staircase else e)
+
+
+class _Train:
+    exponential_decay = staticmethod(lambda learning_rate, global_step, decay_steps, decay_rate, staircase=False, name=None:
+                                     _LearningRate(learning_rate, global_step, decay_steps, decay_rate, staircase))
+
+    class AdamOptimizer:
+        """tf.train.AdamOptimizer(learning_rate, beta1, beta2, epsilon) (:114): holds the hyper-parameters; the update
+        itself is training.Adam, driven by training.run_* (the symbolic compute_gradients / apply_gradients of the
+        reference's graph are not reproduced: the gradient of the VMC cost is rnnwf_vmc_gradient)."""
+
+        def __init__(self, learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8, name="Adam"):
+            self.learning_rate, self.beta1, self.beta2, self.epsilon = learning_rate, beta1, beta2, epsilon
+
+        def variables(self):
+            return []
+
+    class Saver:
+        """tf.train.Saver() (:166): save / restore the wave functions of the graph as TF checkpoints (V2 tensor bundle,
+        tf_checkpoint.py)."""
+
+        def __init__(self, var_list=None):
+            g = get_default_graph()
+            self.wavefunctions = list(g.wavefunctions) if g is not None else []
+
+        def save(self, sess, save_path, global_step=None):
+            from . import tf_checkpoint as T
+            tensors = {}
+            for wf in self.wavefunctions or (sess.graph.wavefunctions if getattr(sess, "graph", None) else []):
+                tensors.update(wf.params)
+            T.write_checkpoint(str(save_path), tensors)
+            return str(save_path)
+
+        def restore(self, sess, save_path):
+            for wf in self.wavefunctions or (sess.graph.wavefunctions if getattr(sess, "graph", None) else []):
+                wf.restore(str(save_path))
+
+
+train = _Train()
+compat = _Namespace(v1=_Namespace(logging=logging, Session=None, placeholder=None))
+
+
 def is_gru_cell(cell):
     if cell is None or cell is CudnnCompatibleGRUCell:
         return True
     name = cell if isinstance(cell, str) else getattr(cell, "__name__", type(cell).__name__)
     return "GRU" in str(name).upper()
+
+
+compat.v1.Session, compat.v1.placeholder = Session, placeholder
+complex128 = np.complex128

@@ -5,6 +5,7 @@
 #include <cstdlib>
 
 #include "crnn_kernels.h"
+#include "crnn_ml_kernels.h"
 #include "models.h"
 #include "pack.h"
 #include "pack_split.h"
@@ -63,8 +64,60 @@ struct CLaunch {
     static size_t hck_bytes_per_block() { return (size_t)L::KT * 64 * sizeof(float); }
 };
 
+// stacked layers (forward passes on the f32-input MFMA; crnn_ml_kernels.h)
+template <int NFULL, int NL, int WAVES>
+struct CMLaunch {
+    using M = CrnnMlCore<NFULL, NL>;
+    static int base(rnnwf_handle* h, const CrnnArgs& a) {
+        const void* fn = (const void*)crnn_ml_base_kernel<NFULL, NL, WAVES>;
+        int bpc = 0;
+        if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, M::BYTES, &bpc)) return rc;
+        const int64_t need = (a.nsb + WAVES - 1) / WAVES;
+        const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
+        TimedLaunch tl(h, 0);
+        crnn_ml_base_kernel<NFULL, NL, WAVES><<<grid, WAVES * 64, M::BYTES, h->stream>>>(a);
+        RNNWF_HIP(h, hipGetLastError());
+        return 0;
+    }
+    static int swap(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles) {
+        const void* fn = (const void*)crnn_ml_swap_kernel<NFULL, NL, WAVES>;
+        int bpc = 0;
+        if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, M::BYTES, &bpc)) return rc;
+        const int64_t need = (max_tiles + WAVES - 1) / WAVES;
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
+        TimedLaunch tl(h, 1);
+        crnn_ml_swap_kernel<NFULL, NL, WAVES><<<grid, WAVES * 64, M::BYTES, h->stream>>>(a);
+        RNNWF_HIP(h, hipGetLastError());
+        return 0;
+    }
+    static std::vector<char> pack(const rnnwf_handle* h) {
+        std::vector<char> img = pack_gru_image<float, NFULL, 3>(h);
+        for (int l = 1; l < NL; ++l) {
+            const std::vector<char> up = pack_upper_image<NFULL>(h, l);
+            img.insert(img.end(), up.begin(), up.end());
+        }
+        return img;
+    }
+    static size_t hck_bytes_per_block() { return (size_t)NL * M::KT * 64 * sizeof(float); }
+};
+
 #define CRNN_DISPATCH(h, EXPR)                                  \
     do {                                                        \
+        if ((h)->NL == 2) {                                     \
+            switch ((h)->NFULL) {                               \
+                case 1: { using K = CMLaunch<1, 2, 4>; EXPR; }  \
+                case 2: { using K = CMLaunch<2, 2, 4>; EXPR; }  \
+                case 3: { using K = CMLaunch<3, 2, 8>; EXPR; }  \
+            }                                                   \
+            break;                                              \
+        }                                                       \
+        if ((h)->NL == 3) {                                     \
+            switch ((h)->NFULL) {                               \
+                case 1: { using K = CMLaunch<1, 3, 4>; EXPR; }  \
+                case 2: { using K = CMLaunch<2, 3, 8>; EXPR; }  \
+            }                                                   \
+            break;                                              \
+        }                                                       \
         switch ((h)->NFULL) {                                   \
             case 1: { using K = CLaunch<1, 4>; EXPR; }          \
             case 2: { using K = CLaunch<2, 4>; EXPR; }          \
@@ -243,7 +296,7 @@ int64_t collect_totals(rnnwf_handle* h, int64_t ns) {
 
 int rnnwf::crnn_pack_image(rnnwf_handle* h, std::vector<char>& img) {
     // swap-pass engine: bf16x3 on the matrix core up to 68 units (RNNWF_ENGINE=f32: f32-input MFMA everywhere)
-    h->engine_split = h->NFULL <= 4 && h->knobs.engine != 1;
+    h->engine_split = h->NL == 1 && h->NFULL <= 4 && h->knobs.engine != 1;     // stacked layers: f32-input MFMA
     if (h->engine_split) {
         std::vector<char> simg;
         CSPLIT_DISPATCH(h, { simg = K::pack(h); break; });

@@ -368,6 +368,9 @@ extern "C" int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double me
     if (h->model != RNNWF_MODEL_GRU1D && h->model != RNNWF_MODEL_CRNN_U1 && h->model != RNNWF_MODEL_GRU1D_F64)
         return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: not implemented for the parity-symmetrised GRU RNN");
     if (h->NL != 1) {
+        if (h->model == RNNWF_MODEL_CRNN_U1)
+            return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: the stacked-layer complex RNN has forward passes only (sample, "
+                                              "log_amplitude, J1-J2 local energies); its gradient is implemented for one layer");
         if (h->model != RNNWF_MODEL_GRU1D) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: not implemented for the parity-symmetrised GRU RNN");
         if (h->last_ns <= 0 || !h->last_has_ckpt)
             return h->fail(RNNWF_ERR_STATE, "rnnwf_vmc_gradient: call rnnwf_vmc_step first (its samples, states and E_loc are reused)");

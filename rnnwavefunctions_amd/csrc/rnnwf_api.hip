@@ -128,9 +128,11 @@ extern "C" int rnnwf_create(const rnnwf_config* cfg, rnnwf_handle** out) {
         return bad("rnnwf_create: len(units) must be 1..3");
     if (cfg->units[0] < 1) return bad("rnnwf_create: units[0] must be positive");
     if (cfg->num_layers > 1) {
-        // MultiRNNCell stacks (1DTFIM/RNNwavefunction.py:32): f32 positive RNN only, equal widths, image must fit LDS
-        if (cfg->model != RNNWF_MODEL_GRU1D && cfg->model != RNNWF_MODEL_GRU1D_PARITY)
-            return bad("rnnwf_create: stacked layers (len(units) > 1) are implemented for the 1D positive GRU RNN only");
+        // MultiRNNCell stacks (1DTFIM/RNNwavefunction.py:32, J1J2/ComplexRNNwavefunction.py:40): f32 models, equal widths,
+        // image must fit LDS
+        if (cfg->model != RNNWF_MODEL_GRU1D && cfg->model != RNNWF_MODEL_GRU1D_PARITY && cfg->model != RNNWF_MODEL_CRNN_U1)
+            return bad("rnnwf_create: stacked layers (len(units) > 1) are implemented for the 1D GRU wave functions in float32 "
+                       "(positive, parity-symmetric, complex) only");
         for (int l = 1; l < cfg->num_layers; ++l)
             if (cfg->units[l] != cfg->units[0]) return bad("rnnwf_create: stacked layers must have equal num_units");
         const int limit = cfg->num_layers == 2 ? 52 : 36;

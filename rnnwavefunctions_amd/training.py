@@ -209,7 +209,8 @@ def run_J1J2(numsteps=10 ** 5, systemsize=20, J1_=1.0, J2_=0.0, Marshall_sign=Fa
     (J1J2/TrainingRNN_J1J2.py:118): Marshall_sign=True therefore selects the PERIODIC chain
     without a Marshall sign - reproduced here on purpose so that runs compare with the reference's."""
     if num_layers != 1:
-        raise ValueError("only num_layers = 1 is implemented on gfx950 (the reference's run scripts use 1)")
+        raise ValueError("training the complex RNN: num_layers = 1 only (stacked layers have the forward passes - sample, "
+                         "log_amplitude, J1-J2 local energies - but no gradient yet; the reference's run scripts use 1)")
     N = systemsize
     scope = "RNNwavefunction"
     lr = np.float64(learningrate)

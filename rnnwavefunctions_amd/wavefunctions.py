@@ -23,6 +23,7 @@ class _NativeWF:
         self._step = 0                    # one Philox sub-stream per drawn batch (sess.run(samples_))
         self._sample_offset = 0           # first GLOBAL sample index of this device's shard
         self._native = _lib.NativeWavefunction(self._model, nx, ny, tuple(units), device=device)
+        self.graph.wavefunctions.append(self)
         self.set_params(params)
 
     # -- parameters (tf.train.Saver stand-in: flat {tf_variable_name: array}) ----------------------
@@ -55,6 +56,12 @@ class _NativeWF:
     def num_params(self):
         return self._native.num_params()
 
+    def _views(self, *prefixes):
+        """Parameter views by TF-name prefix below the scope: what the reference keeps as layer objects
+        (self.rnn = MultiRNNCell(...), self.dense = Dense(...), RNNwavefunction.py:32-33)."""
+        pre = tuple(self.scope + "/" + p for p in prefixes)
+        return ParameterView(self, [k for k in self.params if k.startswith(pre)])
+
     def set_shard(self, sample_offset):
         """Multi-GPU: this handle draws global samples [sample_offset, sample_offset + numsamples)."""
         self._sample_offset = int(sample_offset)
@@ -75,6 +82,37 @@ class _NativeWF:
         if isinstance(samples, Placeholder):
             return EvalOp(self, samples, kind)
         return self._evaluate(np.asarray(samples), kind)
+
+
+class ParameterView:
+    """Stand-in for a Keras/TF-1 layer object holding some of a wave function's variables: `.variables`,
+    `.trainable_variables`, `.weights` (TF names + current values), `.get_weights()` / `.set_weights()`."""
+
+    def __init__(self, wf, keys):
+        self._wf, self._keys = wf, list(keys)
+
+    @property
+    def variables(self):
+        from .compat import VariableRef
+        return [VariableRef(self._wf, k) for k in self._keys]
+
+    trainable_variables = weights = trainable_weights = variables
+
+    def get_weights(self):
+        return [self._wf.params[k].copy() for k in self._keys]
+
+    def set_weights(self, values):
+        if len(values) != len(self._keys):
+            raise ValueError("expected %d arrays" % len(self._keys))
+        p = self._wf.get_params()
+        for k, v in zip(self._keys, values):
+            if tuple(np.shape(v)) != p[k].shape:
+                raise ValueError("%s: shape %s, expected %s" % (k, np.shape(v), p[k].shape))
+            p[k] = np.asarray(v, dtype=p[k].dtype)
+        self._wf.set_params(p)
+
+    def count_params(self):
+        return int(sum(self._wf.params[k].size for k in self._keys))
 
 
 def match_checkpoint_names(params, tensors, scope):
@@ -115,6 +153,15 @@ class GRUWavefunction1D(_NativeWF):
         self.N = systemsize
         prm = P.init_gru_params(units, seed=seed, scope=scope, dtype=self._dtype, heads=self._heads)
         self._setup(systemsize, 1, units, scope, seed, device, prm)
+        self._layer_views()
+
+    def _layer_views(self):
+        self.rnn = self._views("multi_rnn_cell/")                         # RNNwavefunction.py:32
+        if len(self._heads) == 1:
+            self.dense = self._views("wf_dense/")                         # :33
+        else:
+            self.dense_ampl = self._views("wf_dense_ampl/")               # ComplexRNNwavefunction.py:42-43
+            self.dense_phase = self._views("wf_dense_phase/")
 
     def sample(self, numsamples, inputdim):
         """RNNwavefunction.sample (:35-74): op handle yielding (numsamples, N) int64 spins."""
@@ -175,6 +222,7 @@ class GRUWavefunction2DRaster(GRUWavefunction1D):
         self.N = systemsize_x * systemsize_y
         prm = P.init_gru_params(units, seed=seed, scope=scope, dtype=np.float64)
         self._setup(systemsize_x, systemsize_y, units, scope, seed, device, prm)
+        self._layer_views()
 
 
 class MDRNNWavefunction2D(_NativeWF):
@@ -190,6 +238,8 @@ class MDRNNWavefunction2D(_NativeWF):
         self.rnn = cell(num_units=units[0], num_in=2, name="rnn_0", dtype=np.float64) if cell is not None else None
         prm = P.init_mdrnn_params(units[0], seed=seed, scope=scope)
         self._setup(systemsize_x, systemsize_y, units[:1], scope, seed, device, prm)
+        self.cell = self._views("Wh_", "Uh_", "Wv_", "Uv_", "b_")        # the MDRNNcell's variables (MDRNNcell.py:21-35)
+        self.dense = self._views("wf_dense/")                             # 2DTFIM_2DRNN/RNNwavefunction.py:33
 
     def sample(self, numsamples, inputdim):
         GRUWavefunction1D._check_inputdim(inputdim)

@@ -195,3 +195,55 @@ def test_cooperative_base_pass_is_bit_identical(N, H, ns, monkeypatch):
     assert np.array_equal(s1, s2) and np.array_equal(a1, a2)
     assert n1 == n2 and np.array_equal(e1, e2)
     assert np.all(s1.sum(axis=1) == N // 2)
+
+
+# ---- stacked layers: the reference's DEFAULT constructor is units=[10, 10] (J1J2/ComplexRNNwavefunction.py:16,40) ----
+
+def stacked_like(H, L, seed):
+    return P.randomize_biases(P.scale_kernels(P.init_gru_params([H] * L, seed=seed, heads=HEADS), 1.6), seed + 1)
+
+
+@pytest.mark.parametrize("N,H,L,B", [(12, 10, 2, 40), (10, 20, 3, 33), (20, 50, 2, 24), (8, 36, 3, 17), (16, 52, 2, 16)])
+def test_stacked_layers_log_amplitude_sampling_and_eloc_match_oracle(N, H, L, B):
+    from rnnwavefunctions_amd import _lib
+    prm = stacked_like(H, L, seed=N + H)
+    wf = _lib.NativeWavefunction(_lib.MODEL_CRNN_U1, N, 1, (H,) * L)
+    wf.set_params(prm, scope="RNNwavefunction")
+    assert wf.num_params() == P.count_params(prm)
+    s = zero_mag_batch(B, N, 5)
+    got, ref = wf.log_amp(s), M.crnn_log_amplitude(prm, s)
+    tol = 3e-6 * N * L + 3e-6
+    assert np.abs(got.real - ref.real).max() <= tol and np.abs(got.imag - ref.imag).max() <= 4 * tol
+    smp = wf.sample(200, seed=3, step=1)
+    assert np.all(smp.sum(axis=1) == N // 2)
+    s_ref = M.crnn_sample(prm, N, philox.uniforms(3, 1, 0, 200, N))
+    assert (smp != s_ref).any(axis=1).sum() <= 2
+    J1, J2, Bz = np.ones(N), 0.5 * np.ones(N), np.zeros(N)
+    e, ncon = wf.j1j2_eloc(s, J1, J2, Bz)
+    e_ref = E.j1j2_local_energies(J1, J2, Bz, s, lambda x: M.crnn_log_amplitude(prm, x), False, False)
+    assert np.allclose(e, e_ref, rtol=1e-4, atol=1e-4)
+    out = wf.vmc_step(64, seed=9, step=0, couplings=np.concatenate([J1, J2, Bz, [0.0, 0.0]]), want_samples=True, want_eloc=True)
+    e2, _ = wf.j1j2_eloc(out["samples"], J1, J2, Bz)
+    assert np.allclose(out["eloc"], e2, rtol=1e-6, atol=1e-6)
+
+
+def test_default_constructor_of_the_complex_wave_function():
+    """RNNwavefunction(systemsize, cell) with every other argument at the reference's default: units=[10, 10]."""
+    from rnnwavefunctions_amd import compat as tf
+    from rnnwavefunctions_amd.J1J2.ComplexRNNwavefunction import RNNwavefunction
+    N = 12
+    wf = RNNwavefunction(N, cell=tf.contrib.cudnn_rnn.CudnnCompatibleGRUCell)
+    assert wf.units == [10, 10]
+    # two GRU layers (3h(d+h)+... as the TF variables count them) + two Dense(2) heads
+    h = 10
+    assert wf.num_params() == (2 + h) * 2 * h + 2 * h + 2 * h + h + h * h + h + (h + h) * 2 * h + 2 * h + h * h + h + h * h + h + 2 * (2 * h + 2)
+    sess = tf.Session(graph=wf.graph)
+    samples = sess.run(wf.sample(numsamples=50, inputdim=2))
+    assert samples.shape == (50, N) and np.all(samples.sum(axis=1) == N // 2)
+    ph = tf.placeholder(tf.int32, shape=(None, N))
+    la = sess.run(wf.log_amplitude(ph, inputdim=2), feed_dict={ph: samples})
+    assert np.allclose(la, M.crnn_log_amplitude(wf.get_params(), samples.astype(np.int32)), atol=1e-4)
+    assert len(wf.rnn.variables) == 12 and wf.dense_ampl.count_params() == 22 and wf.dense_phase.count_params() == 22
+    with pytest.raises(ValueError, match="forward passes only"):
+        wf._native.vmc_step(16, seed=1, step=0, couplings=np.concatenate([np.ones(N), np.zeros(2 * N), [0.0, 0.0]]))
+        wf._native.vmc_gradient(0.0, 16, {"wf_dense_ampl/kernel": (10, 2)})

@@ -109,11 +109,12 @@ def test_vmc_step_2d_and_facade():
     assert np.isclose(out["moments"][0] / numsamples, e.mean(), rtol=1e-12)
 
 
-def test_config4_properties():
-    """BASELINE config 4 (12x12, num_units=50, numsamples=10000) at reduced batch: energy per site of HIP
-    vs the oracle on the same sample matrix."""
+def test_config4_at_full_size():
+    """BASELINE config 4 exactly as stated (2DTFIM_2DRNN/run_2dTFIM.py:10: 12x12, num_units=50, numsamples=10000;
+    the 600 MB state buffer and the full persistent grid): energy per site of HIP vs the oracle on an 8-sample subset of
+    the same sample matrix, plus size-independent properties on the whole batch."""
     Nx = Ny = 12
-    H, ns = 50, 512
+    H, ns = 50, 10000
     prm = P.init_mdrnn_params(H, seed=111)
     wf = make_wf(Nx, Ny, H, prm)
     Jz = np.ones((Nx, Ny))
@@ -125,3 +126,21 @@ def test_config4_properties():
     per_site = np.abs(e[sub] - e_ref).max() / (Nx * Ny)
     print("cfg4: max |E_loc diff| / N over 8 samples = %.2e" % per_site)
     assert per_site < 1e-10
+    assert s.shape == (ns, Nx, Ny) and set(np.unique(s)) <= {0, 1}
+    # E_loc = diagonal - Bx * (sum of N positive ratios): strictly below the diagonal energy for every sample
+    sz = 2.0 * s - 1.0
+    diag = -((sz[:, :-1, :] * sz[:, 1:, :]).sum(axis=(1, 2)) + (sz[:, :, :-1] * sz[:, :, 1:]).sum(axis=(1, 2)))
+    assert np.all(e < diag)
+    m = out["moments"]
+    assert abs(m[0] / m[2] - e.mean()) < 1e-9 * abs(e.mean()) and m[2] == ns
+    # the flipped-configuration queue of the reference (N+1 rows per sample) through log_prob on a few samples:
+    # sum_i exp(lp(flip i) - lp) reproduces (diag - E_loc) / Bx
+    k = 3
+    lp = wf.log_prob(s[:k].astype(np.int32))
+    acc = np.zeros(k)
+    for i in range(Nx):
+        for j in range(Ny):
+            f = s[:k].astype(np.int32).copy()
+            f[:, i, j] ^= 1
+            acc += np.exp(0.5 * (wf.log_prob(f) - lp))
+    assert np.allclose((diag[:k] - e[:k]) / 3.0, acc, rtol=1e-9)

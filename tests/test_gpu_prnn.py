@@ -229,6 +229,49 @@ def test_rccl_all_reduce_single_rank():
         wf.comm_init(uid, 3, 2)
 
 
+def _rccl_rank(rank, world, port, out):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), GLOO_SOCKET_IFNAME="lo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from rnnwavefunctions_amd import _lib
+    from rnnwavefunctions_amd import distributed as D
+    wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D, 16, 1, (20,), device=rank)      # one rank per GPU
+    wf.set_params(trained_like(20, seed=1), scope=SCOPE)
+    r, w = D.init_rccl_from_env(wf)
+    info = wf.comm_info()
+    ns = 300
+    m = wf.vmc_step(ns, seed=7, step=0, couplings=np.append(np.ones(16), 1.0), sample_offset=rank * ns)["moments"]
+    g = wf.allreduce_moments(m)
+    if rank == 0:
+        np.save(out, np.concatenate([g, [info["nranks"], info["rank"], info["device"], w]]))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_all_reduce_over_two_gpus(tmp_path):
+    """Two ranks, one GPU each, through rnnwf_comm_unique_id -> launcher broadcast -> rnnwf_comm_init (ncclCommInitRank
+    with nranks = 2) -> rnnwf_allreduce_moments: the reduced moments equal those of the single-device batch of both
+    shards.  Skipped where fewer than two GPUs are visible (RCCL refuses two ranks on one device)."""
+    import socket
+    from rnnwavefunctions_amd import _lib
+    _lib.load_library()                 # the product library (and /opt/rocm's HIP runtime) before torch's bundled copies
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (this box has %d)" % torch.cuda.device_count())
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = str(tmp_path / "g.npy")
+    mp.spawn(_rccl_rank, args=(2, port, out), nprocs=2, join=True)
+    g = np.load(out)
+    assert list(g[4:]) == [2, 0, 0, 2]                      # ncclCommCount = 2, rank 0 on device 0
+    wf = make_wf(_lib.MODEL_GRU1D, 16, 20, trained_like(20, seed=1))
+    m = wf.vmc_step(600, seed=7, step=0, couplings=np.append(np.ones(16), 1.0))["moments"]
+    assert g[2] == 600 and np.allclose(g[:4], m, rtol=1e-12)
+
+
 @pytest.mark.parametrize("N,H,ns", [(1, 10, 5), (2, 10, 1), (32, 20, 17), (33, 20, 16), (64, 36, 31), (200, 100, 19)])
 def test_edge_sizes(N, H, ns):
     """Ragged batches (ns not a multiple of the 16-chain tile, down to one sample), chain lengths around the 32-bit
@@ -350,8 +393,8 @@ def test_stacked_layers_limits_and_facade():
         _lib.NativeWavefunction(_lib.MODEL_GRU1D, 10, 1, (20, 10))
     with pytest.raises(ValueError, match="LDS budget"):
         _lib.NativeWavefunction(_lib.MODEL_GRU1D, 10, 1, (64, 64))
-    with pytest.raises(ValueError, match="1D positive GRU"):
-        _lib.NativeWavefunction(_lib.MODEL_CRNN_U1, 10, 1, (10, 10))
+    with pytest.raises(ValueError, match="float32"):            # the float64 raster GRU and the MDRNN: one layer
+        _lib.NativeWavefunction(_lib.MODEL_GRU1D_F64, 4, 4, (10, 10))
     wf = RNNwavefunction(10, cell="CudnnCompatibleGRUCell", units=[10, 10], seed=111)
     # layer 0: 12*20 + 20 + 2*10 + 10 + 10*10 + 10 = 400; layer 1: 20*20 + 20 + 10*10 + 10 + 10*10 + 10 = 640; head 22
     assert wf.num_params() == 400 + 640 + 22

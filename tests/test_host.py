@@ -97,7 +97,60 @@ def test_session_standins():
     assert compat.is_gru_cell(compat.CudnnCompatibleGRUCell) and compat.is_gru_cell(None)
     assert not compat.is_gru_cell("LSTMCell")
     with compat.Graph().as_default() as g:
-        assert isinstance(g, compat.Graph)
+        assert isinstance(g, compat.Graph) and compat.get_default_graph() is g
+    assert compat.get_default_graph() is None
+    # the handful of further TF-1 names the reference's training scripts touch (TrainingRNN_1DTFIM.py:2,82-123)
+    assert compat.contrib.cudnn_rnn.CudnnCompatibleGRUCell is compat.CudnnCompatibleGRUCell
+    compat.compat.v1.logging.set_verbosity(compat.compat.v1.logging.ERROR)
+    compat.reset_default_graph()
+    compat.set_random_seed(3)
+    step = compat.Variable(0, trainable=False)
+    lr_ph = compat.placeholder(dtype=compat.float64, shape=[])
+    lr = compat.train.exponential_decay(lr_ph, global_step=step, decay_steps=100, decay_rate=0.5, staircase=True)
+    assert lr.value({lr_ph: 0.01}) == 0.01
+    step.value = np.asarray(250)
+    assert lr.value({lr_ph: 0.01}) == 0.0025
+    opt = compat.train.AdamOptimizer(learning_rate=lr)
+    assert (opt.beta1, opt.beta2, opt.epsilon) == (0.9, 0.999, 1e-8)
+    assert sess.run(compat.global_variables_initializer()) is None and sess.run(step) == 250
+    with compat.variable_scope("RNNwavefunction", reuse=compat.AUTO_REUSE):
+        pass
+    with pytest.raises(RuntimeError):
+        compat.trainable_variables()
+
+
+def test_drivers_pick_the_launchers_gpu(monkeypatch):
+    """comm="env" (one process per GPU under torch.distributed.run): the handle opens LOCAL_RANK's device unless the
+    caller names one (round-1 finding: every rank opened GPU 0)."""
+    from rnnwavefunctions_amd import training as T
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    assert T._resolve_device(None, "env") == 5
+    assert T._resolve_device(2, "env") == 2
+    assert T._resolve_device(None, None) == 0
+    monkeypatch.delenv("LOCAL_RANK")
+    assert T._resolve_device(None, "env") == 0
+    import inspect
+    for fn in (T.run_1DTFIM, T.run_J1J2, T.run_2DTFIM_2DRNN, T.run_2DTFIM_1DRNN):
+        assert inspect.signature(fn).parameters["device"].default is None
+
+
+def test_adam_state_round_trips_through_a_checkpoint(tmp_path):
+    from rnnwavefunctions_amd import tf_checkpoint as TC
+    from rnnwavefunctions_amd.training import Adam
+    prm = P.init_gru_params([5], seed=1)
+    opt = Adam()
+    rng = np.random.RandomState(0)
+    for _ in range(7):
+        prm = opt.step(prm, {k: rng.standard_normal(v.shape) for k, v in prm.items()}, 1e-2)
+    TC.write_checkpoint(str(tmp_path / "m.ckpt"), dict(prm, **opt.state_tensors(prm, "RNNwavefunction")))
+    model, state = TC.split_saver_variables(TC.read_checkpoint(str(tmp_path / "m.ckpt")))
+    assert set(model) == set(prm) and state["global_step"] == 7
+    assert abs(state["beta1_power"] - 0.9 ** 8) < 1e-7        # TF: beta1_power = beta1^(t+1) after t steps
+    back = Adam()
+    back.load_state(state, list(prm))
+    assert back.t == 7
+    for k in prm:
+        assert np.allclose(back.m[k], opt.m[k], rtol=1e-6, atol=1e-12) and np.allclose(back.v[k], opt.v[k], rtol=1e-6, atol=1e-12)
 
 
 def test_params_roundtrip(tmp_path):
