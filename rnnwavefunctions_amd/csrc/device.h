@@ -62,6 +62,48 @@ __device__ __forceinline__ double exp_fast(double x) {
     p = __builtin_fma(p, r, 1.0);
     return ldexp(p, (int)kf);
 }
+// ---- table-driven f64 exp / log for the per-site elementwise work of the float64 models -------------------------------
+// On gfx950 the f64 MFMA and the f64 VALU do not overlap at all - neither inside a wave nor across the waves of a SIMD
+// (tools/microbench/issue_model: k_roles_g, g_q*) - so every VALU instruction of the MDRNN step is exposed time and the
+// 13 exp() of a 16-chain wave-step are worth shortening.  A 3 x 64-entry table in LDS (F64Tables, 1.5 KB, written
+// by the host packers) cuts exp from 21 to 16 instructions and log(1 + e), e in (0, 1], from ocml's ~60 to 14.
+// 1/d to ~1 ulp: v_rcp_f64 plus two Newton steps (5 instructions instead of an IEEE division's ~15)
+__device__ __forceinline__ double rcp_fast_f64(double d) {
+    double y = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-d, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+// e^x for x <= 0 (clamped at -700): x = (64 m + j) ln2/64 + r, |r| <= ln2/128; e^r by a degree-5 polynomial
+// (truncation r^6/720 < 4e-17); relative error ~1 ulp of the tabulated 2^(j/64).
+__device__ __forceinline__ double exp_tab(double x, const double* tab) {
+    x = __builtin_fmax(x, -700.0);
+    const double kf = __builtin_rint(x * 0x1.71547652b82fep+6);                  // 64 / ln 2
+    double r = __builtin_fma(kf, -0x1.62e42fee00000p-7, x);                     // ln2/64, high part (21 trailing zero bits: k * high is exact)
+    r = __builtin_fma(kf, -0x1.a39ef35793c76p-39, r);                            // ln2/64 - high
+    const int k = (int)kf;
+    const double t = tab[F64Tables::EXP2 + (k & 63)];
+    double q = __builtin_fma(r, 1.0 / 120.0, 1.0 / 24.0);
+    q = __builtin_fma(q, r, 1.0 / 6.0);
+    q = __builtin_fma(q, r, 0.5);
+    q = __builtin_fma(q, r, 1.0);
+    return ldexp(__builtin_fma(t, r * q, t), k >> 6);
+}
+// log(1 + e) for e in [0, 1]: y = 1 + e = c_j (1 + u), |u| <= 2^-7; log1p(u) to degree 7 (truncation u^8/8 < 3e-18)
+__device__ __forceinline__ double log1p_tab(double e, const double* tab) {
+    const double y = 1.0 + e;
+    int j = (int)__builtin_fma(y, 64.0, -64.0);
+    j = j > 63 ? 63 : j;
+    const double u = __builtin_fma(y, tab[F64Tables::RCPC + j], -1.0);
+    double p = __builtin_fma(u, 1.0 / 7.0, -1.0 / 6.0);
+    p = __builtin_fma(p, u, 1.0 / 5.0);
+    p = __builtin_fma(p, u, -0.25);
+    p = __builtin_fma(p, u, 1.0 / 3.0);
+    p = __builtin_fma(p, u, -0.5);
+    p = __builtin_fma(p, u, 1.0);
+    return __builtin_fma(p, u, tab[F64Tables::LOGC + j]);
+}
 __device__ __forceinline__ float exp_(float x) { return expf(x); }
 __device__ __forceinline__ double exp_(double x) { return exp(x); }
 __device__ __forceinline__ float sqrt_(float x) { return sqrtf(x); }

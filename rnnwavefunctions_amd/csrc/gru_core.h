@@ -41,13 +41,7 @@ template <> struct Act<double> {
     // f64 without ocml's special-case handling: exp_fast (20 instructions, device.h) and a reciprocal from v_rcp_f64
     // plus two Newton steps (5 instructions) instead of exp (~40) + IEEE division (~15) and tanh (~60 with branches);
     // relative error < 1e-15, i.e. the level of the f64 oracle's own libm.  2DTFIM_1DRNN flip pass 58 -> see DESIGN.md.
-    static __device__ __forceinline__ double rcp_fast(double d) {
-        double y = __builtin_amdgcn_rcp(d);
-        double e = __builtin_fma(-d, y, 1.0);
-        y = __builtin_fma(y, e, y);
-        e = __builtin_fma(-d, y, 1.0);
-        return __builtin_fma(y, e, y);
-    }
+    static __device__ __forceinline__ double rcp_fast(double d) { return rcp_fast_f64(d); }
     static __device__ __forceinline__ double sigmoid_scaled(double a) {
         const double x = a > 700.0 ? 700.0 : a;                    // exp_fast clamps the other side
         return rcp_fast(1.0 + exp_fast(-x));

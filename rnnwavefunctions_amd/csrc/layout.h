@@ -24,6 +24,16 @@
 
 namespace rnnwf {
 
+// exp / log tables of the float64 models (device.h: exp_tab, log1p_tab; filled by pack.h: fill_f64_tables)
+struct F64Tables {                       // layout of the table block in LDS (doubles)
+    static constexpr int EXP2 = 0;       // [64]  2^(j/64)
+    static constexpr int RCPC = 64;      // [64]  1 / c_j,  c_j = 1 + (j + 1/2) / 64
+    static constexpr int LOGC = 128;     // [64]  log(c_j)
+    static constexpr int COUNT = 192;
+    static constexpr size_t BYTES = COUNT * 8;
+};
+
+
 constexpr int kChains = 16;  // chains (spin configurations) per wave: the N dimension of the 16x16x4 MFMA
 
 template <typename T, int NFULL_, int NOUT_>

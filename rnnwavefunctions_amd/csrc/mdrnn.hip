@@ -29,10 +29,11 @@ struct MLaunch {
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }
+    static constexpr size_t FLIP_LDS = L::BYTES + (size_t)WAVES * L::WORDS_BYTES;     // image + the waves' spin words
     static int flip_grid(rnnwf_handle* h, int64_t ntiles, unsigned* grid) {
         const void* fn = (const void*)mdrnn_flip_kernel<NFULL, WAVES>;
         int bpc = 0;
-        if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
+        if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, FLIP_LDS, &bpc)) return rc;
         const int64_t need = (ntiles + WAVES - 1) / WAVES;
         *grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
         return 0;
@@ -40,12 +41,12 @@ struct MLaunch {
     static int flip(rnnwf_handle* h, MdArgs a) {
         unsigned grid = 0;
         if (int rc = flip_grid(h, a.ntiles, &grid)) return rc;
-        const size_t ring_bytes = (size_t)grid * WAVES * 2 * a.Nx * ((L::KT + 1) / 2) * 64 * 16;
+        const size_t ring_bytes = (size_t)grid * WAVES * a.Nx * ((L::KT + 1) / 2) * 64 * 16;      // one slot per lattice column
         if (int rc = ensure(h, h->rowbuf, ring_bytes)) return rc;
         a.ring = (double*)h->rowbuf.p;
         a.ablate = h->knobs.ablate;   // 0 unless a -DRNNWF_DIAGNOSTICS build read RNNWF_ABLATE
         TimedLaunch tl(h, 1);
-        mdrnn_flip_kernel<NFULL, WAVES><<<grid, WAVES * 64, L::BYTES, h->stream>>>(a);
+        mdrnn_flip_kernel<NFULL, WAVES><<<grid, WAVES * 64, FLIP_LDS, h->stream>>>(a);
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }
@@ -112,6 +113,15 @@ struct MLaunch {
             }
         BD[0] = bd[0];
         BD[1] = bd[1];
+        // b + Uh[x_h] + Uv[x_v] for the nine (x_h, x_v) in {none, 0, 1}^2: one accumulator start value per step
+        for (int vh = 0; vh < 3; ++vh)
+            for (int vv = 0; vv < 3; ++vv) {
+                double* BHV = reinterpret_cast<double*>(img.data() + L::OFF_BHV + (size_t)(vh * 3 + vv) * L::SZ_B);
+                const double* BH = reinterpret_cast<const double*>(img.data() + L::OFF_BH + vh * L::SZ_B);
+                const double* BV = reinterpret_cast<const double*>(img.data() + L::OFF_BV + vv * L::SZ_B);
+                for (size_t k = 0; k < L::SZ_B / 8; ++k) BHV[k] = BH[k] + BV[k];
+            }
+        fill_f64_tables(reinterpret_cast<double*>(img.data() + L::OFF_TAB));
         double* WDD = reinterpret_cast<double*>(img.data() + L::OFF_WDD);
         for (int unit = 0; unit < H; ++unit) WDD[unit] = Wd[(size_t)unit * 2 + 1] - Wd[(size_t)unit * 2];   // slot 4 kt + q
         WDD[L::KT * 4] = bd[1] - bd[0];

@@ -29,7 +29,10 @@ struct MdLayout {
     static constexpr size_t OFF_WD = OFF_BV + 3 * SZ_B;                      // [KT][4][2] f64
     static constexpr size_t OFF_BD = OFF_WD + (size_t)KT * 4 * 2 * 8;        // [2] f64
     static constexpr size_t OFF_WDD = OFF_BD + 16;                           // [KT][4] f64: Wd[:,1] - Wd[:,0], then bd[1] - bd[0]
-    static constexpr size_t BYTES = ((OFF_WDD + ((size_t)KT * 4 + 1) * 8 + 15) / 16) * 16;
+    static constexpr size_t OFF_TAB = ((OFF_WDD + ((size_t)KT * 4 + 1) * 8 + 15) / 16) * 16;   // F64Tables (exp / log tables)
+    static constexpr size_t OFF_BHV = OFF_TAB + F64Tables::BYTES;            // [3 x_h][3 x_v][NT][4][4] f64 : b + Uh[x_h] + Uv[x_v]
+    static constexpr size_t BYTES = OFF_BHV + 9 * SZ_B;
+    static constexpr size_t WORDS_BYTES = 8 * 64 * 4;                        // per wave, behind the image: the chain's spin words
 };
 
 struct MdArgs {
@@ -48,7 +51,8 @@ struct MdArgs {
     uint64_t seed, step;
     int64_t sample_offset;
     int32_t sampling;
-    int32_t ablate;                // diagnostics only (RNNWF_ABLATE), flip pass: 1 no ring stores, 2 no h_v loads, 4 no head
+    int32_t ablate;                // diagnostics only (RNNWF_ABLATE), flip pass: 1 no ring stores, 2 no h_v loads, 4 no head,
+                                   // 8 no elu, 16 no remainder-unit FMAs, 32 no MFMAs
     int64_t ntiles;
 };
 
@@ -83,40 +87,62 @@ struct MdCore {
         for (int g = 0; g < KP; ++g) dst[g * 64] = V2{srcv[2 * g], 2 * g + 1 < KT ? srcv[2 * g + 1] : 0.0};
     }
 
-    static __device__ __forceinline__ double elu(double x) {
-        const double e = exp_fast(x < 0.0 ? x : 0.0) - 1.0;             // tf.nn.elu; abs error < 3e-16
-        return x > 0.0 ? x : e;
+    // tf.nn.elu = max(x, 0) + (e^min(x, 0) - 1): no select, table-driven exp (abs error ~1e-16)
+    static __device__ __forceinline__ double elu(double x, const double* tab) {
+        return __builtin_fmax(x, 0.0) + (exp_tab(__builtin_fmin(x, 0.0), tab) - 1.0);
     }
 
-    // hh = h_h fragment, hv = h_v fragment; result in out[KT].  rem = num_units - 16 NFULL (1..4).
+    // hh = h_h fragment, hv = h_v fragment; result in out[KT] (may alias hh).  rem = num_units - 16 NFULL (1..4).
+    // Everything that needs only h_h (its half of the remainder-unit FMAs, the first 2 floor(KT/2) k-steps of the MFMA
+    // chain) is issued before anything touches h_v: in the flip pass h_v is a 7 KB read from HBM that has then ~2 300
+    // cycles to land.
     static __device__ __forceinline__ void step(const char* lds, int sig_h, int sig_v, const double (&hh)[KT],
-                                                const double (&hv)[KT], double (&out)[KT], int lane, int rem) {
+                                                const double (&hv)[KT], double (&out)[KT], int lane, int rem, int ablate = 0) {
         const int q = lane >> 4;
-        double hk[2 * KT];
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) { hk[kt] = hh[kt]; hk[KT + kt] = hv[kt]; }
         asm volatile("" ::: "memory");   // keep the weight fragments in LDS, not in registers (see gru_core.h)
-        const char* bh = lds + L::OFF_BH + (size_t)(sig_h + 1) * L::SZ_B + (size_t)q * 32;
-        const char* bv = lds + L::OFF_BV + (size_t)(sig_v + 1) * L::SZ_B + (size_t)q * 32;
+        const double* tab = reinterpret_cast<const double*>(lds + L::OFF_TAB);
+        const char* bhv = lds + L::OFF_BHV + (size_t)((sig_h + 1) * 3 + (sig_v + 1)) * L::SZ_B + (size_t)q * 32;
+        const V2* wr = reinterpret_cast<const V2*>(lds + L::OFF_WR) + q * 2;
+        const V2* av = reinterpret_cast<const V2*>(lds + L::OFF_A) + lane;
+        auto hk = [&](int kk) -> double { return kk < KT ? hh[kk] : hv[kk - KT]; };
         // remainder units on the VALU: this lane's rows 4 kt + q of [Wh ; Wv] against its own fragment values
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        {
-            const V2* wr = reinterpret_cast<const V2*>(lds + L::OFF_WR) + q * 2;
+        auto rem_part = [&](int k0, int k1) {
 #pragma unroll
-            for (int kk = 0; kk < 2 * KT; ++kk) {
+            for (int kk = k0; kk < k1; ++kk) {
                 const V2 w01 = wr[kk * 8];
-                s0 = __builtin_fma(hk[kk], w01[0], s0);
-                s1 = __builtin_fma(hk[kk], w01[1], s1);
+                s0 = __builtin_fma(hk(kk), w01[0], s0);
+                s1 = __builtin_fma(hk(kk), w01[1], s1);
             }
             if (rem > 2) {
 #pragma unroll
-                for (int kk = 0; kk < 2 * KT; ++kk) {
+                for (int kk = k0; kk < k1; ++kk) {
                     const V2 w23 = wr[kk * 8 + 1];
-                    s2 = __builtin_fma(hk[kk], w23[0], s2);
-                    s3 = __builtin_fma(hk[kk], w23[1], s3);
+                    s2 = __builtin_fma(hk(kk), w23[0], s2);
+                    s3 = __builtin_fma(hk(kk), w23[1], s3);
                 }
             }
-        }
+        };
+        V4 acc[NFULL];
+#pragma unroll
+        for (int t = 0; t < NFULL; ++t) acc[t] = *reinterpret_cast<const V4*>(bhv + t * 128);
+        auto mfma_part = [&](int g0, int g1) {          // k-step pairs [g0, g1) of the concatenated [h_h ; h_v]
+#pragma unroll
+            for (int g = g0; g < g1; ++g) {
+                V2 a[NFULL];
+#pragma unroll
+                for (int t = 0; t < NFULL; ++t) a[t] = av[(t * KT + g) * 64];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int t = 0; t < NFULL; ++t) acc[t] = F::mfma(a[t][j], hk(2 * g + j), acc[t]);
+            }
+        };
+        constexpr int GH = KT / 2;                      // pairs made of h_h k-steps only
+        if (!RNNWF_ABLATED(ablate, 16)) rem_part(0, KT);
+        if (!RNNWF_ABLATED(ablate, 32)) mfma_part(0, GH);
+        if (!RNNWF_ABLATED(ablate, 16)) rem_part(KT, 2 * KT);
+        if (!RNNWF_ABLATED(ablate, 32)) mfma_part(GH, KT);
         // quarter q keeps unit j = q: fold the four quarters' partial sums with three exchanges
         const bool lo = q < 2;
         double ka = lo ? s0 : s2, kb = lo ? s1 : s3;
@@ -125,28 +151,20 @@ struct MdCore {
         const bool even = (q & 1) == 0;
         double mine = even ? ka : kb;
         mine += __shfl_xor(even ? kb : ka, 16);
-        mine += *reinterpret_cast<const double*>(bh + NFULL * 128) + *reinterpret_cast<const double*>(bv + NFULL * 128);
-        asm volatile("" ::: "memory");
-        V4 acc[NFULL];
+        mine += *reinterpret_cast<const double*>(bhv + NFULL * 128);
+        if (RNNWF_ABLATED(ablate, 8)) {                 // timing only: no elu
 #pragma unroll
-        for (int t = 0; t < NFULL; ++t)
-            acc[t] = *reinterpret_cast<const V4*>(bh + t * 128) + *reinterpret_cast<const V4*>(bv + t * 128);
-        const V2* av = reinterpret_cast<const V2*>(lds + L::OFF_A) + lane;
+            for (int m = 0; m < NFULL; ++m)
 #pragma unroll
-        for (int g = 0; g < KT; ++g) {
-            V2 a[NFULL];
-#pragma unroll
-            for (int t = 0; t < NFULL; ++t) a[t] = av[(t * KT + g) * 64];
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int t = 0; t < NFULL; ++t) acc[t] = F::mfma(a[t][j], hk[2 * g + j], acc[t]);
+                for (int r = 0; r < 4; ++r) out[4 * m + r] = acc[m][r] * 0.001;
+            out[KT - 1] = mine * 0.001;
+            return;
         }
 #pragma unroll
         for (int m = 0; m < NFULL; ++m)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[4 * m + r] = elu(acc[m][r]);
-        out[KT - 1] = q < rem ? elu(mine) : 0.0;
+            for (int r = 0; r < 4; ++r) out[4 * m + r] = elu(acc[m][r], tab);
+        out[KT - 1] = q < rem ? elu(mine, tab) : 0.0;
     }
 
     // log p(0), log p(1) of the Dense(2)+softmax head (and p(0) for the sampler), from the logit difference:
@@ -160,13 +178,14 @@ struct MdCore {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) d = __builtin_fma(h[kt], wdd[kt * 4 + q], d);
         d += __shfl_xor(d, 16); d += __shfl_xor(d, 32); d += wdd[KT * 4];
-        const double ad = d < 0.0 ? -d : d;
-        const double e = exp_fast(-ad);                     // in (0, 1]
-        const double lg = log(1.0 + e);
+        const double* tab = reinterpret_cast<const double*>(lds + L::OFF_TAB);
+        const double ad = __builtin_fabs(d);
+        const double e = exp_tab(-ad, tab);                 // in (0, 1]
+        const double lg = log1p_tab(e, tab);
         const double big = -(ad + lg), small = -lg;         // log-probability of the less / more likely value
         lp0 = d > 0.0 ? big : small;
         lp1 = d > 0.0 ? small : big;
-        const double inv = 1.0 / (1.0 + e);
+        const double inv = rcp_fast_f64(1.0 + e);  // (sampler only)
         p0 = d > 0.0 ? e * inv : inv;
     }
 };
@@ -263,27 +282,43 @@ __global__ void __launch_bounds__(WAVES * 64, NFULL <= 3 ? 2 : 1) mdrnn_flip_ker
     const int64_t nw = (int64_t)gridDim.x * WAVES;
     const int N = a.N;
     const int W = (N + 31) / 32;
-    const int R = 2 * a.Nx;                                            // ring slots (positions) per wave
-    double* ring = a.ring + (int64_t)gw * R * C::KP * 128 + 2 * lane;
+    // States this chain produced itself: ONE slot per lattice column.  On the zig-zag path row ny+1 consumes the states
+    // of row ny in reverse order of their production, so the state above site (nx, ny+1) is always the last one written
+    // to column nx, and the site's own state replaces it: Nx slots (84 KB per wave at 12 columns), half of what a
+    // position-indexed ring of 2 Nx needs - 172 MB for the whole grid at config 4, which fits the 256 MB Infinity Cache.
+    const int Nx = a.Nx;
+    double* ring = a.ring + (int64_t)gw * Nx * C::KP * 128 + 2 * lane;
+    uint32_t* words = reinterpret_cast<uint32_t*>(lds + C::L::BYTES) + (threadIdx.x >> 6) * 8 * 64 + lane;
     for (int64_t tile = gw; tile < a.ntiles; tile += nw) {
         const int i = (int)(tile / a.nsb);
         const int64_t sb = tile - (int64_t)i * a.nsb;
         const int64_t s = sb * kChains + c;
         const bool valid = s < a.ns;
         const int64_t sc = valid ? s : a.ns - 1;
-        uint32_t words[8];
+        // the flipped configuration's spin words live in LDS ([word][lane], private to the wave): three 4-byte reads per
+        // step at a wave-uniform word index instead of three 8-way register selects (48 VALU instructions per step)
 #pragma unroll
-        for (int w = 0; w < 8; ++w) words[w] = w < W ? a.bits[(int64_t)w * a.ns + sc] : 0u;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) if (w == (i >> 5)) words[w] ^= 1u << (i & 31);    // the flipped configuration
+        for (int w = 0; w < 8; ++w) {
+            uint32_t v = w < W ? a.bits[(int64_t)w * a.ns + sc] : 0u;
+            if (w == (i >> 5)) v ^= 1u << (i & 31);
+            words[w * 64] = v;
+        }
         double hv[KT], hn[KT];
         C::load_state(a.hs + (((int64_t)i * a.nsb + sb) * C::KP) * 128 + 2 * lane, hn);   // state after position i (unchanged)
         // h_v operand of position p: zero (first row), the state just computed (row turn), a base-pass state
         // (pv <= i) or one this chain produced (ring).  (Fetching one step ahead, behind the previous position's
         // head, measured 3 % SLOWER at config 4, and non-temporal ring accesses made no difference: the loads are
         // not latency-bound at 2 waves/SIMD.)
-        auto fetch_v = [&](int p) {
-            const int pv = a.vert_pos[p];
+        // position bookkeeping of the zig-zag path without table look-ups: p = ny Nx + j, column nx = j (even rows) or
+        // Nx-1-j (odd rows), vertical neighbour (nx, ny-1) at position p - 2j - 1
+        int ny = (i + 1) / Nx, j = (i + 1) - ny * Nx;
+        double lp = 0.0;
+        for (int p = i + 1; p < N; ++p) {
+            const bool first = j == 0;
+            const int pv = ny > 0 ? p - 2 * j - 1 : -1;
+            const int nx = (ny & 1) ? Nx - 1 - j : j;
+            // h_v operand: zero (first row), the state just computed (row turn), a base-pass state (pv <= i) or one this
+            // chain produced (its column slot).  A row turn copies hn into hv before hn is cleared.
             if (pv < 0) {
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) hv[kt] = 0.0;
@@ -296,38 +331,23 @@ __global__ void __launch_bounds__(WAVES * 64, NFULL <= 3 ? 2 : 1) mdrnn_flip_ker
             } else if (pv <= i) {
                 C::load_state(a.hs + (((int64_t)pv * a.nsb + sb) * C::KP) * 128 + 2 * lane, hv);
             } else {
-                C::load_state(ring + (int64_t)(pv % R) * C::KP * 128, hv);
+                C::load_state(ring + (int64_t)nx * C::KP * 128, hv);
             }
-        };
-        double lp = 0.0;
-        for (int p = i + 1; p < N; ++p) {
-            const int pv = a.vert_pos[p];
-            const bool first = a.row_first[p] != 0;
-            fetch_v(p);                            // (a row turn copies hn into hv here, before hn is cleared)
             if (first) {                           // no horizontal neighbour: uniform, once per row
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) hn[kt] = 0.0;
             }
-            uint32_t wq = 0;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) if (w == ((p - 1) >> 5)) wq = words[w];
+            const uint32_t wq = words[((p - 1) >> 5) * 64];
             const int sig_h = first ? -1 : (int)((wq >> ((p - 1) & 31)) & 1);
             int sig_v = -1;
-            if (pv >= 0) {
-                uint32_t wv = 0;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) if (w == (pv >> 5)) wv = words[w];
-                sig_v = (wv >> (pv & 31)) & 1;
-            }
-            C::step(lds, sig_h, sig_v, hn, hv, hn, lane, a.rem);      // in place: step copies its inputs first
+            if (pv >= 0) sig_v = (int)((words[(pv >> 5) * 64] >> (pv & 31)) & 1);
+            C::step(lds, sig_h, sig_v, hn, hv, hn, lane, a.rem, a.ablate);
             double lp0 = hn[0], lp1 = hn[1], p0;
             if (!RNNWF_ABLATED(a.ablate, 4)) C::head(lds, hn, lane, lp0, lp1, p0);
-            uint32_t wp = 0;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) if (w == (p >> 5)) wp = words[w];
-            lp += ((wp >> (p & 31)) & 1) ? lp1 : lp0;
+            lp += ((words[(p >> 5) * 64] >> (p & 31)) & 1) ? lp1 : lp0;
             // the last row has no vertical successor: nothing reads its states
-            if (p < N - a.Nx && !RNNWF_ABLATED(a.ablate, 1)) C::store_state(ring + (int64_t)(p % R) * C::KP * 128, hn);
+            if (p < N - Nx && !RNNWF_ABLATED(a.ablate, 1)) C::store_state(ring + (int64_t)nx * C::KP * 128, hn);
+            if (++j == Nx) { j = 0; ++ny; }
         }
         if (valid && q == 0) a.lpq[(int64_t)a.row_of_pos[i] * a.ns + s] += lp;
     }

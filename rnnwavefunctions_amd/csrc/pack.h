@@ -1,5 +1,6 @@
 // pack.h - host-side packing of TF-named parameters into the LDS weight image of layout.h.
 #pragma once
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -119,6 +120,16 @@ std::vector<char> pack_gru_image(const rnnwf_handle* h) {
         bd[2] = (T)bp[1];
     }
     return img;
+}
+
+// exp / log tables of device.h (F64Tables): 2^(j/64), 1/c_j, log(c_j) with c_j = 1 + (j + 1/2)/64
+inline void fill_f64_tables(double* t) {
+    for (int j = 0; j < 64; ++j) {
+        const double c = 1.0 + (j + 0.5) / 64.0;
+        t[F64Tables::EXP2 + j] = std::exp2(j / 64.0);
+        t[F64Tables::RCPC + j] = 1.0 / c;
+        t[F64Tables::LOGC + j] = std::log(c);
+    }
 }
 
 // Image of GRU layer `layer` >= 1 (input = state of the layer below, dimension H), UpperLayout<NFULL>.

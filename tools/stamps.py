@@ -12,7 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-if not os.environ.get("RNNWF_ABLATE"):
+if os.environ.get("RNNWF_ABLATE") is None:
     os.environ["RNNWF_STAMPS"] = "1"          # with RNNWF_ABLATE=bits: timing only (1 no MFMA segment, 2 no gates, 4 no head, 8 no split)
 from rnnwavefunctions_amd import _lib   # noqa: E402
 
