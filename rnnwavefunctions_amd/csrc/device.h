@@ -75,10 +75,27 @@ __device__ __forceinline__ double rcp_fast_f64(double d) {
     e = __builtin_fma(-d, y, 1.0);
     return __builtin_fma(y, e, y);
 }
-// e^x for x <= 0 (clamped at -700): x = (64 m + j) ln2/64 + r, |r| <= ln2/128; e^r by a degree-5 polynomial
-// (truncation r^6/720 < 4e-17); relative error ~1 ulp of the tabulated 2^(j/64).
+// ---- cross-quarter exchanges of doubles on v_permlane16_swap / v_permlane32_swap (VALU, 4 cycles per dword) instead of
+// ds_bpermute (an LDS round trip each): swap32(a, b) leaves {a.lower | b.lower} and {a.upper | b.upper} (lane halves),
+// swap16 the same for the 16-lane rows {r0, r2} / {r1, r3}; the sum of the two results is, per half (row pair), the
+// reduction of a over the halves in the lower one and of b in the upper one.
+__device__ __forceinline__ double pair_sum32(double a, double b) {
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double pair_sum16(double a, double b) {
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// sum of v over the four lane quarters, in every lane
+__device__ __forceinline__ double quarter_sum(double v) { const double t = pair_sum16(v, v); return pair_sum32(t, t); }
+
+// e^x for x <= 0: x = (64 m + j) ln2/64 + r, |r| <= ln2/128; e^r by a degree-5 polynomial (truncation r^6/720 < 4e-17);
+// relative error ~1 ulp of the tabulated 2^(j/64).  No clamp: far below the underflow threshold the integer conversion
+// saturates, r stays finite and v_ldexp_f64 returns 0.
 __device__ __forceinline__ double exp_tab(double x, const double* tab) {
-    x = __builtin_fmax(x, -700.0);
     const double kf = __builtin_rint(x * 0x1.71547652b82fep+6);                  // 64 / ln 2
     double r = __builtin_fma(kf, -0x1.62e42fee00000p-7, x);                     // ln2/64, high part (21 trailing zero bits: k * high is exact)
     r = __builtin_fma(kf, -0x1.a39ef35793c76p-39, r);                            // ln2/64 - high

@@ -143,14 +143,9 @@ struct MdCore {
         if (!RNNWF_ABLATED(ablate, 32)) mfma_part(0, GH);
         if (!RNNWF_ABLATED(ablate, 16)) rem_part(KT, 2 * KT);
         if (!RNNWF_ABLATED(ablate, 32)) mfma_part(GH, KT);
-        // quarter q keeps unit j = q: fold the four quarters' partial sums with three exchanges
-        const bool lo = q < 2;
-        double ka = lo ? s0 : s2, kb = lo ? s1 : s3;
-        ka += __shfl_xor(lo ? s2 : s0, 32);
-        kb += __shfl_xor(lo ? s3 : s1, 32);
-        const bool even = (q & 1) == 0;
-        double mine = even ? ka : kb;
-        mine += __shfl_xor(even ? kb : ka, 16);
+        // quarter q keeps unit j = q: lower half folds (s0, s1), upper half (s2, s3); then even rows keep the first
+        const double ka = pair_sum32(s0, s2), kb = pair_sum32(s1, s3);
+        double mine = pair_sum16(ka, kb);
         mine += *reinterpret_cast<const double*>(bhv + NFULL * 128);
         if (RNNWF_ABLATED(ablate, 8)) {                 // timing only: no elu
 #pragma unroll
@@ -177,7 +172,7 @@ struct MdCore {
         double d = 0.0;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) d = __builtin_fma(h[kt], wdd[kt * 4 + q], d);
-        d += __shfl_xor(d, 16); d += __shfl_xor(d, 32); d += wdd[KT * 4];
+        d = quarter_sum(d) + wdd[KT * 4];
         const double* tab = reinterpret_cast<const double*>(lds + L::OFF_TAB);
         const double ad = __builtin_fabs(d);
         const double e = exp_tab(-ad, tab);                 // in (0, 1]
@@ -313,6 +308,16 @@ __global__ void __launch_bounds__(WAVES * 64, NFULL <= 3 ? 2 : 1) mdrnn_flip_ker
         // Nx-1-j (odd rows), vertical neighbour (nx, ny-1) at position p - 2j - 1
         int ny = (i + 1) / Nx, j = (i + 1) - ny * Nx;
         double lp = 0.0;
+        // the three spin bits a step needs (horizontal input, vertical input, the observed spin) are looked up ONE step
+        // ahead: the LDS reads, shifts and the table address of the accumulator start value leave the critical path
+        auto bits_of = [&](int p, int jj, int nyy, int& sh, int& sv, int& so) {
+            const int pv = nyy > 0 ? p - 2 * jj - 1 : -1;
+            sh = jj == 0 ? -1 : (int)((words[((p - 1) >> 5) * 64] >> ((p - 1) & 31)) & 1);
+            sv = pv >= 0 ? (int)((words[(pv >> 5) * 64] >> (pv & 31)) & 1) : -1;
+            so = (int)((words[(p >> 5) * 64] >> (p & 31)) & 1);
+        };
+        int sig_h = -1, sig_v = -1, sig_o = 0;
+        if (i + 1 < N) bits_of(i + 1, j, ny, sig_h, sig_v, sig_o);
         for (int p = i + 1; p < N; ++p) {
             const bool first = j == 0;
             const int pv = ny > 0 ? p - 2 * j - 1 : -1;
@@ -337,17 +342,17 @@ __global__ void __launch_bounds__(WAVES * 64, NFULL <= 3 ? 2 : 1) mdrnn_flip_ker
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) hn[kt] = 0.0;
             }
-            const uint32_t wq = words[((p - 1) >> 5) * 64];
-            const int sig_h = first ? -1 : (int)((wq >> ((p - 1) & 31)) & 1);
-            int sig_v = -1;
-            if (pv >= 0) sig_v = (int)((words[(pv >> 5) * 64] >> (pv & 31)) & 1);
-            C::step(lds, sig_h, sig_v, hn, hv, hn, lane, a.rem, a.ablate);
+            const int sh = sig_h, sv = sig_v, so = sig_o;
+            int jn = j + 1, nyn = ny;
+            if (jn == Nx) { jn = 0; ++nyn; }
+            if (p + 1 < N) bits_of(p + 1, jn, nyn, sig_h, sig_v, sig_o);      // next step's bits, in flight during this one
+            C::step(lds, sh, sv, hn, hv, hn, lane, a.rem, a.ablate);
             double lp0 = hn[0], lp1 = hn[1], p0;
             if (!RNNWF_ABLATED(a.ablate, 4)) C::head(lds, hn, lane, lp0, lp1, p0);
-            lp += ((words[(p >> 5) * 64] >> (p & 31)) & 1) ? lp1 : lp0;
+            lp += so ? lp1 : lp0;
             // the last row has no vertical successor: nothing reads its states
             if (p < N - Nx && !RNNWF_ABLATED(a.ablate, 1)) C::store_state(ring + (int64_t)nx * C::KP * 128, hn);
-            if (++j == Nx) { j = 0; ++ny; }
+            j = jn; ny = nyn;
         }
         if (valid && q == 0) a.lpq[(int64_t)a.row_of_pos[i] * a.ns + s] += lp;
     }
