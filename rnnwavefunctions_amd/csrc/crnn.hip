@@ -8,8 +8,6 @@
 #include "crnn_ml_kernels.h"
 #include "models.h"
 #include "pack.h"
-#include "pack_split.h"
-#include "crnn_split_kernels.h"
 
 using namespace rnnwf;
 
@@ -127,64 +125,6 @@ struct CMLaunch {
         }                                                       \
     } while (0)
 
-// ---- bf16x3 engine for the swap pass (num_units <= 68) ---------------------------------------------------
-template <int NF32, int RJ, int WAVES, int MODE>
-struct CSLaunch {
-    using L = SplitLayout<NF32, RJ, 3, MODE>;
-    static int swap(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles, int kt16) {
-        const void* fn = (const void*)crnn_swap_split_kernel<NF32, RJ, WAVES, MODE>;
-        int bpc = 0;
-        if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, L::BYTES, &bpc)) return rc;
-        const int64_t need = (max_tiles + WAVES - 1) / WAVES;
-        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
-        TimedLaunch tl(h, 1);
-        crnn_swap_split_kernel<NF32, RJ, WAVES, MODE><<<grid, WAVES * 64, L::BYTES, h->stream>>>(a, h->wsplit.p, kt16);
-        RNNWF_HIP(h, hipGetLastError());
-        return 0;
-    }
-    // ping-pong form (8 waves per workgroup, alternating MFMA / VALU segments): K-packed layout MODE 2 only
-    static int swap_pp(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles, int kt16) {
-        if constexpr (MODE == 2) {
-            const void* fn = (const void*)crnn_swap_pp_kernel<NF32, RJ>;
-            if (L::HP > 4 * kt16) return h->fail(RNNWF_ERR_INVALID, "bf16x3 layout wider than the checkpoint rows (%d > %d)", L::HP, 4 * kt16);
-            int bpc = 0;
-            if (int rc = rnnwf::blocks_per_cu(h, fn, 512, L::BYTES, &bpc)) return rc;
-            const int64_t need = (max_tiles + 7) / 8;
-            const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
-            TimedLaunch tl(h, 1);
-            crnn_swap_pp_kernel<NF32, RJ><<<grid, 512, L::BYTES, h->stream>>>(a, h->wsplit.p, kt16);
-            RNNWF_HIP(h, hipGetLastError());
-            return 0;
-        } else {
-            return swap(h, a, max_tiles, kt16);
-        }
-    }
-    static std::vector<char> pack(const rnnwf_handle* h) { return pack_split_image<NF32, RJ, 3, MODE>(h); }
-    static double mfma_flops_per_step() { return (double)L::NT * L::KS * 32768.0; }
-};
-
-#define CSPLIT_DISPATCH(h, EXPR)                                     \
-    do {                                                             \
-        switch ((h)->NFULL) {                                        \
-            case 1: { using K = CSLaunch<0, 10, 4, 1>; EXPR; }       \
-            case 2: { using K = CSLaunch<1, 2, 4, 1>; EXPR; }        \
-            case 3: if ((h)->H <= 50) { using K = CSLaunch<1, 9, 4, 2>; EXPR; } \
-                    else { using K = CSLaunch<1, 10, 4, 0>; EXPR; }  \
-            case 4: { using K = CSLaunch<2, 2, 4, 0>; EXPR; }        \
-        }                                                            \
-    } while (0)
-
-int launch_swap_split(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles) {
-    const int kt16 = 4 * h->NFULL + 1;
-    if (h->knobs.engine == 3) { CSPLIT_DISPATCH(h, return K::swap(h, a, max_tiles, kt16)); }      // RNNWF_ENGINE=bf16x3-serial: A/B only
-    else { CSPLIT_DISPATCH(h, return K::swap_pp(h, a, max_tiles, kt16)); }
-    return h->fail(RNNWF_ERR_INVALID, "no bf16x3 cRNN kernel for NFULL=%d", h->NFULL);
-}
-double csplit_mfma_flops_per_step(rnnwf_handle* h) {
-    CSPLIT_DISPATCH(h, return K::mfma_flops_per_step());
-    return 0;
-}
-
 int launch_base(rnnwf_handle* h, const CrnnArgs& a) {
     CRNN_DISPATCH(h, return K::base(h, a));
     return h->fail(RNNWF_ERR_INVALID, "no cRNN kernel for NFULL=%d", h->NFULL);
@@ -270,7 +210,7 @@ int j1j2_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
     a.contrib = (double2*)h->lpq.p;
     const int64_t max_tiles = (int64_t)N * ((2 * ns + kChains - 1) / kChains + 2);
     if (h->engine_split) {
-        if (int rc = launch_swap_split(h, a, max_tiles)) return rc;
+        if (int rc = crnn_split_swap(h, a, max_tiles)) return rc;
     } else {
         if (int rc = launch_swap(h, a, max_tiles)) return rc;
     }
@@ -287,7 +227,7 @@ int j1j2_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
 int64_t collect_totals(rnnwf_handle* h, int64_t ns) {
     const int64_t* t = (const int64_t*)((char*)h->pinned + 64);
     h->work[0] += (double)t[1];
-    h->work[1] += (double)t[2] * (h->engine_split ? csplit_mfma_flops_per_step(h)
+    h->work[1] += (double)t[2] * (h->engine_split ? crnn_split_flops_per_step(h)
                                                   : (double)(3 * h->NFULL + 1) * (4 * h->NFULL + 1) * 2048.0);
     return t[0] + ns;   // + one diagonal configuration per sample
 }
@@ -299,7 +239,7 @@ int rnnwf::crnn_pack_image(rnnwf_handle* h, std::vector<char>& img) {
     h->engine_split = h->NL == 1 && h->NFULL <= 4 && h->knobs.engine != 1;     // stacked layers: f32-input MFMA
     if (h->engine_split) {
         std::vector<char> simg;
-        CSPLIT_DISPATCH(h, { simg = K::pack(h); break; });
+        if (int rc = crnn_split_pack(h, simg)) return rc;
         if (int rc = ensure(h, h->wsplit, simg.size())) return rc;
         RNNWF_HIP(h, hipStreamSynchronize(h->stream));
         RNNWF_HIP(h, hipMemcpy(h->wsplit.p, simg.data(), simg.size(), hipMemcpyHostToDevice));

@@ -214,7 +214,7 @@ __device__ __forceinline__ int lo_of_block(int N, int slot, int periodic) {
 }
 
 // grid.y = bond slot (0..2N-1), 256 samples per block
-__global__ void __launch_bounds__(256) j1j2_enumerate_kernel(J1J2Args a) {
+static __global__ void __launch_bounds__(256) j1j2_enumerate_kernel(J1J2Args a) {
     const int N = a.N;
     const int slot = blockIdx.y;
     const int dist = slot < N ? 1 : 2;
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(256) j1j2_enumerate_kernel(J1J2Args a) {
 // tile_start[lo] = sum_{l < lo} ceil(cnt[l] / 16); tile_start[N] = total;
 // totals[0] = sum cnt (off-diagonal configurations), totals[1] = sum cnt[lo] (N-1-lo) (cell evaluations),
 // totals[2] = sum tiles[lo] (N-1-lo) (wave-steps actually issued)
-__global__ void j1j2_tile_scan_kernel(const int32_t* cnt, int N, int32_t* tile_start, int64_t* totals, int tile_items) {
+static __global__ void j1j2_tile_scan_kernel(const int32_t* cnt, int N, int32_t* tile_start, int64_t* totals, int tile_items) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     int32_t acc = 0;
     int64_t items = 0, evals = 0, wsteps = 0;
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(WAVES * 64) crnn_swap_kernel(CrnnArgs a) {
 }
 
 // E_loc[s] = diag + sum over bond slots (J1 bonds by site, then J2 bonds by site: the reference's row order)
-__global__ void j1j2_eloc_kernel(const double2* __restrict__ contrib, const double* __restrict__ diag, int64_t ns,
+static __global__ void j1j2_eloc_kernel(const double2* __restrict__ contrib, const double* __restrict__ diag, int64_t ns,
                                  int N, float2* __restrict__ eloc) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= ns) return;

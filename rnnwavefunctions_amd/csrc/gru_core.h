@@ -121,6 +121,11 @@ struct GruCore {
         for (int t = 0; t < NT; ++t)
             acc[t] = BIAS_LAST ? V4{T(0), T(0), T(0), T(0)} : *reinterpret_cast<const V4*>(binit + (size_t)t * 16 * sizeof(T));
         const VA* av = reinterpret_cast<const VA*>(lds + L::OFF_AVEC) + lane;
+        // The MFMA chain and the gate arithmetic stay separate scheduling regions: merged into one, hipcc weaves the
+        // gates between the f32 MFMAs - which cannot overlap them on gfx950 - and pays 17 more hazard no-ops and 7 % of
+        // config 5 (measured round 2: 320.8 vs 297.3 ms; round 1 had the regions by accident, through the run-time
+        // diagnostics branches that stood here).
+        __builtin_amdgcn_sched_barrier(0);
         if (!RNNWF_ABLATED(ablate, 1)) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -143,6 +148,7 @@ struct GruCore {
             for (int t = 0; t < NT; ++t) acc[t] = F::mfma(ar[t * 64], h[KT - 1], acc[t]);
         }
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (BIAS_LAST) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] += *reinterpret_cast<const V4*>(binit + (size_t)t * 16 * sizeof(T));

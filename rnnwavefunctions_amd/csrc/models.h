@@ -49,6 +49,16 @@ int mdrnn_tfim_eloc(rnnwf_handle* h, const int32_t* samples, int64_t ns, const d
 int mdrnn_vmc_step(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t step, int64_t offset, const double* couplings,
                    int32_t* out_samples, double* out_eloc, double* moments);
 
+// ---- bf16x3 engine (split.hip; compiled without SLP packing) -----------------------------------------
+struct PrnnArgs;
+struct CrnnArgs;
+int prnn_split_flip(rnnwf_handle* h, const PrnnArgs& a);
+double prnn_split_flops_per_step(rnnwf_handle* h);      // MFMA flops issued per 32-chain wave-step
+int prnn_split_pack(rnnwf_handle* h, std::vector<char>& simg);
+int crnn_split_swap(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles);
+double crnn_split_flops_per_step(rnnwf_handle* h);
+int crnn_split_pack(rnnwf_handle* h, std::vector<char>& simg);
+
 // ---- gradient (grad.hip) ---------------------------------------------------------------------------
 int mdrnn_vmc_gradient(rnnwf_handle* h, double mean_energy, double norm);
 void grad_invalidate(rnnwf_handle* h);

@@ -8,8 +8,6 @@
 #include "ml_kernels.h"
 #include "models.h"
 #include "pack.h"
-#include "pack_split.h"
-#include "split_kernels.h"
 
 using namespace rnnwf;
 
@@ -138,90 +136,6 @@ struct MLaunchL {
         }                                                                                   \
     } while (0)
 
-// ---- bf16x3 engine for the flip pass (f32 models, num_units <= 68) ---------------------------------------
-template <int NF32, int RJ, int WAVES, int MODE>
-struct SLaunch {
-    using L = SplitLayout<NF32, RJ, 1, MODE>;
-    static int flip(rnnwf_handle* h, const PrnnArgs& a, int kt16) {
-        const void* fn = (const void*)prnn_flip_split_kernel<NF32, RJ, WAVES, MODE>;
-        int bpc = 0;
-        if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, L::BYTES, &bpc)) return rc;
-        const int64_t ntiles = (int64_t)(a.N - 1) * ((a.ns + 31) / 32);
-        const int64_t need = (ntiles + WAVES - 1) / WAVES;
-        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
-        TimedLaunch tl(h, 1);
-        prnn_flip_split_kernel<NF32, RJ, WAVES, MODE><<<grid, WAVES * 64, L::BYTES, h->stream>>>(a, h->wsplit.p, kt16);
-        RNNWF_HIP(h, hipGetLastError());
-        return 0;
-    }
-    // ping-pong form (8 waves per workgroup, two per SIMD, alternating MFMA / VALU segments): K-packed layouts only
-    static int flip_pp(rnnwf_handle* h, const PrnnArgs& a, int kt16) {
-        if constexpr (MODE == 2) {
-            const void* fn = (const void*)prnn_flip_pp_kernel<NF32, RJ>;
-            if (L::HP > 4 * kt16) return h->fail(RNNWF_ERR_INVALID, "bf16x3 layout wider than the checkpoint rows (%d > %d)", L::HP, 4 * kt16);
-            int bpc = 0;
-            if (int rc = rnnwf::blocks_per_cu(h, fn, 512, L::BYTES, &bpc)) return rc;
-            const int64_t ntiles = (int64_t)(a.N - 1) * ((a.ns + 31) / 32);
-            const int64_t need = (ntiles + 7) / 8;
-            const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
-#ifdef RNNWF_DIAGNOSTICS
-            if (getenv("RNNWF_STAMPS")) {     // in-kernel cycle stamps, median over waves -> stderr (tools/stamps.py)
-                PrnnArgs b = a;
-                const size_t nwv = (size_t)grid * 8;
-                RNNWF_HIP(h, hipMalloc((void**)&b.stamps, nwv * 128));
-                RNNWF_HIP(h, hipMemsetAsync(b.stamps, 0, nwv * 128, h->stream));
-                prnn_flip_pp_kernel<NF32, RJ><<<grid, 512, L::BYTES, h->stream>>>(b, h->wsplit.p, kt16);
-                RNNWF_HIP(h, hipStreamSynchronize(h->stream));
-                std::vector<unsigned long long> st(nwv * 16);
-                RNNWF_HIP(h, hipMemcpy(st.data(), b.stamps, nwv * 128, hipMemcpyDeviceToHost));
-                RNNWF_HIP(h, hipFree(b.stamps));
-                const char* names[10] = {"mfma_seg", "barrier_after_mfma", "valu_seg_split_part", "barrier_after_valu", "tile_switch", "total_cycles",
-                                         "realtime_ticks_100MHz", "iterations", "valu_seg_gates", "valu_seg_head_logsoftmax"};
-                fprintf(stderr, "RNNWF_STAMPS grid=%u waves=%zu:", grid, nwv);
-                for (int k = 0; k < 10; ++k) {
-                    std::vector<unsigned long long> v(nwv);
-                    for (size_t w = 0; w < nwv; ++w) v[w] = st[w * 16 + k];
-                    std::sort(v.begin(), v.end());
-                    fprintf(stderr, " %s med %llu min %llu max %llu;", names[k], v[nwv / 2], v[0], v[nwv - 1]);
-                }
-                fprintf(stderr, "\n");
-                return 0;
-            }
-#endif
-            TimedLaunch tl(h, 1);
-            prnn_flip_pp_kernel<NF32, RJ><<<grid, 512, L::BYTES, h->stream>>>(a, h->wsplit.p, kt16);
-            RNNWF_HIP(h, hipGetLastError());
-            return 0;
-        } else {
-            return flip(h, a, kt16);
-        }
-    }
-    static std::vector<char> pack(const rnnwf_handle* h) { return pack_split_image<NF32, RJ, 1, MODE>(h); }
-    static double mfma_flops_per_step() { return (double)L::NT * L::KS * 32768.0; }   // per 32-chain wave-step
-};
-
-#define SPLIT_DISPATCH(h, EXPR)                                      \
-    do {                                                             \
-        switch ((h)->NFULL) {                                        \
-            case 1: { using K = SLaunch<0, 10, 4, 1>; EXPR; }        \
-            case 2: { using K = SLaunch<1, 2, 4, 1>; EXPR; }         \
-            case 3: if ((h)->H <= 50) { using K = SLaunch<1, 9, 4, 2>; EXPR; } \
-                    else { using K = SLaunch<1, 10, 4, 0>; EXPR; }   \
-            case 4: { using K = SLaunch<2, 2, 4, 0>; EXPR; }         \
-        }                                                            \
-    } while (0)
-
-int launch_flip_split(rnnwf_handle* h, const PrnnArgs& a) {
-    const int kt16 = 4 * h->NFULL + 1;
-    if (h->knobs.engine == 3) { SPLIT_DISPATCH(h, return K::flip(h, a, kt16)); }      // RNNWF_ENGINE=bf16x3-serial: A/B only
-    else { SPLIT_DISPATCH(h, return K::flip_pp(h, a, kt16)); }
-    return h->fail(RNNWF_ERR_INVALID, "no bf16x3 kernel for NFULL=%d", h->NFULL);
-}
-double split_mfma_flops_per_step(rnnwf_handle* h) {
-    SPLIT_DISPATCH(h, return K::mfma_flops_per_step());
-    return 0;
-}
-
 int launch_base(rnnwf_handle* h, const PrnnArgs& a) {
     PRNN_DISPATCH(h, return K::base(h, a));
     return h->fail(RNNWF_ERR_INVALID, "no pRNN kernel for NFULL=%d f64=%d", h->NFULL, (int)h->f64);
@@ -297,8 +211,8 @@ int eloc_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
         a.sampling = 0;
         a.ablate |= h->knobs.ablate & 15;   // 0 unless a -DRNNWF_DIAGNOSTICS build read RNNWF_ABLATE
         if (use_split(h, ns)) {
-            if (int rc = launch_flip_split(h, a)) return rc;
-            h->work[1] += (double)((ns + 31) / 32) * N * (N - 1) / 2.0 * split_mfma_flops_per_step(h);
+            if (int rc = prnn_split_flip(h, a)) return rc;
+            h->work[1] += (double)((ns + 31) / 32) * N * (N - 1) / 2.0 * prnn_split_flops_per_step(h);
         } else {
             if (int rc = launch_flip(h, a)) return rc;
             h->work[1] += (double)nsb * N * (N - 1) / 2.0 * mfma_flops_per_step(h);
@@ -322,8 +236,8 @@ int eloc_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
         if (Bx != 0.0 && N > 1) {
             b.ntiles = (int64_t)(N - 1) * nsb;
             if (use_split(h, ns)) {
-                if (int rc = launch_flip_split(h, b)) return rc;
-                h->work[1] += (double)((ns + 31) / 32) * N * (N - 1) / 2.0 * split_mfma_flops_per_step(h);
+                if (int rc = prnn_split_flip(h, b)) return rc;
+                h->work[1] += (double)((ns + 31) / 32) * N * (N - 1) / 2.0 * prnn_split_flops_per_step(h);
             } else {
                 if (int rc = launch_flip(h, b)) return rc;
                 h->work[1] += (double)nsb * N * (N - 1) / 2.0 * mfma_flops_per_step(h);
@@ -352,7 +266,7 @@ int rnnwf::prnn_pack_image(rnnwf_handle* h, std::vector<char>& img) {
     h->engine_forced = h->knobs.engine >= 2;
     if (h->engine_split) {
         std::vector<char> simg;
-        SPLIT_DISPATCH(h, { simg = K::pack(h); break; });
+        if (int rc = prnn_split_pack(h, simg)) return rc;
         if (int rc = ensure(h, h->wsplit, simg.size())) return rc;
         RNNWF_HIP(h, hipStreamSynchronize(h->stream));
         RNNWF_HIP(h, hipMemcpy(h->wsplit.p, simg.data(), simg.size(), hipMemcpyHostToDevice));

@@ -1,0 +1,175 @@
+// split.hip - host side of the bf16x3 engine (split_core.h): the flip pass of the positive RNN and the swap pass of the
+// complex RNN on the bf16 matrix core, incl. their ping-pong kernels.  A translation unit of its own because it is
+// compiled with -fno-slp-vectorize (build.py): packed-f32 instructions stall behind bf16 MFMAs - their own wave's and the
+// SIMD partner's - whereas the f32-input-MFMA kernels of prnn.hip / crnn.hip WANT the packed forms (their MFMA and VALU
+// serialise anyway, so half the VALU instructions is a straight gain: config 5 0.79 -> 0.86 of the f32 pipe).
+#include <algorithm>
+#include <cstdlib>
+
+#include "crnn_split_kernels.h"
+#include "models.h"
+#include "pack.h"
+#include "pack_split.h"
+#include "split_kernels.h"
+
+using namespace rnnwf;
+
+namespace {
+
+// ---- bf16x3 engine for the flip pass (f32 models, num_units <= 68) ---------------------------------------
+template <int NF32, int RJ, int WAVES, int MODE>
+struct SLaunch {
+    using L = SplitLayout<NF32, RJ, 1, MODE>;
+    static int flip(rnnwf_handle* h, const PrnnArgs& a, int kt16) {
+        const void* fn = (const void*)prnn_flip_split_kernel<NF32, RJ, WAVES, MODE>;
+        int bpc = 0;
+        if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, L::BYTES, &bpc)) return rc;
+        const int64_t ntiles = (int64_t)(a.N - 1) * ((a.ns + 31) / 32);
+        const int64_t need = (ntiles + WAVES - 1) / WAVES;
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
+        TimedLaunch tl(h, 1);
+        prnn_flip_split_kernel<NF32, RJ, WAVES, MODE><<<grid, WAVES * 64, L::BYTES, h->stream>>>(a, h->wsplit.p, kt16);
+        RNNWF_HIP(h, hipGetLastError());
+        return 0;
+    }
+    // ping-pong form (8 waves per workgroup, two per SIMD, alternating MFMA / VALU segments): K-packed layouts only
+    static int flip_pp(rnnwf_handle* h, const PrnnArgs& a, int kt16) {
+        if constexpr (MODE == 2) {
+            const void* fn = (const void*)prnn_flip_pp_kernel<NF32, RJ>;
+            if (L::HP > 4 * kt16) return h->fail(RNNWF_ERR_INVALID, "bf16x3 layout wider than the checkpoint rows (%d > %d)", L::HP, 4 * kt16);
+            int bpc = 0;
+            if (int rc = rnnwf::blocks_per_cu(h, fn, 512, L::BYTES, &bpc)) return rc;
+            const int64_t ntiles = (int64_t)(a.N - 1) * ((a.ns + 31) / 32);
+            const int64_t need = (ntiles + 7) / 8;
+            const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
+#ifdef RNNWF_DIAGNOSTICS
+            if (getenv("RNNWF_STAMPS")) {     // in-kernel cycle stamps, median over waves -> stderr (tools/stamps.py)
+                PrnnArgs b = a;
+                const size_t nwv = (size_t)grid * 8;
+                RNNWF_HIP(h, hipMalloc((void**)&b.stamps, nwv * 128));
+                RNNWF_HIP(h, hipMemsetAsync(b.stamps, 0, nwv * 128, h->stream));
+                prnn_flip_pp_kernel<NF32, RJ><<<grid, 512, L::BYTES, h->stream>>>(b, h->wsplit.p, kt16);
+                RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+                std::vector<unsigned long long> st(nwv * 16);
+                RNNWF_HIP(h, hipMemcpy(st.data(), b.stamps, nwv * 128, hipMemcpyDeviceToHost));
+                RNNWF_HIP(h, hipFree(b.stamps));
+                const char* names[10] = {"mfma_seg", "barrier_after_mfma", "valu_seg_split_part", "barrier_after_valu", "tile_switch", "total_cycles",
+                                         "realtime_ticks_100MHz", "iterations", "valu_seg_gates", "valu_seg_head_logsoftmax"};
+                fprintf(stderr, "RNNWF_STAMPS grid=%u waves=%zu:", grid, nwv);
+                for (int k = 0; k < 10; ++k) {
+                    std::vector<unsigned long long> v(nwv);
+                    for (size_t w = 0; w < nwv; ++w) v[w] = st[w * 16 + k];
+                    std::sort(v.begin(), v.end());
+                    fprintf(stderr, " %s med %llu min %llu max %llu;", names[k], v[nwv / 2], v[0], v[nwv - 1]);
+                }
+                fprintf(stderr, "\n");
+                return 0;
+            }
+#endif
+            TimedLaunch tl(h, 1);
+            prnn_flip_pp_kernel<NF32, RJ><<<grid, 512, L::BYTES, h->stream>>>(a, h->wsplit.p, kt16);
+            RNNWF_HIP(h, hipGetLastError());
+            return 0;
+        } else {
+            return flip(h, a, kt16);
+        }
+    }
+    static std::vector<char> pack(const rnnwf_handle* h) { return pack_split_image<NF32, RJ, 1, MODE>(h); }
+    static double mfma_flops_per_step() { return (double)L::NT * L::KS * 32768.0; }   // per 32-chain wave-step
+};
+
+#define SPLIT_DISPATCH(h, EXPR)                                      \
+    do {                                                             \
+        switch ((h)->NFULL) {                                        \
+            case 1: { using K = SLaunch<0, 10, 4, 1>; EXPR; }        \
+            case 2: { using K = SLaunch<1, 2, 4, 1>; EXPR; }         \
+            case 3: if ((h)->H <= 50) { using K = SLaunch<1, 9, 4, 2>; EXPR; } \
+                    else { using K = SLaunch<1, 10, 4, 0>; EXPR; }   \
+            case 4: { using K = SLaunch<2, 2, 4, 0>; EXPR; }         \
+        }                                                            \
+    } while (0)
+
+
+// ---- bf16x3 engine for the swap pass (num_units <= 68) ---------------------------------------------------
+template <int NF32, int RJ, int WAVES, int MODE>
+struct CSLaunch {
+    using L = SplitLayout<NF32, RJ, 3, MODE>;
+    static int swap(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles, int kt16) {
+        const void* fn = (const void*)crnn_swap_split_kernel<NF32, RJ, WAVES, MODE>;
+        int bpc = 0;
+        if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, L::BYTES, &bpc)) return rc;
+        const int64_t need = (max_tiles + WAVES - 1) / WAVES;
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
+        TimedLaunch tl(h, 1);
+        crnn_swap_split_kernel<NF32, RJ, WAVES, MODE><<<grid, WAVES * 64, L::BYTES, h->stream>>>(a, h->wsplit.p, kt16);
+        RNNWF_HIP(h, hipGetLastError());
+        return 0;
+    }
+    // ping-pong form (8 waves per workgroup, alternating MFMA / VALU segments): K-packed layout MODE 2 only
+    static int swap_pp(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles, int kt16) {
+        if constexpr (MODE == 2) {
+            const void* fn = (const void*)crnn_swap_pp_kernel<NF32, RJ>;
+            if (L::HP > 4 * kt16) return h->fail(RNNWF_ERR_INVALID, "bf16x3 layout wider than the checkpoint rows (%d > %d)", L::HP, 4 * kt16);
+            int bpc = 0;
+            if (int rc = rnnwf::blocks_per_cu(h, fn, 512, L::BYTES, &bpc)) return rc;
+            const int64_t need = (max_tiles + 7) / 8;
+            const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
+            TimedLaunch tl(h, 1);
+            crnn_swap_pp_kernel<NF32, RJ><<<grid, 512, L::BYTES, h->stream>>>(a, h->wsplit.p, kt16);
+            RNNWF_HIP(h, hipGetLastError());
+            return 0;
+        } else {
+            return swap(h, a, max_tiles, kt16);
+        }
+    }
+    static std::vector<char> pack(const rnnwf_handle* h) { return pack_split_image<NF32, RJ, 3, MODE>(h); }
+    static double mfma_flops_per_step() { return (double)L::NT * L::KS * 32768.0; }
+};
+
+#define CSPLIT_DISPATCH(h, EXPR)                                     \
+    do {                                                             \
+        switch ((h)->NFULL) {                                        \
+            case 1: { using K = CSLaunch<0, 10, 4, 1>; EXPR; }       \
+            case 2: { using K = CSLaunch<1, 2, 4, 1>; EXPR; }        \
+            case 3: if ((h)->H <= 50) { using K = CSLaunch<1, 9, 4, 2>; EXPR; } \
+                    else { using K = CSLaunch<1, 10, 4, 0>; EXPR; }  \
+            case 4: { using K = CSLaunch<2, 2, 4, 0>; EXPR; }        \
+        }                                                            \
+    } while (0)
+
+
+}  // namespace
+
+int rnnwf::prnn_split_flip(rnnwf_handle* h, const PrnnArgs& a) {
+    const int kt16 = 4 * h->NFULL + 1;
+    if (h->knobs.engine == 3) { SPLIT_DISPATCH(h, return K::flip(h, a, kt16)); }      // RNNWF_ENGINE=bf16x3-serial: A/B only
+    else { SPLIT_DISPATCH(h, return K::flip_pp(h, a, kt16)); }
+    return h->fail(RNNWF_ERR_INVALID, "no bf16x3 kernel for NFULL=%d", h->NFULL);
+}
+double rnnwf::prnn_split_flops_per_step(rnnwf_handle* h) {
+    SPLIT_DISPATCH(h, return K::mfma_flops_per_step());
+    return 0;
+}
+
+
+int rnnwf::prnn_split_pack(rnnwf_handle* h, std::vector<char>& simg) {
+    SPLIT_DISPATCH(h, { simg = K::pack(h); return 0; });
+    return h->fail(RNNWF_ERR_INVALID, "no bf16x3 layout for NFULL=%d", h->NFULL);
+}
+
+int rnnwf::crnn_split_swap(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles) {
+    const int kt16 = 4 * h->NFULL + 1;
+    if (h->knobs.engine == 3) { CSPLIT_DISPATCH(h, return K::swap(h, a, max_tiles, kt16)); }      // RNNWF_ENGINE=bf16x3-serial: A/B only
+    else { CSPLIT_DISPATCH(h, return K::swap_pp(h, a, max_tiles, kt16)); }
+    return h->fail(RNNWF_ERR_INVALID, "no bf16x3 cRNN kernel for NFULL=%d", h->NFULL);
+}
+double rnnwf::crnn_split_flops_per_step(rnnwf_handle* h) {
+    CSPLIT_DISPATCH(h, return K::mfma_flops_per_step());
+    return 0;
+}
+
+
+int rnnwf::crnn_split_pack(rnnwf_handle* h, std::vector<char>& simg) {
+    CSPLIT_DISPATCH(h, { simg = K::pack(h); return 0; });
+    return h->fail(RNNWF_ERR_INVALID, "no bf16x3 layout for NFULL=%d", h->NFULL);
+}

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/kernel_resources.sh prnn   -> compact VGPR/AGPR/scratch/occupancy table for one TU
 f=${1:-prnn}
-/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wno-unused-value -ffp-contract=fast -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form \
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wno-unused-value -ffp-contract=fast $([ "$f" = split ] && echo -fno-slp-vectorize) -mllvm -amdgpu-mfma-vgpr-form \
   -Rpass-analysis=kernel-resource-usage -c rnnwavefunctions_amd/csrc/$f.hip -o /tmp/$f.o 2>&1 |
 python3 -c '
 import sys,re,subprocess

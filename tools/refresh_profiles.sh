@@ -17,7 +17,7 @@ for w in cfg2 cfg3; do
   RNNWF_ENGINE=f32 timeout -k 10 200 python bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline --no-alt-engine > $out/${tag}_bench_${w}_engine_f32.json 2>/dev/null || exit 1
 done
 cd /tmp && export TMPDIR=/tmp
-for w in cfg2 cfg3 cfg4; do
+for w in cfg1 cfg2 cfg3 cfg4 cfg5; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof_$w -- python3 $R/bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline --no-alt-engine > $out/${tag}_prof_$w.log 2>&1 || { echo "rocprof $w failed"; exit 1; }
   cp $out/${tag}_prof_$w/*/*kernel_stats.csv $out/${tag}_kernel_stats_$w.csv
   echo "stats $w done"
@@ -27,6 +27,25 @@ for w in cfg2 cfg4; do
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/${tag}_pmc_${w}_$c -- python3 $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-alt-engine > $out/${tag}_pmc_${w}_$c.log 2>&1 || { echo "pmc $w $c failed"; exit 1; }
   done
 done
+# SQ counters of the dominant kernels at config 2 (one pass per counter set; no trace domains besides --kernel-trace)
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" "SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES"; do
+  t=$(echo $set | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/${tag}_sq_cfg2/$t -- python3 $R/bench.py --workload cfg2 --steps 2 --warmup 1 --no-cpu-baseline --no-alt-engine > $out/${tag}_sq_cfg2_$t.log 2>&1 || echo "sq set failed: $set"
+done
+python3 - <<PY
+import csv, glob, collections
+root = "$out/${tag}_sq_cfg2"
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(lambda: collections.defaultdict(int))
+for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0][:70]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
+with open("$out/${tag}_sq_cfg2_summary.txt", "w") as o:
+    for k in agg:
+        o.write(k + "\n")
+        for c in sorted(agg[k]):
+            o.write("    %-28s per launch %.6g  (launches %d)\n" % (c, agg[k][c] / cnt[k][c], cnt[k][c]))
+PY
 python3 - <<PY
 import csv, glob, json, collections
 out = "$out"; tag = "$tag"
@@ -43,5 +62,21 @@ for w in res:
     for k, d in res[w].items():
         if "flip" in k or "base" in k:
             print(w, k, d)
+# profiles/pmc_traffic.json: what bench.py replays as roofline.traffic (labelled with this build)
+def pick(w, sub):
+    for k, d in res.get(w, {}).items():
+        if sub in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            return k, d
+    return None, None
+traffic = {}
+for w, sub in (("cfg2", "flip"), ("cfg4", "mdrnn_flip")):
+    k, d = pick(w, sub)
+    if k:
+        fetch, write = d["FETCH_SIZE"] * 1024.0, d["WRITE_SIZE"] * 1024.0       # counter unit KiB
+        traffic[w] = {"kernel": k, "fetch_bytes_raw": fetch, "fetch_bytes_x2": 2 * fetch, "write_bytes": write,
+                      "hbm_bytes_per_launch": 2 * fetch + write, "build": tag,
+                      "source": "gpurun_out/%s_pmc_%s_{FETCH,WRITE}_SIZE (rocprofv3 --pmc, separate passes, tools/refresh_profiles.sh); "
+                                "FETCH_SIZE doubled as the gfx950 guide prescribes" % (tag, w)}
+json.dump(traffic, open("%s/%s_pmc_traffic.json" % (out, tag), "w"), indent=1)
 PY
 echo refresh done
