@@ -246,11 +246,12 @@ def main():
             box = [w.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
             w.comm_init(box[0], rank, world)
+            w.comm_reduce_in_step(True)       # the step's moments come back already summed over the ranks
 
-    def reduce_moments(w, m):                 # ONE all-reduce: (sum E, sum E^2, n, sum Im E)
-        if world == 1:
+    def reduce_moments(w, m):                 # ONE all-reduce per step: (sum E, sum E^2, n, sum Im E)
+        if world == 1 or not gloo_reduce:     # RCCL: done inside rnnwf_vmc_step, on the stream (comm_reduce_in_step)
             return m
-        return gloo_reduce(m) if gloo_reduce else w.allreduce_moments(m)
+        return gloo_reduce(m)
 
     def barrier(w):
         w.synchronize()

@@ -54,6 +54,7 @@ PROTOTYPES = {
     "rnnwf_comm_init": (C.c_int, [_P, _P, _I32, _I32]),
     "rnnwf_allreduce_moments": (C.c_int, [_P, _F64P, _I32]),
     "rnnwf_comm_info": (C.c_int, [_P, _P, _P, _P]),
+    "rnnwf_comm_reduce_in_step": (C.c_int, [_P, _I32]),
     "rnnwf_comm_destroy": (C.c_int, [_P]),
     "rnnwf_timing_enable": (C.c_int, [_P, _I32]),
     "rnnwf_timing_reset": (C.c_int, [_P]),
@@ -281,6 +282,10 @@ class NativeWavefunction:
 
     def comm_init(self, unique_id, rank, nranks):
         self._check(self.lib.rnnwf_comm_init(self.h, C.c_char_p(unique_id), rank, nranks))
+
+    def comm_reduce_in_step(self, on=True):
+        """vmc_step returns the moments summed over all ranks (one in-stream RCCL all-reduce, one host sync per step)."""
+        self._check(self.lib.rnnwf_comm_reduce_in_step(self.h, int(on)))
 
     def comm_info(self):
         """What the RCCL communicator itself reports (ncclCommCount / ncclCommUserRank) plus the handle's device."""

@@ -100,6 +100,21 @@ extern "C" int rnnwf_comm_info(rnnwf_handle* h, int32_t* nranks, int32_t* rank, 
     return RNNWF_OK;
 }
 
+// in-stream sum over the ranks of `count` doubles already on the device (no host round trip, no synchronisation)
+int rnnwf::comm_allreduce_device(rnnwf_handle* h, void* dev, size_t count) {
+    if (!h->comm) return 0;
+    const int rc = g_rccl.all_reduce(dev, dev, count, kNcclFloat64, kNcclSum, h->comm, h->stream);
+    if (rc != 0) return h->fail(RNNWF_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.error_string ? g_rccl.error_string(rc) : "?");
+    return 0;
+}
+
+extern "C" int rnnwf_comm_reduce_in_step(rnnwf_handle* h, int32_t on) {
+    if (!h) return RNNWF_ERR_INVALID;
+    if (on && !h->comm) return h->fail(RNNWF_ERR_STATE, "rnnwf_comm_reduce_in_step: communicator not initialised");
+    h->reduce_in_step = on != 0;
+    return RNNWF_OK;
+}
+
 extern "C" int rnnwf_allreduce_moments(rnnwf_handle* h, double* moments, int32_t count) {
     if (!h || !moments || count < 1 || count > 64) return RNNWF_ERR_INVALID;
     if (!h->comm) {
@@ -148,5 +163,6 @@ extern "C" int rnnwf_comm_destroy(rnnwf_handle* h) {
     h->comm = nullptr;
     h->nranks = 1;
     h->rank = 0;
+    h->reduce_in_step = false;
     return RNNWF_OK;
 }

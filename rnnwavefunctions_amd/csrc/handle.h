@@ -88,6 +88,8 @@ struct rnnwf_handle {
 
     void* comm = nullptr;  // ncclComm_t
     int rank = 0, nranks = 1;
+    bool reduce_in_step = false;   // rnnwf_vmc_step returns the moments summed over all ranks (one RCCL all-reduce on the
+                                   // stream, before the single host synchronisation of the step)
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];

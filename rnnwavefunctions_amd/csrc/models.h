@@ -65,6 +65,8 @@ void grad_invalidate(rnnwf_handle* h);
 // bytes of per-site hidden states one pass may hold; RNNWF_STATE_BUDGET_MB (read at rnnwf_create) overrides the
 // default (tests use it to drive the multi-pass path at small sizes)
 size_t state_budget_bytes(const rnnwf_handle* h, size_t dflt);
+// RCCL sum of device-resident doubles on the handle's stream (comm.hip); no-op without a communicator
+int comm_allreduce_device(rnnwf_handle* h, void* dev, size_t count);
 // h->coupl <- n doubles; skipped when they are what the device already holds
 int upload_couplings(rnnwf_handle* h, const double* src, size_t n);
 

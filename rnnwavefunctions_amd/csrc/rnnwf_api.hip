@@ -376,6 +376,8 @@ int rnnwf::run_moments(rnnwf_handle* h, const void* eloc_dev, int64_t ns, bool c
             moments_kernel<double><<<1, 1024, 0, h->stream>>>((const double*)eloc_dev, ns, 1, 0, (double*)h->moments.p);
     }
     RNNWF_HIP(h, hipGetLastError());
+    if (h->reduce_in_step)
+        if (int rc = comm_allreduce_device(h, h->moments.p, 4)) return rc;
     if (moments_host) {
         RNNWF_HIP(h, hipMemcpyAsync(h->pinned, h->moments.p, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         RNNWF_HIP(h, hipStreamSynchronize(h->stream));

@@ -95,7 +95,11 @@ class ShardComm:
 
     @classmethod
     def from_rccl(cls, native, rank, world):
-        return cls(rank, world, lambda a: native.allreduce_moments(np.ascontiguousarray(a, dtype=np.float64)), native=native)
+        """RCCL through the handle's communicator.  The moments of a `vmc_step` are summed over the ranks inside the step
+        (rnnwf_comm_reduce_in_step: in-stream all-reduce before the step's one host synchronisation), so `allreduce` of the
+        moments is the identity here; gradients go through rnnwf_allreduce_grads."""
+        native.comm_reduce_in_step(True)
+        return cls(rank, world, lambda a: np.asarray(a, dtype=np.float64), native=native)
 
     def allreduce(self, a):
         if self.world == 1 or self._allreduce is None:

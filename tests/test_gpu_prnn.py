@@ -225,6 +225,12 @@ def test_rccl_all_reduce_single_rank():
     wf.comm_init(uid, 0, 1)
     m = np.array([1.5, -2.0, 64.0, 0.25])
     assert np.array_equal(wf.allreduce_moments(m), m)
+    assert wf.comm_info() == {"nranks": 1, "rank": 0, "device": 0}        # ncclCommCount / ncclCommUserRank
+    # the in-step form: the all-reduce runs on the stream inside rnnwf_vmc_step
+    c = np.append(np.ones(8), 1.0)
+    m0 = wf.vmc_step(64, seed=3, step=0, couplings=c)["moments"]
+    wf.comm_reduce_in_step(True)
+    assert np.array_equal(wf.vmc_step(64, seed=3, step=0, couplings=c)["moments"], m0)
     with pytest.raises(ValueError):
         wf.comm_init(uid, 3, 2)
 
@@ -242,6 +248,9 @@ def _rccl_rank(rank, world, port, out):
     ns = 300
     m = wf.vmc_step(ns, seed=7, step=0, couplings=np.append(np.ones(16), 1.0), sample_offset=rank * ns)["moments"]
     g = wf.allreduce_moments(m)
+    wf.comm_reduce_in_step(True)          # the same sum, taken on the stream inside the step
+    g2 = wf.vmc_step(ns, seed=7, step=0, couplings=np.append(np.ones(16), 1.0), sample_offset=rank * ns)["moments"]
+    assert np.allclose(g2, g, rtol=1e-14)
     if rank == 0:
         np.save(out, np.concatenate([g, [info["nranks"], info["rank"], info["device"], w]]))
     import torch.distributed as dist
