@@ -177,6 +177,11 @@ int rnnwf_vmc_step(rnnwf_handle* h, int64_t numsamples, uint64_t seed, uint64_t 
  * rnnwf_get_grad     <- the gradient of one TF variable (same names and shapes as rnnwf_set_param).
  * rnnwf_allreduce_grads: one RCCL all-reduce (sum) over all gradient arrays of the handle.             */
 int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double mean_energy_im, double norm);
+/* rnnwf_load_batch: the batch rnnwf_vmc_gradient works on, supplied by the caller instead of drawn by rnnwf_vmc_step -
+ * what `sess.run(optstep, feed_dict={Eloc: local_energies, samp: samples, ...})` feeds (TrainingRNN_1DTFIM.py:221,
+ * TrainingRNN_J1J2.py:286).  samples: int32 (ns, N) as for rnnwf_log_prob; eloc: float64[ns] (TFIM models) or
+ * complex64[ns] as float pairs (complex RNN).  Runs the teacher-forced pass that stores the hidden-state checkpoints.  */
+int rnnwf_load_batch(rnnwf_handle* h, const int32_t* samples, int64_t ns, const void* eloc);
 int rnnwf_get_grad(rnnwf_handle* h, const char* tf_name, void* data, int64_t count, int32_t dtype);
 int rnnwf_allreduce_grads(rnnwf_handle* h);
 

@@ -48,6 +48,7 @@ PROTOTYPES = {
     "rnnwf_j1j2_eloc": (C.c_int, [_P, _I32P, _I64, _F64P, _F64P, _F64P, _I32, _I32, _F32P, C.POINTER(_I64)]),
     "rnnwf_vmc_step": (C.c_int, [_P, _I64, _U64, _U64, _I64, _F64P, _I64, _I32P, _P, _F64P]),
     "rnnwf_vmc_gradient": (C.c_int, [_P, _F64, _F64, _F64]),
+    "rnnwf_load_batch": (C.c_int, [_P, _I32P, _I64, _P]),
     "rnnwf_get_grad": (C.c_int, [_P, C.c_char_p, _P, _I64, _I32]),
     "rnnwf_allreduce_grads": (C.c_int, [_P]),
     "rnnwf_comm_unique_id": (C.c_int, [_P]),
@@ -256,6 +257,18 @@ class NativeWavefunction:
         if want_eloc:
             out["eloc"] = el.view(np.complex64)[:, 0] if self.model == MODEL_CRNN_U1 else el
         return out
+
+    def load_batch(self, samples, eloc):
+        """Make a caller-supplied batch (samples + their local energies) the one vmc_gradient works on."""
+        s = np.ascontiguousarray(samples, dtype=np.int32)
+        ns = s.shape[0]
+        if self.model == MODEL_CRNN_U1:
+            e = np.ascontiguousarray(np.asarray(eloc, dtype=np.complex64))
+        else:
+            e = np.ascontiguousarray(np.asarray(eloc, dtype=np.float64))
+        if e.shape != (ns,):
+            raise ValueError("load_batch: %d samples but local energies of shape %s" % (ns, e.shape))
+        self._check(self.lib.rnnwf_load_batch(self.h, s.ctypes.data_as(_I32P), ns, e.ctypes.data_as(_P)))
 
     # -- gradient of the VMC cost -----------------------------------------------------------------
     def vmc_gradient(self, mean_energy, norm, shapes, allreduce=False):

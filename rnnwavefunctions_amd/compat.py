@@ -38,7 +38,67 @@ def get_default_graph():
     return _graph_stack[-1] if _graph_stack else None
 
 
-class Placeholder:
+class Sym:
+    """Just enough symbolic arithmetic to write the reference's VMC cost with these objects
+    (`tf.reduce_mean(tf.multiply(log_probs_, Eloc)) - tf.reduce_mean(Eloc) * tf.reduce_mean(log_probs_)`,
+    TrainingRNN_1DTFIM.py:156; the complex form at TrainingRNN_J1J2.py:197).  Nothing is evaluated symbolically: the tree
+    is only RECOGNISED by `AdamOptimizer.compute_gradients`, whose gradient is rnnwf_vmc_gradient."""
+
+    def __mul__(self, other):
+        return Expr("mul", self, other)
+
+    __rmul__ = __mul__
+
+    def __sub__(self, other):
+        return Expr("sub", self, other)
+
+    def __rsub__(self, other):
+        return Expr("sub", other, self)
+
+
+class Expr(Sym):
+    def __init__(self, op, *args):
+        self.op, self.args = op, args
+
+
+def _sig(e):
+    """Canonical string of a cost tree: L = log-probability / log-amplitude op, E = fed local energies."""
+    if isinstance(e, Expr):
+        if e.op == "stop":
+            return _sig(e.args[0])
+        parts = [_sig(a) for a in e.args]
+        if e.op == "mul":
+            parts.sort()
+        return "%s(%s)" % (e.op, ",".join(parts))
+    if isinstance(e, EvalOp):
+        return "L"
+    if isinstance(e, Placeholder):
+        return "E"
+    if isinstance(e, (int, float)):
+        return repr(float(e)) if float(e) != int(e) else str(int(e))
+    raise TypeError("cannot take %r into a cost expression" % (e,))
+
+
+def _leaves(e, kind, out):
+    if isinstance(e, Expr):
+        for a in e.args:
+            _leaves(a, kind, out)
+    elif isinstance(e, kind) and e not in out:
+        out.append(e)
+    return out
+
+
+reduce_mean = lambda x, *a, **k: Expr("mean", x)                 # noqa: E731
+multiply = lambda a, b, *r, **k: Expr("mul", a, b)               # noqa: E731
+stop_gradient = lambda x, *a, **k: Expr("stop", x)               # noqa: E731
+conj = lambda x, *a, **k: Expr("conj", x)                        # noqa: E731
+real = lambda x, *a, **k: Expr("real", x)                        # noqa: E731
+
+_COST_REAL = "sub(mean(mul(E,L)),mul(mean(E),mean(L)))"
+_COST_COMPLEX = "mul(2,real(sub(mean(mul(E,conj(L))),mul(conj(mean(L)),mean(E)))))"
+
+
+class Placeholder(Sym):
     """tf.placeholder stand-in (TrainingRNN_1DTFIM.py:192)."""
 
     def __init__(self, dtype=np.int32, shape=None, name=None):
@@ -54,7 +114,7 @@ def placeholder(dtype=np.int32, shape=None, name=None):
     return Placeholder(dtype, shape, name)
 
 
-class Op:
+class Op(Sym):
     """Lazy result of a wave-function method; evaluated by Session.run or .eval()."""
 
     def __init__(self, wf):
@@ -250,20 +310,86 @@ class _LearningRate:
         return float(lr) * self.decay_rate ** (np.floor(e) if self.staircase else e)
 
 
+class _CostPlan:
+    def __init__(self, wf, samples_ph, eloc_ph, is_complex):
+        self.wf, self.samples_ph, self.eloc_ph, self.is_complex = wf, samples_ph, eloc_ph, is_complex
+
+
+class _Gradient:
+    def __init__(self, plan, var):
+        self.plan, self.var = plan, var
+
+
+class _OptStep(Op):
+    """One training step of the reference's loop: `sess.run(optstep, feed_dict=...)` (TrainingRNN_1DTFIM.py:221)."""
+
+    def __init__(self, optimizer, plan, global_step):
+        Op.__init__(self, plan.wf)
+        self.opt, self.plan, self.global_step = optimizer, plan, global_step
+
+    def _run(self, feed):
+        from .training import Adam, cost_gradient
+        plan, wf = self.plan, self.plan.wf
+        for ph in (plan.samples_ph, plan.eloc_ph):
+            if ph not in feed:
+                raise ValueError("feed_dict lacks a value for %r" % (ph,))
+        samples, eloc = np.asarray(feed[plan.samples_ph]), np.asarray(feed[plan.eloc_ph])
+        ns = samples.shape[0]
+        lr = self.opt.learning_rate
+        lr = lr.value(feed) if isinstance(lr, _LearningRate) else float(feed[lr]) if isinstance(lr, Placeholder) else float(lr)
+        wf._native.load_batch(samples, eloc)
+        mean_e = complex(np.mean(eloc)) if plan.is_complex else float(np.mean(eloc))
+        grads = cost_gradient(wf._native, wf.params, wf.scope, mean_e, ns)
+        if self.opt._adam is None:
+            self.opt._adam = Adam(self.opt.beta1, self.opt.beta2, self.opt.epsilon)
+        wf.set_params(self.opt._adam.step(wf.get_params(), grads, lr))
+        if isinstance(self.global_step, Variable):
+            self.global_step.value = np.asarray(int(self.global_step.value) + 1)
+        return None
+
+
 class _Train:
     exponential_decay = staticmethod(lambda learning_rate, global_step, decay_steps, decay_rate, staircase=False, name=None:
                                      _LearningRate(learning_rate, global_step, decay_steps, decay_rate, staircase))
 
     class AdamOptimizer:
-        """tf.train.AdamOptimizer(learning_rate, beta1, beta2, epsilon) (:114): holds the hyper-parameters; the update
-        itself is training.Adam, driven by training.run_* (the symbolic compute_gradients / apply_gradients of the
-        reference's graph are not reproduced: the gradient of the VMC cost is rnnwf_vmc_gradient)."""
+        """tf.train.AdamOptimizer(learning_rate, beta1, beta2, epsilon) (:114) for the reference's VMC cost.
+
+        `compute_gradients(cost)` recognises the cost  mean(log P * E) - mean(E) mean(log P)  (TrainingRNN_1DTFIM.py:156,
+        with or without stop_gradient on E as in the 2D scripts) and its complex form (TrainingRNN_J1J2.py:197); its
+        gradient is rnnwf_vmc_gradient on the fed batch (rnnwf_load_batch).  `apply_gradients(...)` returns the op that
+        `sess.run(optstep, feed_dict={Eloc: ..., samp: ..., learningrate_placeholder: lr})` runs: load the batch, take the
+        gradient on the GPU, Adam update (training.Adam = TF-1 formulas), advance `global_step`.  Any other graph is
+        refused: there is no general autodiff here."""
 
         def __init__(self, learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8, name="Adam"):
             self.learning_rate, self.beta1, self.beta2, self.epsilon = learning_rate, beta1, beta2, epsilon
+            self._adam = None
 
         def variables(self):
             return []
+
+        def compute_gradients(self, cost, var_list=None):
+            sig = _sig(cost) if isinstance(cost, Expr) else None
+            if sig not in (_COST_REAL, _COST_COMPLEX):
+                raise NotImplementedError(
+                    "compute_gradients: only the reference's VMC cost is differentiated here (rnnwf_vmc_gradient); got %s" % sig)
+            ops, phs = _leaves(cost, EvalOp, []), _leaves(cost, Placeholder, [])
+            if len(ops) != 1 or len(phs) != 1 or not isinstance(ops[0].source, Placeholder):
+                raise NotImplementedError("compute_gradients: expected ONE log-probability op of a placeholder and ONE energy placeholder")
+            if (sig == _COST_COMPLEX) != (ops[0].kind == "log_amp"):
+                raise NotImplementedError("compute_gradients: the complex cost goes with log_amplitude, the real one with log_probability")
+            plan = _CostPlan(ops[0].wf, ops[0].source, phs[0], sig == _COST_COMPLEX)
+            return [(_Gradient(plan, v), v) for v in (var_list or [VariableRef(plan.wf, k) for k in plan.wf.params])]
+
+        def apply_gradients(self, grads_and_vars, global_step=None, name=None):
+            gv = list(grads_and_vars)
+            if not gv or not isinstance(gv[0][0], _Gradient):
+                raise NotImplementedError("apply_gradients: pass what compute_gradients returned")
+            return _OptStep(self, gv[0][0].plan, global_step)
+
+        def minimize(self, cost, global_step=None, var_list=None):
+            return self.apply_gradients(self.compute_gradients(cost, var_list), global_step)
 
     class Saver:
         """tf.train.Saver() (:166): save / restore the wave functions of the graph as TF checkpoints (V2 tensor bundle,
@@ -299,3 +425,5 @@ def is_gru_cell(cell):
 
 compat.v1.Session, compat.v1.placeholder = Session, placeholder
 complex128 = np.complex128
+abs = lambda x, *a, **k: Expr("abs", x)                            # noqa: E731,A001
+reduce_max = lambda x, *a, **k: Expr("max", x)                     # noqa: E731

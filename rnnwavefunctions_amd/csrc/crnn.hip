@@ -313,6 +313,16 @@ int rnnwf::crnn_j1j2_eloc(rnnwf_handle* h, const int32_t* samples, int64_t ns, c
     return RNNWF_OK;
 }
 
+int rnnwf::crnn_load_batch(rnnwf_handle* h, const int32_t* samples, int64_t ns) {
+    const int N = h->N;
+    if (ns > max_chains_per_pass(h))
+        return h->fail(RNNWF_ERR_NOMEM, "rnnwf_load_batch: %lld samples exceed the checkpoint budget; split the batch", (long long)ns);
+    const std::vector<double> zeros((size_t)3 * N, 0.0);              // no bonds: base pass + checkpoints only
+    if (int rc = upload_couplings(h, zeros.data(), zeros.size())) return rc;
+    if (int rc = upload_and_pack(h, samples, ns, h->bits, 0, nullptr)) return rc;
+    return j1j2_on_device(h, ns, false, 0, 0, 0, (const double*)h->coupl.p, 0, 0);
+}
+
 int rnnwf::crnn_vmc_step(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t step, int64_t offset,
                          const double* couplings, int32_t* out_samples, float* out_eloc, double* moments) {
     const int N = h->N;

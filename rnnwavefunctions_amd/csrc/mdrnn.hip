@@ -309,6 +309,18 @@ int rnnwf::mdrnn_tfim_eloc(rnnwf_handle* h, const int32_t* samples, int64_t ns, 
     return RNNWF_OK;
 }
 
+int rnnwf::mdrnn_load_batch(rnnwf_handle* h, const int32_t* samples, int64_t ns) {
+    const int N = h->N;
+    Maps m;
+    if (int rc = get_maps(h, &m)) return rc;
+    if (ns > max_chains_per_pass(h))
+        return h->fail(RNNWF_ERR_NOMEM, "rnnwf_load_batch: %lld samples exceed the hidden-state budget; split the batch", (long long)ns);
+    const std::vector<double> zeros((size_t)N, 0.0);
+    if (int rc = upload_couplings(h, zeros.data(), (size_t)N)) return rc;
+    if (int rc = upload_and_pack(h, samples, ns, h->bits, 0, m.col_of_pos)) return rc;
+    return eloc_on_device(h, ns, m, false, 0, 0, 0, (const double*)h->coupl.p, 0.0);
+}
+
 int rnnwf::mdrnn_vmc_step(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t step, int64_t offset,
                           const double* couplings, int32_t* out_samples, double* out_eloc, double* moments) {
     const int N = h->N;

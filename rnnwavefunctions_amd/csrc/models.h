@@ -59,6 +59,11 @@ int crnn_split_swap(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles);
 double crnn_split_flops_per_step(rnnwf_handle* h);
 int crnn_split_pack(rnnwf_handle* h, std::vector<char>& simg);
 
+// teacher-forced base pass with checkpoints on caller-supplied samples (rnnwf_load_batch)
+int prnn_load_batch(rnnwf_handle* h, const int32_t* samples, int64_t ns);
+int crnn_load_batch(rnnwf_handle* h, const int32_t* samples, int64_t ns);
+int mdrnn_load_batch(rnnwf_handle* h, const int32_t* samples, int64_t ns);
+
 // ---- gradient (grad.hip) ---------------------------------------------------------------------------
 int mdrnn_vmc_gradient(rnnwf_handle* h, double mean_energy, double norm);
 void grad_invalidate(rnnwf_handle* h);

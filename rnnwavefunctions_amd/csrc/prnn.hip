@@ -355,6 +355,23 @@ int rnnwf::prnn_tfim_eloc(rnnwf_handle* h, const int32_t* samples, int64_t ns, i
     return RNNWF_OK;
 }
 
+// Teacher-forced base pass with checkpoints on caller-supplied samples (no flips, no energies): what the gradient needs
+// resident besides E_loc, which rnnwf_load_batch uploads afterwards.
+int rnnwf::prnn_load_batch(rnnwf_handle* h, const int32_t* samples, int64_t ns) {
+    const int N = h->N;
+    if (ns > max_chains_per_pass(h))
+        return h->fail(RNNWF_ERR_NOMEM, "rnnwf_load_batch: %lld samples exceed the checkpoint budget; split the batch", (long long)ns);
+    h->call_ns = ns;
+    const std::vector<double> zeros((size_t)N, 0.0);
+    if (int rc = upload_couplings(h, zeros.data(), (size_t)N)) return rc;
+    if (int rc = upload_and_pack(h, samples, ns, h->bits, 0, nullptr)) return rc;
+    if (h->model == RNNWF_MODEL_GRU1D_PARITY)
+        if (int rc = pack_device(h, ns, h->bits2, 1, nullptr)) return rc;
+    const int Nx = h->model == RNNWF_MODEL_GRU1D_F64 ? h->Nx : 1;
+    const int Ny = h->model == RNNWF_MODEL_GRU1D_F64 ? h->Ny : N;
+    return eloc_on_device(h, ns, false, 0, 0, 0, Nx, Ny, (const double*)h->coupl.p, 0.0);
+}
+
 int rnnwf::prnn_vmc_step(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t step, int64_t offset,
                          const double* couplings, int32_t* out_samples, double* out_eloc, double* moments) {
     const int N = h->N;

@@ -483,6 +483,23 @@ extern "C" int rnnwf_vmc_step(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64
     return crnn_vmc_step(h, ns, seed, step, offset, couplings, out_samples, (float*)out_eloc, moments);
 }
 
+extern "C" int rnnwf_load_batch(rnnwf_handle* h, const int32_t* samples, int64_t ns, const void* eloc) {
+    if (int rc = check_ready(h)) return rc;
+    if (ns < 1 || !samples || !eloc) return h->fail(RNNWF_ERR_INVALID, "rnnwf_load_batch: bad arguments");
+    h->last_ns = 0;
+    int rc;
+    if (is_prnn(h)) rc = prnn_load_batch(h, samples, ns);
+    else if (h->model == RNNWF_MODEL_CRNN_U1) rc = crnn_load_batch(h, samples, ns);
+    else rc = mdrnn_load_batch(h, samples, ns);
+    if (rc) return rc;
+    const size_t bytes = (size_t)ns * 8;                  // float64 per sample, or complex64 = two float32 per sample
+    RNNWF_HIP(h, hipMemcpyAsync(h->eloc.p, eloc, bytes, hipMemcpyHostToDevice, h->stream));
+    RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+    h->last_ns = ns;
+    h->last_has_ckpt = true;
+    return RNNWF_OK;
+}
+
 // -------------------------------------------------------------------------------------------------
 // measurement
 // -------------------------------------------------------------------------------------------------

@@ -304,3 +304,101 @@ def test_run_1dtfim_with_two_layers_reaches_the_ground_state():
     final = np.mean(meanE[-50:])
     print("run_1DTFIM 2 layers N=10: E(first)=%.4f  last-50 mean=%.5f (ED %.5f) var=%.4f" % (meanE[0], final, ed, np.mean(varE[-50:])))
     assert final > ed - 0.02 and abs(final - ed) < 0.04
+
+
+# ---- the reference's OWN training loop (graph-mode cost, compute_gradients / apply_gradients, sess.run(optstep)) -------
+
+def test_reference_training_loop_of_1dtfim_runs_with_compat_as_tf():
+    """The statements of 1DTFIM/TrainingRNN_1DTFIM.py:103-123,147-166,185-221 - set-up, the cost
+    `mean(log_probs_ * Eloc) - mean(Eloc) mean(log_probs_)`, `optimizer.compute_gradients(cost)`,
+    `optimizer.apply_gradients(..., global_step)`, and `sess.run(optstep, feed_dict={Eloc, samp, learningrate})` in the
+    sampling / local-energy loop - written here with the same calls, `tf` being rnnwavefunctions_amd.compat.  The
+    trajectory must be that of training.run_1DTFIM (same seed, same Philox sub-streams): the two are the same GPU work."""
+    import rnnwavefunctions_amd.compat as tf
+    from rnnwavefunctions_amd.TFIM1D.TrainingRNN_1DTFIM import Ising_local_energies, RNNwavefunction, run_1DTFIM
+    numsteps, N, num_units, numsamples, seed, learningrate, Bx = 12, 10, 10, 100, 111, 5e-3, 1.0
+    Jz = +np.ones(N)
+    lr = np.float64(learningrate)
+    units = [num_units]
+    wf = RNNwavefunction(N, units=units, cell=tf.contrib.cudnn_rnn.CudnnCompatibleGRUCell, seed=seed)
+    with wf.graph.as_default():
+        global_step = tf.Variable(0, trainable=False)
+        learningrate_placeholder = tf.placeholder(dtype=tf.float64, shape=[])
+        learning_rate_withexpdecay = tf.train.exponential_decay(learningrate_placeholder, global_step=global_step,
+                                                                decay_steps=100, decay_rate=1.0, staircase=True)
+        optimizer = tf.train.AdamOptimizer(learning_rate=learning_rate_withexpdecay)
+        init = tf.global_variables_initializer()
+    sess = tf.Session(graph=wf.graph, config=tf.ConfigProto())
+    sess.run(init)
+    with tf.variable_scope(wf.scope, reuse=tf.AUTO_REUSE):
+        with wf.graph.as_default():
+            Eloc = tf.placeholder(dtype=tf.float64, shape=[numsamples])
+            samp = tf.placeholder(dtype=tf.int32, shape=[numsamples, N])
+            log_probs_ = wf.log_probability(samp, inputdim=2)
+            cost = tf.reduce_mean(tf.multiply(log_probs_, Eloc)) - tf.reduce_mean(Eloc) * tf.reduce_mean(log_probs_)
+            gradients, variables = zip(*optimizer.compute_gradients(cost))
+            optstep = optimizer.apply_gradients(zip(gradients, variables), global_step=global_step)
+            sess.run(tf.variables_initializer(optimizer.variables()))
+    assert len(variables) == 8
+    meanEnergy, varEnergy = [], []
+    with tf.variable_scope(wf.scope, reuse=tf.AUTO_REUSE):
+        with wf.graph.as_default():
+            samples_ = wf.sample(numsamples=numsamples, inputdim=2)
+            samples_placeholder = tf.placeholder(dtype=tf.int32, shape=(None, N))
+            log_probs_tensor = wf.log_probability(samples_placeholder, inputdim=2)
+            queue_samples = np.zeros((N + 1, numsamples, N), dtype=np.int32)
+            log_probs = np.zeros((N + 1) * numsamples, dtype=np.float64)
+            for it in range(len(meanEnergy), numsteps + 1):
+                samples = sess.run(samples_)
+                local_energies = Ising_local_energies(Jz, Bx, samples, queue_samples, log_probs_tensor,
+                                                      samples_placeholder, log_probs, sess)
+                meanEnergy.append(np.mean(local_energies))
+                varEnergy.append(np.var(local_energies))
+                sess.run(optstep, feed_dict={Eloc: local_energies, samp: samples, learningrate_placeholder: lr})
+    assert int(sess.run(global_step)) == numsteps + 1
+    mE, vE = run_1DTFIM(numsteps=numsteps, systemsize=N, num_units=num_units, Bx=Bx, numsamples=numsamples,
+                        learningrate=learningrate, seed=seed, verbose=False)
+    print("reference-style loop vs run_1DTFIM: max |dE| = %.2e" % np.abs(np.array(meanEnergy) - np.array(mE)).max())
+    assert np.allclose(meanEnergy, mE, rtol=1e-6, atol=1e-6) and np.allclose(varEnergy, vE, rtol=1e-5, atol=1e-6)
+    # a cost that is not the VMC cost is refused rather than mis-differentiated
+    with pytest.raises(NotImplementedError):
+        optimizer.compute_gradients(tf.reduce_mean(log_probs_))
+
+
+def test_reference_training_loop_of_j1j2_runs_with_compat_as_tf():
+    """J1J2/TrainingRNN_J1J2.py:185-207,241-306: the complex cost `2 Re(mean(conj(log psi) E) - conj(mean log psi) mean E)`
+    and the J1J2Slices / log-amplitude / E_loc loop, against training.run_J1J2."""
+    import rnnwavefunctions_amd.compat as tf
+    from rnnwavefunctions_amd.J1J2.TrainingRNN_J1J2 import J1J2_local_energies, RNNwavefunction, run_J1J2
+    numsteps, N, num_units, numsamples, seed, learningrate, J2_ = 8, 10, 10, 100, 111, 2.5e-4, 0.2
+    J1, J2, Bz = np.ones(N), J2_ * np.ones(N), np.zeros(N)
+    wf = RNNwavefunction(N, units=[num_units], cell=tf.contrib.cudnn_rnn.CudnnCompatibleGRUCell, seed=seed)
+    with wf.graph.as_default():
+        global_step = tf.Variable(0, trainable=False)
+        learningrate_placeholder = tf.placeholder(dtype=tf.float64, shape=[])
+        learning_rate_withexpdecay = tf.train.exponential_decay(learningrate_placeholder, global_step=global_step,
+                                                                decay_steps=100, decay_rate=1.0, staircase=True)
+        optimizer = tf.train.AdamOptimizer(learning_rate=learning_rate_withexpdecay, beta1=0.9, beta2=0.999, epsilon=1e-8)
+    sess = tf.Session(graph=wf.graph, config=tf.ConfigProto())
+    with tf.variable_scope(wf.scope, reuse=tf.AUTO_REUSE):
+        with wf.graph.as_default():
+            Eloc = tf.placeholder(dtype=tf.complex64, shape=[numsamples])
+            samp = tf.placeholder(dtype=tf.int32, shape=[numsamples, N])
+            log_amplitudes_ = wf.log_amplitude(samp, inputdim=2)
+            cost = 2 * tf.real(tf.reduce_mean(tf.conj(log_amplitudes_) * tf.stop_gradient(Eloc)) -
+                               tf.conj(tf.reduce_mean(log_amplitudes_)) * tf.reduce_mean(tf.stop_gradient(Eloc)))
+            gradients, variables = zip(*optimizer.compute_gradients(cost))
+            optstep = optimizer.apply_gradients(zip(gradients, variables), global_step=global_step)
+            samples_ = wf.sample(numsamples=numsamples, inputdim=2)
+            inputs = tf.placeholder(dtype=tf.int32, shape=(None, N))
+            log_amps = wf.log_amplitude(inputs, inputdim=2)
+    meanEnergy = []
+    for it in range(numsteps + 1):
+        samples = sess.run(samples_)
+        local_energies = J1J2_local_energies(J1, J2, Bz, samples, log_amps)
+        meanEnergy.append(np.mean(local_energies))
+        sess.run(optstep, feed_dict={Eloc: local_energies, samp: samples, learningrate_placeholder: np.float64(learningrate)})
+    mE, _ = run_J1J2(numsteps=numsteps, systemsize=N, J1_=1.0, J2_=J2_, num_units=num_units, numsamples=numsamples,
+                     learningrate=learningrate, seed=seed, verbose=False)
+    print("reference-style J1J2 loop vs run_J1J2: max |dE| = %.2e" % np.abs(np.array(meanEnergy) - np.array(mE)).max())
+    assert np.allclose(meanEnergy, mE, rtol=1e-5, atol=1e-5)
