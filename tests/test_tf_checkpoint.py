@@ -164,3 +164,21 @@ def test_real_tf_checkpoint_if_present():
     for idx in found:
         got = T.read_checkpoint(idx[:-len(".index")])
         assert got and all(np.all(np.isfinite(v)) for v in got.values() if v.dtype.kind == "f")
+
+
+def test_converter_tool_round_trips_names_and_values(tmp_path):
+    """tools/ckpt_convert.py: npz -> ckpt -> npz keeps every TF variable name (with its '/') and every bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prm = P.init_gru_params([6], seed=2)
+    P.save_npz(tmp_path / "a.npz", prm)
+    tool = os.path.join(root, "tools", "ckpt_convert.py")
+    subprocess.run([sys.executable, tool, "ckpt", str(tmp_path / "a.npz"), str(tmp_path / "m.ckpt")], check=True, capture_output=True)
+    out = subprocess.run([sys.executable, tool, "list", str(tmp_path / "m.ckpt")], check=True, capture_output=True, text=True).stdout
+    assert "RNNwavefunction/wf_dense/kernel" in out and "(6, 2)" in out
+    subprocess.run([sys.executable, tool, "npz", str(tmp_path / "m.ckpt"), str(tmp_path / "b.npz")], check=True, capture_output=True)
+    back = P.load_npz(tmp_path / "b.npz")
+    assert set(back) == set(prm) and all(np.array_equal(back[k], prm[k]) for k in prm)
+    import re
+    assert all(re.fullmatch(r"[A-Za-z0-9.][A-Za-z0-9_.\\/>-]*", k) for k in back)        # TF's variable-name grammar
