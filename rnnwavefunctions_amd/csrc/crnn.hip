@@ -138,6 +138,9 @@ size_t hck_bytes_per_block(rnnwf_handle* h) {
     return 0;
 }
 
+// sites with a stored state: a stack keeps all N (the layer-wise gradient reads the lower layers' last site too)
+int hck_sites(const rnnwf_handle* h) { return h->NL > 1 ? h->N : std::max(h->N - 1, 1); }
+
 CrnnArgs base_args(rnnwf_handle* h, int64_t ns) {
     CrnnArgs a{};
     a.wimg = h->wimg.p;
@@ -148,7 +151,7 @@ CrnnArgs base_args(rnnwf_handle* h, int64_t ns) {
 }
 
 int64_t max_chains_per_pass(rnnwf_handle* h) {
-    const size_t per_block = (size_t)std::max(h->N - 1, 1) * hck_bytes_per_block(h);
+    const size_t per_block = (size_t)hck_sites(h) * hck_bytes_per_block(h);
     return std::max<int64_t>(1, (int64_t)(state_budget_bytes(h, kHckBudget) / per_block)) * kChains;
 }
 
@@ -160,7 +163,7 @@ int j1j2_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
     const int N = h->N;
     const int64_t nsb = (ns + kChains - 1) / kChains;
     const int64_t cap = 4 * ns;
-    if (int rc = ensure(h, h->hck, (size_t)std::max(N - 1, 1) * nsb * hck_bytes_per_block(h))) return rc;
+    if (int rc = ensure(h, h->hck, (size_t)hck_sites(h) * nsb * hck_bytes_per_block(h))) return rc;
     if (int rc = ensure(h, h->cbase, (size_t)N * ns * sizeof(double2))) return rc;
     if (int rc = ensure(h, h->cout, (size_t)ns * (sizeof(double2) + sizeof(double)))) return rc;
     if (int rc = ensure(h, h->tile_count, (size_t)(2 * N + 8) * 4 + 64)) return rc;

@@ -5,7 +5,7 @@
 // pass over the compacted items), with the layer stack of ml_kernels.h: every layer's state in registers in B-fragment
 // order, the new state of layer l is the X operand of layer l + 1 (UpperCore), the three head rows read the top layer.
 // f32-input MFMA, 16 chains per wave.  LDS image: [GruLayout<float, NFULL, 3> | UpperLayout<NFULL> x (NL - 1)].
-//   hck [N-1][nsb][NL][KT][64] f32   states of all layers after site n
+//   hck [N][nsb][NL][KT][64] f32   states of all layers after site n (all N sites: ml_grad_kernels.h needs the last one)
 #pragma once
 #include "crnn_kernels.h"
 
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(WAVES * 64) crnn_ml_base_kernel(CrnnArgs a) {
                 a.cb[(int64_t)n * a.ns + s] = make_double2(re + (double)(sig ? la0 : la1), im + (double)(sig ? ph0 : ph1));
             re += (double)(sig ? la1 : la0);
             im += (double)(sig ? ph1 : ph0);
-            if (a.hck && n < N - 1) {
+            if (a.hck) {
                 float* dst = reinterpret_cast<float*>(a.hck) + (((int64_t)n * a.nsb + sb) * NL * KT) * 64 + lane;
 #pragma unroll
                 for (int l = 0; l < NL; ++l)

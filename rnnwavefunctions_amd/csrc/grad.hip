@@ -163,14 +163,15 @@ struct GLaunch {
     } while (0)
 
 // ---- stacked layers: one backward pass per layer, top first (ml_grad_kernels.h) ---------------------------------
-template <int NFULL, int NL, int WAVES>
+// NOUT = 1: positive RNN; NOUT = 3: complex RNN (heads on the top layer, complex weights w_s as in gru_bwd_kernel).
+template <int NFULL, int NL, int WAVES, int NOUT = 1>
 struct MLGrad {
-    using G0 = GLaunch<float, NFULL, WAVES, 1>;
-    using L0 = GruLayout<float, NFULL, 1>;
+    using G0 = GLaunch<float, NFULL, WAVES, NOUT>;
+    using L0 = GruLayout<float, NFULL, NOUT>;
     using U = UpperLayout<NFULL>;
-    using GU = UpperGradLayout<NFULL>;
+    using GU = UpperGradLayout<NFULL, NOUT>;
     static constexpr size_t DW0 = (size_t)G0::G::PCOLS * G0::G::QCOLS;     // floats
-    static constexpr size_t HEAD = G0::G::HEAD_ROW;
+    static constexpr size_t HEAD = (size_t)NOUT * G0::G::HEAD_ROW;
     static constexpr size_t DWU = (size_t)GU::PCOLS * GU::QCOLS;
     static constexpr size_t DW_FLOATS = DW0 + HEAD + (NL - 1) * DWU;       // [dW layer 0 | head | dW layer 1 | ...]
 
@@ -218,14 +219,14 @@ struct MLGrad {
 
     template <bool TOP>
     static int upper_pass(rnnwf_handle* h, const UpperGradArgs& a) {
-        const void* fn = (const void*)gru_upper_bwd_kernel<NFULL, WAVES, TOP>;
+        const void* fn = (const void*)gru_upper_bwd_kernel<NFULL, WAVES, TOP, NOUT>;
         const size_t lds = U::BYTES + GU::BWD_BYTES + (TOP ? GU::HEAD_BYTES : 0);
         if (lds > 160 * 1024) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: stacked-layer images (%zu B) exceed the 160 KB LDS", lds);
         int bpc = 0;
         if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, lds, &bpc)) return rc;
         const int64_t need = (a.nsb + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
-        gru_upper_bwd_kernel<NFULL, WAVES, TOP><<<grid, WAVES * 64, lds, h->stream>>>(a);
+        gru_upper_bwd_kernel<NFULL, WAVES, TOP, NOUT><<<grid, WAVES * 64, lds, h->stream>>>(a);
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }
@@ -240,9 +241,10 @@ struct MLGrad {
         return 0;
     }
 
-    static int run(rnnwf_handle* h, double mean_energy, double norm) {
+    static int run(rnnwf_handle* h, double mean_energy, double mean_energy_im, double norm) {
         const int N = h->N;
         const int64_t ns = h->last_ns, R = ns * N, nsb = (ns + kChains - 1) / kChains;
+        const double inv_norm = (NOUT == 3 ? 2.0 : 1.0) / norm;     // the complex cost carries a factor 2 (TrainingRNN_J1J2.py:197)
         if (!h->wbwd.p) {
             const std::vector<char> img = pack_all(h);
             if (int rc = ensure(h, h->wbwd, img.size())) return rc;
@@ -268,8 +270,10 @@ struct MLGrad {
             a.bits = (const uint32_t*)h->bits.p;
             a.hck = (const float*)h->hck.p;
             a.eloc = (const double*)h->eloc.p;
+            a.eloc_c = (const float2*)h->eloc.p;
             a.mean_e = mean_energy;
-            a.inv_norm = 1.0 / norm;
+            a.mean_im = mean_energy_im;
+            a.inv_norm = inv_norm;
             a.dh_in = dh_in;
             a.dx_out = (float*)h->gradDX[(NL - 1 - l) & 1].p;
             a.P = (float*)h->gradP.p;
@@ -287,11 +291,13 @@ struct MLGrad {
         a.bits = (const uint32_t*)h->bits.p;
         a.hck = h->hck.p;
         a.eloc = (const double*)h->eloc.p;
+        a.eloc_c = (const float2*)h->eloc.p;
         a.mean_e = mean_energy;
-        a.inv_norm = 1.0 / norm;
+        a.mean_im = mean_energy_im;
+        a.inv_norm = inv_norm;
         a.P = h->gradP.p;
         a.Q = h->gradQ.p;
-        a.head_grad = dW + DW_FLOATS;          // scratch row: layer 0 has no head term here (its adds are zeros)
+        a.head_grad = dW + DW_FLOATS;          // scratch rows: layer 0 has no head term here (its adds are zeros)
         a.dh_in = dh_in;
         a.hck_nl = NL;
         if (int rc = G0::run(h, a, R, dW)) return rc;
@@ -343,20 +349,25 @@ struct MLGrad {
     }
 };
 
-#define MLGRAD_DISPATCH(h, EXPR)                                        \
+#define MLGRAD_DISPATCH_(h, NOUT, EXPR)                                 \
     do {                                                                \
         if ((h)->NL == 2) {                                             \
             switch ((h)->NFULL) {                                       \
-                case 1: { using K = MLGrad<1, 2, 4>; EXPR; }            \
-                case 2: { using K = MLGrad<2, 2, 4>; EXPR; }            \
-                case 3: { using K = MLGrad<3, 2, 4>; EXPR; }            \
+                case 1: { using K = MLGrad<1, 2, 4, NOUT>; EXPR; }      \
+                case 2: { using K = MLGrad<2, 2, 4, NOUT>; EXPR; }      \
+                case 3: { using K = MLGrad<3, 2, 4, NOUT>; EXPR; }      \
             }                                                           \
         } else if ((h)->NL == 3) {                                      \
             switch ((h)->NFULL) {                                       \
-                case 1: { using K = MLGrad<1, 3, 4>; EXPR; }            \
-                case 2: { using K = MLGrad<2, 3, 4>; EXPR; }            \
+                case 1: { using K = MLGrad<1, 3, 4, NOUT>; EXPR; }      \
+                case 2: { using K = MLGrad<2, 3, 4, NOUT>; EXPR; }      \
             }                                                           \
         }                                                               \
+    } while (0)
+#define MLGRAD_DISPATCH(h, EXPR)                                        \
+    do {                                                                \
+        if ((h)->model == RNNWF_MODEL_CRNN_U1) MLGRAD_DISPATCH_(h, 3, EXPR); \
+        else MLGRAD_DISPATCH_(h, 1, EXPR);                              \
     } while (0)
 
 }  // namespace
@@ -368,15 +379,13 @@ extern "C" int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double me
     if (h->model != RNNWF_MODEL_GRU1D && h->model != RNNWF_MODEL_CRNN_U1 && h->model != RNNWF_MODEL_GRU1D_F64)
         return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: not implemented for the parity-symmetrised GRU RNN");
     if (h->NL != 1) {
-        if (h->model == RNNWF_MODEL_CRNN_U1)
-            return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: the stacked-layer complex RNN has forward passes only (sample, "
-                                              "log_amplitude, J1-J2 local energies); its gradient is implemented for one layer");
-        if (h->model != RNNWF_MODEL_GRU1D) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: not implemented for the parity-symmetrised GRU RNN");
+        if (h->model != RNNWF_MODEL_GRU1D && h->model != RNNWF_MODEL_CRNN_U1)
+            return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: stacked layers are implemented for the float32 models (1D positive GRU RNN, complex RNN)");
         if (h->last_ns <= 0 || !h->last_has_ckpt)
             return h->fail(RNNWF_ERR_STATE, "rnnwf_vmc_gradient: call rnnwf_vmc_step first (its samples, states and E_loc are reused)");
         if (!(norm > 0)) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: norm must be positive");
         RNNWF_HIP(h, hipSetDevice(h->cfg.device));
-        MLGRAD_DISPATCH(h, return K::run(h, mean_energy, norm));
+        MLGRAD_DISPATCH(h, return K::run(h, mean_energy, mean_energy_im, norm));
         return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: no stacked-layer kernel for this width");
     }
     const bool cplx = h->model == RNNWF_MODEL_CRNN_U1;

@@ -13,7 +13,7 @@
 
 namespace rnnwf {
 
-template <int NFULL>
+template <int NFULL, int NOUT = 1>
 struct UpperGradLayout {
     static constexpr int KT = 4 * NFULL + 1;
     static constexpr int NT = 3 * NFULL + 1;
@@ -24,8 +24,9 @@ struct UpperGradLayout {
     static constexpr int KBG = (KB + 3) / 4;
     static constexpr size_t SIDE_BYTES = (size_t)NTO * KBG * 64 * 16;    // [NTO][KBG][64] float4
     static constexpr size_t BWD_BYTES = 2 * SIDE_BYTES;                  // H side (-> dh), X side (-> dx)
-    static constexpr int WD_Q = ((KT + 3) / 4) * 4;                      // GruLayout<float, NFULL, 1>::WD_Q
-    static constexpr size_t HEAD_BYTES = ((size_t)(4 * WD_Q + 8) * 4 + 15) / 16 * 16;   // [4 q][WD_Q] + bias
+    static constexpr int WD_Q = ((NOUT * KT + 3) / 4) * 4;               // GruLayout<float, NFULL, NOUT>::WD_Q
+    static constexpr size_t HEAD_BYTES = ((size_t)(4 * WD_Q + 8) * 4 + 15) / 16 * 16;   // [4 q][KT][NOUT] + bias
+    static constexpr int HEAD_ROW = 4 * KT + 4;                          // as GradLayout::HEAD_ROW
 };
 
 struct UpperGradArgs {
@@ -36,19 +37,21 @@ struct UpperGradArgs {
     int64_t ns, nsb;
     const uint32_t* bits;
     const float* hck;          // [N][nsb][NL][KT][64]
-    const double* eloc;
-    double mean_e, inv_norm;
+    const double* eloc;        // [ns] f64 (positive RNN) ...
+    const float2* eloc_c;      // ... or [ns] complex64 (complex RNN)
+    double mean_e, mean_im, inv_norm;
     const float* dh_in;        // [N][nsb][KT][64] from the layer above (nullptr: top layer, head)
     float* dx_out;             // [N][nsb][KT][64]
     float* P;
     float* Q;
-    float* head_grad;          // [HEAD_ROW] (top layer)
+    float* head_grad;          // [NOUT][HEAD_ROW] (top layer)
 };
 
-template <int NFULL, int WAVES, bool TOP>
+// NOUT (top layer only): 1 = positive RNN head, 3 = complex RNN heads (the site terms of gru_bwd_kernel).
+template <int NFULL, int WAVES, bool TOP, int NOUT = 1>
 __global__ void __launch_bounds__(WAVES * 64) gru_upper_bwd_kernel(UpperGradArgs a) {
     using CU = UpperCore<NFULL>;
-    using G = UpperGradLayout<NFULL>;
+    using G = UpperGradLayout<NFULL, NOUT>;
     using V4 = typename CU::V4;
     constexpr int KT = CU::KT, NT = G::NT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -71,14 +74,31 @@ __global__ void __launch_bounds__(WAVES * 64) gru_upper_bwd_kernel(UpperGradArgs
     const int N = a.N;
     const float* wd = reinterpret_cast<const float*>(lds + CU::U::BYTES + G::BWD_BYTES) + q * G::WD_Q;
     const float* bd = reinterpret_cast<const float*>(lds + CU::U::BYTES + G::BWD_BYTES) + 4 * G::WD_Q;
-    float hg[KT], gb = 0.0f;
+    float hg[NOUT][KT], gb[NOUT];
 #pragma unroll
-    for (int k = 0; k < KT; ++k) hg[k] = 0.0f;
+    for (int o = 0; o < NOUT; ++o) {
+        gb[o] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) hg[o][k] = 0.0f;
+    }
     for (int64_t sb = gw; sb < a.nsb; sb += nw) {
         const int64_t s = sb * kChains + c;
         const bool valid = s < a.ns;
         const int64_t sc = valid ? s : a.ns - 1;
-        const float w = (TOP && valid) ? (float)((a.eloc[sc] - a.mean_e) * a.inv_norm) : 0.0f;
+        float w = 0.0f, w_im = 0.0f;
+        if (TOP && valid) {
+            if constexpr (NOUT == 1) {
+                w = (float)((a.eloc[sc] - a.mean_e) * a.inv_norm);
+            } else {
+                const float2 e = a.eloc_c[sc];
+                w = (float)(((double)e.x - a.mean_e) * a.inv_norm);
+                w_im = (float)(((double)e.y - a.mean_im) * a.inv_norm);
+            }
+        }
+        auto spin = [&](int n) { return (int)((a.bits[(int64_t)(n >> 5) * a.ns + sc] >> (n & 31)) & 1); };
+        int num_up = 0;                                   // complex RNN: up spins among sites < n (U(1) mask)
+        if constexpr (TOP && NOUT == 3)
+            for (int m = 0; m < N; ++m) num_up += spin(m);
         float dh[KT];
 #pragma unroll
         for (int k = 0; k < KT; ++k) dh[k] = 0.0f;
@@ -98,16 +118,42 @@ __global__ void __launch_bounds__(WAVES * 64) gru_upper_bwd_kernel(UpperGradArgs
                 for (int k = 0; k < KT; ++k) h[k] = 0.0f;
             }
             CU::step_keep(lds, x, h, hn, rg, ug, cc, qv, lane);
-            float g = 0.0f;
+            float g[NOUT];
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) g[o] = 0.0f;
             if (TOP) {
                 asm volatile("" ::: "memory");
-                float z = 0.0f;
+                float z[NOUT];
 #pragma unroll
-                for (int k = 0; k < KT; ++k) z += hn[k] * wd[k];
-                z += __shfl_xor(z, 16); z += __shfl_xor(z, 32); z += bd[0];
-                const int sig = (int)((a.bits[(int64_t)(n >> 5) * a.ns + sc] >> (n & 31)) & 1);
-                g = w * ((float)sig - (1.0f - prob0(z)));        // d log p(sig) / d(z1 - z0) = sig - p1
-                gb += g;
+                for (int o = 0; o < NOUT; ++o) z[o] = 0.0f;
+#pragma unroll
+                for (int k = 0; k < KT; ++k)
+#pragma unroll
+                    for (int o = 0; o < NOUT; ++o) z[o] += hn[k] * wd[k * NOUT + o];
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) {
+                    z[o] += __shfl_xor(z[o], 16); z[o] += __shfl_xor(z[o], 32); z[o] += bd[o];
+                }
+                const int sig = spin(n);
+                const float p1 = 1.0f - prob0(z[0]);
+                if constexpr (NOUT == 1) {
+                    g[0] = w * ((float)sig - p1);                // d log p(sig) / d(z1 - z0) = sig - p1
+                } else {                                         // the site terms of gru_bwd_kernel<.., 3>
+                    num_up -= sig;
+                    bool both = true;
+                    if (2 * n >= N) {
+                        const int base = N / 2 - 1;
+                        both = (base - (n - num_up) >= 0) && (base - num_up >= 0);
+                    }
+                    g[0] = both ? 0.5f * w * ((float)sig - p1) : 0.0f;
+                    const float zs = sig ? z[2] : z[1];
+                    const float den = 1.0f + fabsf(zs);
+                    const float gp = w_im * 3.14159265358979323846f / (den * den);
+                    g[1] = sig ? 0.0f : gp;
+                    g[2] = sig ? gp : 0.0f;
+                }
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) gb[o] += g[o];
             }
             float dpH[4 * G::KBG], dpX[4 * G::KBG];
             float dy[KT];
@@ -115,8 +161,11 @@ __global__ void __launch_bounds__(WAVES * 64) gru_upper_bwd_kernel(UpperGradArgs
             for (int k = 0; k < KT; ++k) {
                 float d = dh[k];
                 if (TOP) {
-                    hg[k] += g * hn[k];
-                    d += g * wd[k];
+#pragma unroll
+                    for (int o = 0; o < NOUT; ++o) {
+                        hg[o][k] += g[o] * hn[k];
+                        d += g[o] * wd[k * NOUT + o];
+                    }
                 } else {
                     d += a.dh_in[(((int64_t)n * a.nsb + sb) * KT + k) * 64 + lane];
                 }
@@ -188,14 +237,17 @@ __global__ void __launch_bounds__(WAVES * 64) gru_upper_bwd_kernel(UpperGradArgs
     }
     if (TOP) {
 #pragma unroll
-        for (int k = 0; k < KT; ++k) {
-            float v = hg[k];
+        for (int o = 0; o < NOUT; ++o) {
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                float v = hg[o][k];
+                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                if (c == 0) atomicAdd(&a.head_grad[o * G::HEAD_ROW + 4 * k + q], v);
+            }
+            float v = gb[o];
             v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-            if (c == 0) atomicAdd(&a.head_grad[4 * k + q], v);
+            if (c == 0 && q == 0) atomicAdd(&a.head_grad[o * G::HEAD_ROW + 4 * KT], v);
         }
-        float v = gb;
-        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-        if (c == 0 && q == 0) atomicAdd(&a.head_grad[4 * KT], v);
     }
 }
 

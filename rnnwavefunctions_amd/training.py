@@ -208,9 +208,8 @@ def run_J1J2(numsteps=10 ** 5, systemsize=20, J1_=1.0, J2_=0.0, Marshall_sign=Fa
     As in the reference, `Marshall_sign` reaches J1J2MatrixElements through J1J2Slices' `periodic` slot
     (J1J2/TrainingRNN_J1J2.py:118): Marshall_sign=True therefore selects the PERIODIC chain
     without a Marshall sign - reproduced here on purpose so that runs compare with the reference's."""
-    if num_layers != 1:
-        raise ValueError("training the complex RNN: num_layers = 1 only (stacked layers have the forward passes - sample, "
-                         "log_amplitude, J1-J2 local energies - but no gradient yet; the reference's run scripts use 1)")
+    if not 1 <= num_layers <= 3:
+        raise ValueError("num_layers must be 1..3 (stacked layers: num_units <= 52 for 2, <= 36 for 3)")
     N = systemsize
     scope = "RNNwavefunction"
     lr = np.float64(learningrate)
