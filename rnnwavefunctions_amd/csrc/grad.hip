@@ -164,13 +164,15 @@ struct GLaunch {
 
 // ---- stacked layers: one backward pass per layer, top first (ml_grad_kernels.h) ---------------------------------
 // NOUT = 1: positive RNN; NOUT = 3: complex RNN (heads on the top layer, complex weights w_s as in gru_bwd_kernel).
-template <int NFULL, int NL, int WAVES, int NOUT = 1>
+// T = float, or double for the 2D-lattice GRU (NOUT = 1).
+template <int NFULL, int NL, int WAVES, int NOUT = 1, typename T = float>
 struct MLGrad {
-    using G0 = GLaunch<float, NFULL, WAVES, NOUT>;
-    using L0 = GruLayout<float, NFULL, NOUT>;
-    using U = UpperLayout<NFULL>;
-    using GU = UpperGradLayout<NFULL, NOUT>;
-    static constexpr size_t DW0 = (size_t)G0::G::PCOLS * G0::G::QCOLS;     // floats
+    using G0 = GLaunch<T, NFULL, WAVES, NOUT>;
+    using L0 = GruLayout<T, NFULL, NOUT>;
+    using U = UpperLayout<NFULL, T>;
+    using GU = UpperGradLayout<NFULL, NOUT, T>;
+    static constexpr size_t ES = sizeof(T);
+    static constexpr size_t DW0 = (size_t)G0::G::PCOLS * G0::G::QCOLS;     // elements
     static constexpr size_t HEAD = (size_t)NOUT * G0::G::HEAD_ROW;
     static constexpr size_t DWU = (size_t)GU::PCOLS * GU::QCOLS;
     static constexpr size_t DW_FLOATS = DW0 + HEAD + (NL - 1) * DWU;       // [dW layer 0 | head | dW layer 1 | ...]
@@ -183,10 +185,11 @@ struct MLGrad {
         const auto& Wci = pv(h, pre + "candidate/input_projection/kernel");   // [H, H]
         const auto& Wch = pv(h, pre + "candidate/hidden_projection/kernel");  // [H, H]
         for (int side = 0; side < 2; ++side) {                                // 0: H side (-> dh), 1: X side (-> dx)
-            float* A = reinterpret_cast<float*>(img.data() + side * GU::SIDE_BYTES);
+            T* A = reinterpret_cast<T*>(img.data() + side * GU::SIDE_BYTES);
             for (int t = 0; t < GU::NTO; ++t)
                 for (int row = 0; row < 16; ++row) {
-                    const int q = row >> 2, r = row & 3;
+                    int q, r;
+                    row_to_qr<T>(row, q, r);
                     if (t == NFULL && r != 0) continue;
                     const int kout = t < NFULL ? 16 * t + 4 * r + q : 16 * NFULL + q;
                     if (kout >= H) continue;
@@ -200,7 +203,7 @@ struct MLGrad {
                             if (g == 0) w = Wg[grow * 2 * H + u];
                             else if (g == 1) w = Wg[grow * 2 * H + H + u];
                             else w = side == 0 ? Wch[(size_t)kout * H + u] : Wci[(size_t)kout * H + u];
-                            A[(((size_t)t * GU::KBG + kk / 4) * 64 + lane) * 4 + (kk & 3)] = (float)w;
+                            A[(((size_t)t * GU::KBG + kk / GU::VW) * 64 + lane) * GU::VW + (kk % GU::VW)] = (T)w;
                         }
                     }
                 }
@@ -219,24 +222,24 @@ struct MLGrad {
 
     template <bool TOP>
     static int upper_pass(rnnwf_handle* h, const UpperGradArgs& a) {
-        const void* fn = (const void*)gru_upper_bwd_kernel<NFULL, WAVES, TOP, NOUT>;
+        const void* fn = (const void*)gru_upper_bwd_kernel<T, NFULL, WAVES, TOP, NOUT>;
         const size_t lds = U::BYTES + GU::BWD_BYTES + (TOP ? GU::HEAD_BYTES : 0);
         if (lds > 160 * 1024) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: stacked-layer images (%zu B) exceed the 160 KB LDS", lds);
         int bpc = 0;
         if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, lds, &bpc)) return rc;
         const int64_t need = (a.nsb + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
-        gru_upper_bwd_kernel<NFULL, WAVES, TOP, NOUT><<<grid, WAVES * 64, lds, h->stream>>>(a);
+        gru_upper_bwd_kernel<T, NFULL, WAVES, TOP, NOUT><<<grid, WAVES * 64, lds, h->stream>>>(a);
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }
 
-    static int gemm(rnnwf_handle* h, const float* P, const float* Q, int64_t R, float* dW, bool upper) {
+    static int gemm(rnnwf_handle* h, const T* P, const T* Q, int64_t R, T* dW, bool upper) {
         int64_t rpb = (R + (int64_t)h->cu_count * 4 - 1) / ((int64_t)h->cu_count * 4);
         rpb = std::max<int64_t>(64, ((rpb + 3) / 4) * 4);
         const unsigned gblocks = (unsigned)((R + rpb - 1) / rpb);
-        if (upper) tn_gemm_kernel<float, GU::PCOLS / 16, GU::QCOLS / 16><<<gblocks, 256, 0, h->stream>>>(P, Q, R, rpb, dW);
-        else tn_gemm_kernel<float, G0::G::PCOLS / 16, G0::G::QCOLS / 16><<<gblocks, 256, 0, h->stream>>>(P, Q, R, rpb, dW);
+        if (upper) tn_gemm_kernel<T, GU::PCOLS / 16, GU::QCOLS / 16><<<gblocks, 256, 0, h->stream>>>(P, Q, R, rpb, dW);
+        else tn_gemm_kernel<T, G0::G::PCOLS / 16, G0::G::QCOLS / 16><<<gblocks, 256, 0, h->stream>>>(P, Q, R, rpb, dW);
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }
@@ -251,15 +254,15 @@ struct MLGrad {
             RNNWF_HIP(h, hipMemcpyAsync(h->wbwd.p, img.data(), img.size(), hipMemcpyHostToDevice, h->stream));
             RNNWF_HIP(h, hipStreamSynchronize(h->stream));
         }
-        if (int rc = ensure(h, h->gradP, (size_t)R * GU::PCOLS * 4)) return rc;
-        if (int rc = ensure(h, h->gradQ, (size_t)R * GU::QCOLS * 4)) return rc;
-        if (int rc = ensure(h, h->gradW, (DW_FLOATS + HEAD) * 4)) return rc;     // + a scratch head row for layer 0's pass
-        const size_t dx_bytes = (size_t)N * nsb * L0::KT * 64 * 4;
+        if (int rc = ensure(h, h->gradP, (size_t)R * GU::PCOLS * ES)) return rc;
+        if (int rc = ensure(h, h->gradQ, (size_t)R * GU::QCOLS * ES)) return rc;
+        if (int rc = ensure(h, h->gradW, (DW_FLOATS + HEAD) * ES)) return rc;     // + a scratch head row for layer 0's pass
+        const size_t dx_bytes = (size_t)N * nsb * L0::KT * 64 * ES;
         for (int i = 0; i < (NL > 2 ? 2 : 1); ++i) if (int rc = ensure(h, h->gradDX[i], dx_bytes)) return rc;
-        RNNWF_HIP(h, hipMemsetAsync(h->gradW.p, 0, (DW_FLOATS + HEAD) * 4, h->stream));
-        float* dW = (float*)h->gradW.p;
+        RNNWF_HIP(h, hipMemsetAsync(h->gradW.p, 0, (DW_FLOATS + HEAD) * ES, h->stream));
+        T* dW = (T*)h->gradW.p;
         const char* bwd = (const char*)h->wbwd.p;
-        const float* dh_in = nullptr;
+        const void* dh_in = nullptr;
         for (int l = NL - 1; l >= 1; --l) {
             UpperGradArgs a{};
             a.wup = (const char*)h->wimg.p + L0::BYTES + (size_t)(l - 1) * U::BYTES;
@@ -268,20 +271,20 @@ struct MLGrad {
             a.N = N; a.layer = l; a.hck_nl = NL;
             a.ns = ns; a.nsb = nsb;
             a.bits = (const uint32_t*)h->bits.p;
-            a.hck = (const float*)h->hck.p;
+            a.hck = h->hck.p;
             a.eloc = (const double*)h->eloc.p;
             a.eloc_c = (const float2*)h->eloc.p;
             a.mean_e = mean_energy;
             a.mean_im = mean_energy_im;
             a.inv_norm = inv_norm;
             a.dh_in = dh_in;
-            a.dx_out = (float*)h->gradDX[(NL - 1 - l) & 1].p;
-            a.P = (float*)h->gradP.p;
-            a.Q = (float*)h->gradQ.p;
+            a.dx_out = h->gradDX[(NL - 1 - l) & 1].p;
+            a.P = h->gradP.p;
+            a.Q = h->gradQ.p;
             a.head_grad = dW + DW0;
             if (l == NL - 1) { if (int rc = upper_pass<true>(h, a)) return rc; }
             else { if (int rc = upper_pass<false>(h, a)) return rc; }
-            if (int rc = gemm(h, a.P, a.Q, R, dW + DW0 + HEAD + (size_t)(l - 1) * DWU, true)) return rc;
+            if (int rc = gemm(h, (const T*)a.P, (const T*)a.Q, R, dW + DW0 + HEAD + (size_t)(l - 1) * DWU, true)) return rc;
             dh_in = a.dx_out;
         }
         GradArgs a{};
@@ -301,15 +304,15 @@ struct MLGrad {
         a.dh_in = dh_in;
         a.hck_nl = NL;
         if (int rc = G0::run(h, a, R, dW)) return rc;
-        std::vector<float> host(DW_FLOATS);
-        RNNWF_HIP(h, hipMemcpyAsync(host.data(), h->gradW.p, DW_FLOATS * 4, hipMemcpyDeviceToHost, h->stream));
+        std::vector<T> host(DW_FLOATS);
+        RNNWF_HIP(h, hipMemcpyAsync(host.data(), h->gradW.p, DW_FLOATS * ES, hipMemcpyDeviceToHost, h->stream));
         RNNWF_HIP(h, hipStreamSynchronize(h->stream));
         G0::unpack(h, host.data(), DW0);                       // layer 0 + head (written by the top layer's pass)
         for (int l = 1; l < NL; ++l) unpack_upper(h, host.data() + DW0 + HEAD + (size_t)(l - 1) * DWU, l);
         return RNNWF_OK;
     }
 
-    static void unpack_upper(rnnwf_handle* h, const float* dW, int layer) {
+    static void unpack_upper(rnnwf_handle* h, const T* dW, int layer) {
         const int H = h->H;
         const int NT = GU::NT;
         auto col_of_unit = [&](int k) { return k < 16 * NFULL ? 16 * (k / 16) + 4 * (k % 4) + (k % 16) / 4 : 16 * NFULL + 4 * (k - 16 * NFULL); };
@@ -367,7 +370,11 @@ struct MLGrad {
 #define MLGRAD_DISPATCH(h, EXPR)                                        \
     do {                                                                \
         if ((h)->model == RNNWF_MODEL_CRNN_U1) MLGRAD_DISPATCH_(h, 3, EXPR); \
-        else MLGRAD_DISPATCH_(h, 1, EXPR);                              \
+        else if ((h)->model == RNNWF_MODEL_GRU1D_F64) {                 \
+            if ((h)->NL == 2 && (h)->NFULL == 1) { using K = MLGrad<1, 2, 4, 1, double>; EXPR; } \
+            if ((h)->NL == 2 && (h)->NFULL == 2) { using K = MLGrad<2, 2, 4, 1, double>; EXPR; } \
+            if ((h)->NL == 3 && (h)->NFULL == 1) { using K = MLGrad<1, 3, 4, 1, double>; EXPR; } \
+        } else MLGRAD_DISPATCH_(h, 1, EXPR);                            \
     } while (0)
 
 }  // namespace
@@ -379,8 +386,8 @@ extern "C" int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double me
     if (h->model != RNNWF_MODEL_GRU1D && h->model != RNNWF_MODEL_CRNN_U1 && h->model != RNNWF_MODEL_GRU1D_F64)
         return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: not implemented for the parity-symmetrised GRU RNN");
     if (h->NL != 1) {
-        if (h->model != RNNWF_MODEL_GRU1D && h->model != RNNWF_MODEL_CRNN_U1)
-            return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: stacked layers are implemented for the float32 models (1D positive GRU RNN, complex RNN)");
+        if (h->model != RNNWF_MODEL_GRU1D && h->model != RNNWF_MODEL_CRNN_U1 && h->model != RNNWF_MODEL_GRU1D_F64)
+            return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: not implemented for the parity-symmetrised GRU RNN");
         if (h->last_ns <= 0 || !h->last_has_ckpt)
             return h->fail(RNNWF_ERR_STATE, "rnnwf_vmc_gradient: call rnnwf_vmc_step first (its samples, states and E_loc are reused)");
         if (!(norm > 0)) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: norm must be positive");

@@ -44,9 +44,9 @@ struct GradArgs {
     void* P;                   // [N*ns][PCOLS] T
     void* Q;                   // [N*ns][QCOLS] T
     void* head_grad;           // [NOUT][HEAD_ROW] T, zeroed before the launch
-    // stacked layers (f32): this kernel is then the LAST pass (layer 0); dL/dh of every site arrives from
+    // stacked layers: this kernel is then the LAST pass (layer 0); dL/dh of every site arrives from
     // the layer above instead of from the head, and hck holds hck_nl layers per (site, block)
-    const float* dh_in;        // [N][nsb][KT][64] or nullptr
+    const void* dh_in;         // [N][nsb][KT][64] T or nullptr
     int32_t hck_nl;            // layers per checkpoint entry (0 or 1: single layer)
 };
 
@@ -139,11 +139,10 @@ __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
                 g[1] = sig ? T(0) : gp;
                 g[2] = sig ? gp : T(0);
             }
-            if constexpr (sizeof(T) == 4)
-                if (a.dh_in) {                                          // stack: the head sits on the top layer
+            if (a.dh_in) {                                              // stack: the head sits on the top layer
 #pragma unroll
-                    for (int o = 0; o < NOUT; ++o) g[o] = T(0);
-                }
+                for (int o = 0; o < NOUT; ++o) g[o] = T(0);
+            }
             T dp[VW * G::KBG];
             T dy[KT];
 #pragma unroll
@@ -151,8 +150,7 @@ __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
                 T d = dh[k];                                        // total dL/dh_n of this lane's unit
-                if constexpr (sizeof(T) == 4)
-                    if (a.dh_in) d += a.dh_in[(((int64_t)n * a.nsb + sb) * KT + k) * 64 + lane];
+                if (a.dh_in) d += reinterpret_cast<const T*>(a.dh_in)[(((int64_t)n * a.nsb + sb) * KT + k) * 64 + lane];
 #pragma unroll
                 for (int o = 0; o < NOUT; ++o) {
                     hg[o][k] += g[o] * hn[k];

@@ -111,6 +111,15 @@ struct GruCore {
     // prnn_base_coop_kernel, starts the products before the input spin is known and must agree bit for bit).
     template <bool BIAS_LAST = false>
     static __device__ __forceinline__ void step(const char* lds, int sig, T (&h)[KT], int lane, int ablate = 0) {
+        step_impl(lds, sig, h, lane, ablate, BIAS_LAST);
+    }
+    // non-template entry for the stacked-layer cores (hipcc's host pass fails to resolve step<> from inside a second
+    // class template for T = double)
+    static __device__ __forceinline__ void step_plain(const char* lds, int sig, T (&h)[KT], int lane) {
+        step_impl(lds, sig, h, lane, 0, false);
+    }
+    // BIAS_LAST is a compile-time constant at every call site (forced inlining folds the branches)
+    static __device__ __forceinline__ void step_impl(const char* lds, int sig, T (&h)[KT], int lane, int ablate, const bool BIAS_LAST) {
         const int q = lane >> 4;
         // The weight image never changes, so the compiler would hoist all ~NT*KT fragment loads out of
         // the site loop and pin them in registers (1 wave/SIMD).  Re-read them from LDS every step.
@@ -257,18 +266,19 @@ struct GruCore {
 };
 
 // One step of a stacked GRU layer above the first (UpperLayout): x = new state of the layer below.
-template <int NFULL>
+template <int NFULL, typename T = float>
 struct UpperCore {
-    using U = UpperLayout<NFULL>;
-    using F = Frag<float>;
-    using A = Act<float>;
-    using V4 = F::V4;
-    static constexpr int KT = U::KT, NT = U::NT, NT2 = U::NT2, NG = U::NG;
+    using U = UpperLayout<NFULL, T>;
+    using F = Frag<T>;
+    using A = Act<T>;
+    using V4 = typename F::V4;
+    using VA = typename F::VA;
+    static constexpr int KT = U::KT, NT = U::NT, NT2 = U::NT2, NG = U::NG, VW = U::VW;
 
     template <bool XBLOCK>
-    static __device__ __forceinline__ void block(const char* lds, const float (&v)[KT], V4 (&acc)[NT2], int lane) {
-        const V4* av = reinterpret_cast<const V4*>(lds + (XBLOCK ? U::OFF_AX : U::OFF_AH)) + lane;
-        const float* ar = reinterpret_cast<const float*>(lds + (XBLOCK ? U::OFF_AXR : U::OFF_AHR)) + lane;
+    static __device__ __forceinline__ void block(const char* lds, const T (&v)[KT], V4 (&acc)[NT2], int lane) {
+        const VA* av = reinterpret_cast<const VA*>(lds + (XBLOCK ? U::OFF_AX : U::OFF_AH)) + lane;
+        const T* ar = reinterpret_cast<const T*>(lds + (XBLOCK ? U::OFF_AXR : U::OFF_AHR)) + lane;
         // block tile t -> accumulator tile: r, u unchanged; third group -> y (X block) or q (H block); mixed last
         auto dst = [](int t) { return t < 2 * NFULL ? t : t < 3 * NFULL ? (XBLOCK ? t + NFULL : t) : NT2 - 1; };
         constexpr int TC = 5;
@@ -276,37 +286,41 @@ struct UpperCore {
         for (int g = 0; g < NG; ++g) {
 #pragma unroll
             for (int t0 = 0; t0 < NT; t0 += TC) {
-                V4 a[TC];
+                VA a[TC];
 #pragma unroll
                 for (int t = 0; t < TC; ++t)
                     if (t0 + t < NT) a[t] = av[((t0 + t) * NG + g) * 64];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < VW; ++j)
 #pragma unroll
                     for (int t = 0; t < TC; ++t)
-                        if (t0 + t < NT) acc[dst(t0 + t)] = F::mfma(a[t][j], v[g * 4 + j], acc[dst(t0 + t)]);
+                        if (t0 + t < NT) acc[dst(t0 + t)] = F::mfma(a[t][j], v[g * VW + j], acc[dst(t0 + t)]);
             }
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[dst(t)] = F::mfma(ar[t * 64], v[KT - 1], acc[dst(t)]);
     }
 
-    // forward step that keeps this lane's gate values for the backward pass (q = h Wch + bch un-scaled)
-    static __device__ __forceinline__ void step_keep(const char* lds, const float (&x)[KT], const float (&h)[KT],
-                                                     float (&hn)[KT], float (&rg)[KT], float (&ug)[KT], float (&cc)[KT],
-                                                     float (&qv)[KT], int lane) {
+    static __device__ __forceinline__ void products(const char* lds, const T (&x)[KT], const T (&h)[KT], V4 (&acc)[NT2], int lane) {
         const int q = lane >> 4;
         asm volatile("" ::: "memory");
-        V4 acc[NT2];
         {
-            const char* b = lds + U::OFF_B + (size_t)q * 16;
+            const char* b = lds + U::OFF_B + (size_t)q * 4 * sizeof(T);
 #pragma unroll
-            for (int t = 0; t < NT2; ++t) acc[t] = *reinterpret_cast<const V4*>(b + (size_t)t * 64);
+            for (int t = 0; t < NT2; ++t) acc[t] = *reinterpret_cast<const V4*>(b + (size_t)t * 16 * sizeof(T));
         }
         block<true>(lds, x, acc, lane);
         asm volatile("" ::: "memory");
         block<false>(lds, h, acc, lane);
-        const float inv_cs = (float)(1.0 / A::kCandScale);
+    }
+
+    // forward step that keeps this lane's gate values for the backward pass (q = h Wch + bch un-scaled)
+    static __device__ __forceinline__ void step_keep(const char* lds, const T (&x)[KT], const T (&h)[KT],
+                                                     T (&hn)[KT], T (&rg)[KT], T (&ug)[KT], T (&cc)[KT],
+                                                     T (&qv)[KT], int lane) {
+        V4 acc[NT2];
+        products(lds, x, h, acc, lane);
+        const T inv_cs = (T)(1.0 / A::kCandScale);
 #pragma unroll
         for (int m = 0; m < NFULL; ++m)
 #pragma unroll
@@ -328,32 +342,23 @@ struct UpperCore {
         }
     }
 
-    static __device__ __forceinline__ void step(const char* lds, const float (&x)[KT], float (&h)[KT], int lane) {
-        const int q = lane >> 4;
-        asm volatile("" ::: "memory");
+    static __device__ __forceinline__ void step(const char* lds, const T (&x)[KT], T (&h)[KT], int lane) {
         V4 acc[NT2];
-        {
-            const char* b = lds + U::OFF_B + (size_t)q * 16;
-#pragma unroll
-            for (int t = 0; t < NT2; ++t) acc[t] = *reinterpret_cast<const V4*>(b + (size_t)t * 64);
-        }
-        block<true>(lds, x, acc, lane);
-        asm volatile("" ::: "memory");
-        block<false>(lds, h, acc, lane);
+        products(lds, x, h, acc, lane);
 #pragma unroll
         for (int m = 0; m < NFULL; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float rg = A::sigmoid_scaled(acc[m][r]);
-                const float ug = A::sigmoid_scaled(acc[NFULL + m][r]);
-                const float cc = A::tanh_scaled(acc[3 * NFULL + m][r] + rg * acc[2 * NFULL + m][r]);
+                const T rg = A::sigmoid_scaled(acc[m][r]);
+                const T ug = A::sigmoid_scaled(acc[NFULL + m][r]);
+                const T cc = A::tanh_scaled(acc[3 * NFULL + m][r] + rg * acc[2 * NFULL + m][r]);
                 h[4 * m + r] = cc + ug * (h[4 * m + r] - cc);
             }
         {
             const V4 a = acc[NT2 - 1];
-            const float rg = A::sigmoid_scaled(a[0]);
-            const float ug = A::sigmoid_scaled(a[1]);
-            const float cc = A::tanh_scaled(a[3] + rg * a[2]);
+            const T rg = A::sigmoid_scaled(a[0]);
+            const T ug = A::sigmoid_scaled(a[1]);
+            const T cc = A::tanh_scaled(a[3] + rg * a[2]);
             h[KT - 1] = cc + ug * (h[KT - 1] - cc);
         }
     }

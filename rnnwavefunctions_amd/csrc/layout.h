@@ -58,27 +58,28 @@ struct GruLayout {
     static constexpr size_t BYTES = ((OFF_BD + 32 + 15) / 16) * 16;
 };
 
-// Stacked GRU layers above the first (tf.nn.rnn_cell.MultiRNNCell, 1DTFIM/RNNwavefunction.py:32; f32 only):
+// Stacked GRU layers above the first (tf.nn.rnn_cell.MultiRNNCell, 1DTFIM/RNNwavefunction.py:32):
 // the input x is the new state of the layer below - already a B fragment - so one step is two blocks of
 // products into one set of accumulators,
 //   X block (K over x): rows r, u, y = x Wci + bci          H block (K over h): rows r, u, q = h Wch + bch
 // each shaped like the first layer's image (NT = 3 NFULL + 1 tiles: two/three full groups + the mixed tile, whose
 // register slots are 0: r, 1: u, 2: q (H block only), 3: y (X block only)).  Accumulator tiles: r | u | q | y | mixed.
-template <int NFULL_>
+template <int NFULL_, typename T = float>
 struct UpperLayout {
     static constexpr int NFULL = NFULL_;
     static constexpr int KT = 4 * NFULL + 1;
     static constexpr int NT = 3 * NFULL + 1;        // tiles per block
     static constexpr int NT2 = 4 * NFULL + 1;       // accumulator tiles
-    static constexpr int NG = NFULL;                // (KT - 1) / 4 full float4 vectors per (tile, lane)
+    static constexpr int VW = 16 / (int)sizeof(T);  // A values per 16-byte LDS vector
+    static constexpr int NG = (KT - 1) / VW;        // full vectors per (tile, lane)
     static constexpr size_t SZ_AVEC = (size_t)NT * NG * 64 * 16;
-    static constexpr size_t SZ_AREM = (size_t)NT * 64 * 4;
-    static constexpr size_t OFF_AX = 0;                         // [NT][NG][64] float4
-    static constexpr size_t OFF_AXR = OFF_AX + SZ_AVEC;         // [NT][64] float (kt = KT-1)
+    static constexpr size_t SZ_AREM = (size_t)NT * 64 * sizeof(T);
+    static constexpr size_t OFF_AX = 0;                         // [NT][NG][64] x 16 B
+    static constexpr size_t OFF_AXR = OFF_AX + SZ_AVEC;         // [NT][64] T (kt = KT-1)
     static constexpr size_t OFF_AH = OFF_AXR + SZ_AREM;
     static constexpr size_t OFF_AHR = OFF_AH + SZ_AVEC;
-    static constexpr size_t OFF_B = OFF_AHR + SZ_AREM;          // [NT2][4 q][4 r] float
-    static constexpr size_t BYTES = ((OFF_B + (size_t)NT2 * 64 + 15) / 16) * 16;
+    static constexpr size_t OFF_B = OFF_AHR + SZ_AREM;          // [NT2][4 q][4 r] T
+    static constexpr size_t BYTES = ((OFF_B + (size_t)NT2 * 16 * sizeof(T) + 15) / 16) * 16;
 };
 
 // row index inside a 16-row tile  <->  (lane quarter q of the C/D fragment, register r)

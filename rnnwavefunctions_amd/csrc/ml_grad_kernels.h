@@ -13,7 +13,7 @@
 
 namespace rnnwf {
 
-template <int NFULL, int NOUT = 1>
+template <int NFULL, int NOUT = 1, typename T = float>
 struct UpperGradLayout {
     static constexpr int KT = 4 * NFULL + 1;
     static constexpr int NT = 3 * NFULL + 1;
@@ -21,11 +21,12 @@ struct UpperGradLayout {
     static constexpr int PCOLS = 16 * (NT + NTO);         // as GradLayout: [gate rows in image order | dy]
     static constexpr int QCOLS = 32 * NTO;                // [x | h_{n-1} with the constant 1 in a spare slot]
     static constexpr int KB = 3 * KT;
-    static constexpr int KBG = (KB + 3) / 4;
-    static constexpr size_t SIDE_BYTES = (size_t)NTO * KBG * 64 * 16;    // [NTO][KBG][64] float4
+    static constexpr int VW = 16 / (int)sizeof(T);        // k-steps per 16-byte LDS vector
+    static constexpr int KBG = (KB + VW - 1) / VW;
+    static constexpr size_t SIDE_BYTES = (size_t)NTO * KBG * 64 * 16;    // [NTO][KBG][64] x 16 B
     static constexpr size_t BWD_BYTES = 2 * SIDE_BYTES;                  // H side (-> dh), X side (-> dx)
-    static constexpr int WD_Q = ((NOUT * KT + 3) / 4) * 4;               // GruLayout<float, NFULL, NOUT>::WD_Q
-    static constexpr size_t HEAD_BYTES = ((size_t)(4 * WD_Q + 8) * 4 + 15) / 16 * 16;   // [4 q][KT][NOUT] + bias
+    static constexpr int WD_Q = ((NOUT * KT + 3) / 4) * 4;               // GruLayout<T, NFULL, NOUT>::WD_Q
+    static constexpr size_t HEAD_BYTES = ((size_t)4 * WD_Q * sizeof(T) + 32 + 15) / 16 * 16;   // [4 q][KT][NOUT] + bias (OFF_WD .. end of the image)
     static constexpr int HEAD_ROW = 4 * KT + 4;                          // as GradLayout::HEAD_ROW
 };
 
@@ -36,24 +37,28 @@ struct UpperGradArgs {
     int32_t N, layer, hck_nl;
     int64_t ns, nsb;
     const uint32_t* bits;
-    const float* hck;          // [N][nsb][NL][KT][64]
+    const void* hck;           // [N][nsb][NL][KT][64] T
     const double* eloc;        // [ns] f64 (positive RNN) ...
     const float2* eloc_c;      // ... or [ns] complex64 (complex RNN)
     double mean_e, mean_im, inv_norm;
-    const float* dh_in;        // [N][nsb][KT][64] from the layer above (nullptr: top layer, head)
-    float* dx_out;             // [N][nsb][KT][64]
-    float* P;
-    float* Q;
-    float* head_grad;          // [NOUT][HEAD_ROW] (top layer)
+    const void* dh_in;         // [N][nsb][KT][64] T from the layer above (nullptr: top layer, head)
+    void* dx_out;              // [N][nsb][KT][64] T
+    void* P;
+    void* Q;
+    void* head_grad;           // [NOUT][HEAD_ROW] T (top layer)
 };
 
 // NOUT (top layer only): 1 = positive RNN head, 3 = complex RNN heads (the site terms of gru_bwd_kernel).
-template <int NFULL, int WAVES, bool TOP, int NOUT = 1>
+template <typename T, int NFULL, int WAVES, bool TOP, int NOUT = 1>
 __global__ void __launch_bounds__(WAVES * 64) gru_upper_bwd_kernel(UpperGradArgs a) {
-    using CU = UpperCore<NFULL>;
-    using G = UpperGradLayout<NFULL, NOUT>;
+    using CU = UpperCore<NFULL, T>;
+    using G = UpperGradLayout<NFULL, NOUT, T>;
     using V4 = typename CU::V4;
-    constexpr int KT = CU::KT, NT = G::NT;
+    using VA = typename CU::VA;
+    constexpr int KT = CU::KT, NT = G::NT, VW = G::VW;
+    const T* hck = reinterpret_cast<const T*>(a.hck);
+    const T* dh_in = reinterpret_cast<const T*>(a.dh_in);
+    T* head_grad = reinterpret_cast<T*>(a.head_grad);
     extern __shared__ __attribute__((aligned(16))) char lds[];
     {
         auto copy = [&](char* dst_, const void* src_, size_t bytes) {
@@ -72,60 +77,60 @@ __global__ void __launch_bounds__(WAVES * 64) gru_upper_bwd_kernel(UpperGradArgs
     const int64_t gw = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * WAVES;
     const int N = a.N;
-    const float* wd = reinterpret_cast<const float*>(lds + CU::U::BYTES + G::BWD_BYTES) + q * G::WD_Q;
-    const float* bd = reinterpret_cast<const float*>(lds + CU::U::BYTES + G::BWD_BYTES) + 4 * G::WD_Q;
-    float hg[NOUT][KT], gb[NOUT];
+    const T* wd = reinterpret_cast<const T*>(lds + CU::U::BYTES + G::BWD_BYTES) + q * G::WD_Q;
+    const T* bd = reinterpret_cast<const T*>(lds + CU::U::BYTES + G::BWD_BYTES) + 4 * G::WD_Q;
+    T hg[NOUT][KT], gb[NOUT];
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) {
-        gb[o] = 0.0f;
+        gb[o] = T(0);
 #pragma unroll
-        for (int k = 0; k < KT; ++k) hg[o][k] = 0.0f;
+        for (int k = 0; k < KT; ++k) hg[o][k] = T(0);
     }
     for (int64_t sb = gw; sb < a.nsb; sb += nw) {
         const int64_t s = sb * kChains + c;
         const bool valid = s < a.ns;
         const int64_t sc = valid ? s : a.ns - 1;
-        float w = 0.0f, w_im = 0.0f;
+        T w = T(0), w_im = T(0);
         if (TOP && valid) {
             if constexpr (NOUT == 1) {
-                w = (float)((a.eloc[sc] - a.mean_e) * a.inv_norm);
+                w = (T)((a.eloc[sc] - a.mean_e) * a.inv_norm);
             } else {
                 const float2 e = a.eloc_c[sc];
-                w = (float)(((double)e.x - a.mean_e) * a.inv_norm);
-                w_im = (float)(((double)e.y - a.mean_im) * a.inv_norm);
+                w = (T)(((double)e.x - a.mean_e) * a.inv_norm);
+                w_im = (T)(((double)e.y - a.mean_im) * a.inv_norm);
             }
         }
         auto spin = [&](int n) { return (int)((a.bits[(int64_t)(n >> 5) * a.ns + sc] >> (n & 31)) & 1); };
         int num_up = 0;                                   // complex RNN: up spins among sites < n (U(1) mask)
         if constexpr (TOP && NOUT == 3)
             for (int m = 0; m < N; ++m) num_up += spin(m);
-        float dh[KT];
+        T dh[KT];
 #pragma unroll
-        for (int k = 0; k < KT; ++k) dh[k] = 0.0f;
+        for (int k = 0; k < KT; ++k) dh[k] = T(0);
         for (int n = N - 1; n >= 0; --n) {
-            float x[KT], h[KT], hn[KT], rg[KT], ug[KT], cc[KT], qv[KT];
+            T x[KT], h[KT], hn[KT], rg[KT], ug[KT], cc[KT], qv[KT];
             {
-                const float* src = a.hck + ((((int64_t)n * a.nsb + sb) * a.hck_nl + a.layer - 1) * KT) * 64 + lane;
+                const T* src = hck + ((((int64_t)n * a.nsb + sb) * a.hck_nl + a.layer - 1) * KT) * 64 + lane;
 #pragma unroll
                 for (int k = 0; k < KT; ++k) x[k] = src[k * 64];
             }
             if (n > 0) {
-                const float* src = a.hck + ((((int64_t)(n - 1) * a.nsb + sb) * a.hck_nl + a.layer) * KT) * 64 + lane;
+                const T* src = hck + ((((int64_t)(n - 1) * a.nsb + sb) * a.hck_nl + a.layer) * KT) * 64 + lane;
 #pragma unroll
                 for (int k = 0; k < KT; ++k) h[k] = src[k * 64];
             } else {
 #pragma unroll
-                for (int k = 0; k < KT; ++k) h[k] = 0.0f;
+                for (int k = 0; k < KT; ++k) h[k] = T(0);
             }
             CU::step_keep(lds, x, h, hn, rg, ug, cc, qv, lane);
-            float g[NOUT];
+            T g[NOUT];
 #pragma unroll
-            for (int o = 0; o < NOUT; ++o) g[o] = 0.0f;
+            for (int o = 0; o < NOUT; ++o) g[o] = T(0);
             if (TOP) {
                 asm volatile("" ::: "memory");
-                float z[NOUT];
+                T z[NOUT];
 #pragma unroll
-                for (int o = 0; o < NOUT; ++o) z[o] = 0.0f;
+                for (int o = 0; o < NOUT; ++o) z[o] = T(0);
 #pragma unroll
                 for (int k = 0; k < KT; ++k)
 #pragma unroll
@@ -135,9 +140,9 @@ __global__ void __launch_bounds__(WAVES * 64) gru_upper_bwd_kernel(UpperGradArgs
                     z[o] += __shfl_xor(z[o], 16); z[o] += __shfl_xor(z[o], 32); z[o] += bd[o];
                 }
                 const int sig = spin(n);
-                const float p1 = 1.0f - prob0(z[0]);
+                const T p1 = T(1) - prob0(z[0]);
                 if constexpr (NOUT == 1) {
-                    g[0] = w * ((float)sig - p1);                // d log p(sig) / d(z1 - z0) = sig - p1
+                    g[0] = w * ((T)sig - p1);                // d log p(sig) / d(z1 - z0) = sig - p1
                 } else {                                         // the site terms of gru_bwd_kernel<.., 3>
                     num_up -= sig;
                     bool both = true;
@@ -145,21 +150,21 @@ __global__ void __launch_bounds__(WAVES * 64) gru_upper_bwd_kernel(UpperGradArgs
                         const int base = N / 2 - 1;
                         both = (base - (n - num_up) >= 0) && (base - num_up >= 0);
                     }
-                    g[0] = both ? 0.5f * w * ((float)sig - p1) : 0.0f;
-                    const float zs = sig ? z[2] : z[1];
-                    const float den = 1.0f + fabsf(zs);
-                    const float gp = w_im * 3.14159265358979323846f / (den * den);
-                    g[1] = sig ? 0.0f : gp;
-                    g[2] = sig ? gp : 0.0f;
+                    g[0] = both ? T(0.5) * w * ((T)sig - p1) : T(0);
+                    const T zs = sig ? z[2] : z[1];
+                    const T den = T(1) + (zs < T(0) ? -zs : zs);
+                    const T gp = w_im * T(3.14159265358979323846) / (den * den);
+                    g[1] = sig ? T(0) : gp;
+                    g[2] = sig ? gp : T(0);
                 }
 #pragma unroll
                 for (int o = 0; o < NOUT; ++o) gb[o] += g[o];
             }
-            float dpH[4 * G::KBG], dpX[4 * G::KBG];
-            float dy[KT];
+            T dpH[VW * G::KBG], dpX[VW * G::KBG];
+            T dy[KT];
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
-                float d = dh[k];
+                T d = dh[k];
                 if (TOP) {
 #pragma unroll
                     for (int o = 0; o < NOUT; ++o) {
@@ -167,21 +172,21 @@ __global__ void __launch_bounds__(WAVES * 64) gru_upper_bwd_kernel(UpperGradArgs
                         d += g[o] * wd[k * NOUT + o];
                     }
                 } else {
-                    d += a.dh_in[(((int64_t)n * a.nsb + sb) * KT + k) * 64 + lane];
+                    d += dh_in[(((int64_t)n * a.nsb + sb) * KT + k) * 64 + lane];
                 }
-                const float du = d * (h[k] - cc[k]);
-                const float dc = d * (1.0f - ug[k]);
+                const T du = d * (h[k] - cc[k]);
+                const T dc = d * (T(1) - ug[k]);
                 dh[k] = d * ug[k];
-                dy[k] = dc * (1.0f - cc[k] * cc[k]);
-                dpH[k] = dpX[k] = dy[k] * qv[k] * rg[k] * (1.0f - rg[k]);     // d a_r
-                dpH[KT + k] = dpX[KT + k] = du * ug[k] * (1.0f - ug[k]);     // d a_u
+                dy[k] = dc * (T(1) - cc[k] * cc[k]);
+                dpH[k] = dpX[k] = dy[k] * qv[k] * rg[k] * (T(1) - rg[k]);     // d a_r
+                dpH[KT + k] = dpX[KT + k] = du * ug[k] * (T(1) - ug[k]);     // d a_u
                 dpH[2 * KT + k] = dy[k] * rg[k];                             // d q
                 dpX[2 * KT + k] = dy[k];                                     // d y
             }
 #pragma unroll
-            for (int k = G::KB; k < 4 * G::KBG; ++k) dpH[k] = dpX[k] = 0.0f;
+            for (int k = G::KB; k < VW * G::KBG; ++k) dpH[k] = dpX[k] = T(0);
             if (valid) {
-                float* prow = a.P + ((int64_t)n * a.ns + s) * G::PCOLS + 4 * q;
+                T* prow = reinterpret_cast<T*>(a.P) + ((int64_t)n * a.ns + s) * G::PCOLS + 4 * q;
 #pragma unroll
                 for (int m = 0; m < NFULL; ++m) {
 #pragma unroll
@@ -190,40 +195,40 @@ __global__ void __launch_bounds__(WAVES * 64) gru_upper_bwd_kernel(UpperGradArgs
                             V4{dpH[gt * KT + 4 * m], dpH[gt * KT + 4 * m + 1], dpH[gt * KT + 4 * m + 2], dpH[gt * KT + 4 * m + 3]};
                     *reinterpret_cast<V4*>(prow + (NT + m) * 16) = V4{dy[4 * m], dy[4 * m + 1], dy[4 * m + 2], dy[4 * m + 3]};
                 }
-                *reinterpret_cast<V4*>(prow + (NT - 1) * 16) = V4{dpH[KT - 1], dpH[2 * KT - 1], dpH[3 * KT - 1], 0.0f};
-                *reinterpret_cast<V4*>(prow + (NT + NFULL) * 16) = V4{dy[KT - 1], 0.0f, 0.0f, 0.0f};
-                float* qrow = a.Q + ((int64_t)n * a.ns + s) * G::QCOLS + 4 * q;
+                *reinterpret_cast<V4*>(prow + (NT - 1) * 16) = V4{dpH[KT - 1], dpH[2 * KT - 1], dpH[3 * KT - 1], T(0)};
+                *reinterpret_cast<V4*>(prow + (NT + NFULL) * 16) = V4{dy[KT - 1], T(0), T(0), T(0)};
+                T* qrow = reinterpret_cast<T*>(a.Q) + ((int64_t)n * a.ns + s) * G::QCOLS + 4 * q;
 #pragma unroll
                 for (int m = 0; m < NFULL; ++m) {
                     *reinterpret_cast<V4*>(qrow + m * 16) = V4{x[4 * m], x[4 * m + 1], x[4 * m + 2], x[4 * m + 3]};
                     *reinterpret_cast<V4*>(qrow + (G::NTO + m) * 16) = V4{h[4 * m], h[4 * m + 1], h[4 * m + 2], h[4 * m + 3]};
                 }
-                *reinterpret_cast<V4*>(qrow + NFULL * 16) = V4{x[KT - 1], 0.0f, 0.0f, 0.0f};
-                *reinterpret_cast<V4*>(qrow + (G::NTO + NFULL) * 16) = V4{h[KT - 1], q == 0 ? 1.0f : 0.0f, 0.0f, 0.0f};
+                *reinterpret_cast<V4*>(qrow + NFULL * 16) = V4{x[KT - 1], T(0), T(0), T(0)};
+                *reinterpret_cast<V4*>(qrow + (G::NTO + NFULL) * 16) = V4{h[KT - 1], q == 0 ? T(1) : T(0), T(0), T(0)};
             }
             V4 accH[G::NTO], accX[G::NTO];
 #pragma unroll
-            for (int t = 0; t < G::NTO; ++t) accH[t] = accX[t] = V4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < G::NTO; ++t) accH[t] = accX[t] = V4{T(0), T(0), T(0), T(0)};
             asm volatile("" ::: "memory");
-            const V4* abh = reinterpret_cast<const V4*>(lbh) + lane;
-            const V4* abx = reinterpret_cast<const V4*>(lbx) + lane;
+            const VA* abh = reinterpret_cast<const VA*>(lbh) + lane;
+            const VA* abx = reinterpret_cast<const VA*>(lbx) + lane;
 #pragma unroll
             for (int kg = 0; kg < G::KBG; ++kg) {
-                V4 afh[G::NTO], afx[G::NTO];
+                VA afh[G::NTO], afx[G::NTO];
 #pragma unroll
                 for (int t = 0; t < G::NTO; ++t) {
                     afh[t] = abh[(t * G::KBG + kg) * 64];
                     afx[t] = abx[(t * G::KBG + kg) * 64];
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < VW; ++j)
 #pragma unroll
                     for (int t = 0; t < G::NTO; ++t) {
-                        accH[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(afh[t][j], dpH[4 * kg + j], accH[t], 0, 0, 0);
-                        accX[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(afx[t][j], dpX[4 * kg + j], accX[t], 0, 0, 0);
+                        accH[t] = Frag<T>::mfma(afh[t][j], dpH[VW * kg + j], accH[t]);
+                        accX[t] = Frag<T>::mfma(afx[t][j], dpX[VW * kg + j], accX[t]);
                     }
             }
-            float* dxo = a.dx_out + (((int64_t)n * a.nsb + sb) * KT) * 64 + lane;
+            T* dxo = reinterpret_cast<T*>(a.dx_out) + (((int64_t)n * a.nsb + sb) * KT) * 64 + lane;
 #pragma unroll
             for (int m = 0; m < NFULL; ++m)
 #pragma unroll
@@ -240,13 +245,13 @@ __global__ void __launch_bounds__(WAVES * 64) gru_upper_bwd_kernel(UpperGradArgs
         for (int o = 0; o < NOUT; ++o) {
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
-                float v = hg[o][k];
+                T v = hg[o][k];
                 v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-                if (c == 0) atomicAdd(&a.head_grad[o * G::HEAD_ROW + 4 * k + q], v);
+                if (c == 0) atomicAdd(&head_grad[o * G::HEAD_ROW + 4 * k + q], v);
             }
-            float v = gb[o];
+            T v = gb[o];
             v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-            if (c == 0 && q == 0) atomicAdd(&a.head_grad[o * G::HEAD_ROW + 4 * KT], v);
+            if (c == 0 && q == 0) atomicAdd(&head_grad[o * G::HEAD_ROW + 4 * KT], v);
         }
     }
 }

@@ -3,18 +3,19 @@
 //
 // Same decomposition as gru_kernels.h.  Every layer's state stays in registers in B-fragment order; the new
 // state of layer l is directly the X operand of layer l+1 (gru_core.h, UpperCore), the head reads the top layer.
-// LDS image: [GruLayout<float, NFULL, 1> | UpperLayout<NFULL> x (NL-1)].
-//   hck [N][nsb][NL][KT][64] f32   states of all layers after site n (all N sites: the layer-wise gradient of
+// T = float (1D positive RNN) or double (2DTFIM_1DRNN, units=[num_units]*num_layers at Training1DRNN_2DTFIM.py:94).
+// LDS image: [GruLayout<T, NFULL, 1> | UpperLayout<NFULL, T> x (NL-1)].
+//   hck [N][nsb][NL][KT][64] T     states of all layers after site n (all N sites: the layer-wise gradient of
 //                                  ml_grad_kernels.h needs the last site's lower-layer states too)
 #pragma once
 #include "gru_kernels.h"
 
 namespace rnnwf {
 
-template <int NFULL, int NL>
+template <int NFULL, int NL, typename T = float>
 struct MlCore {
-    using C0 = GruCore<float, NFULL, 1>;
-    using CU = UpperCore<NFULL>;
+    using C0 = GruCore<T, NFULL, 1>;
+    using CU = UpperCore<NFULL, T>;
     static constexpr int KT = C0::KT;
     static constexpr size_t BYTES = C0::L::BYTES + (size_t)(NL - 1) * CU::U::BYTES;
 
@@ -25,19 +26,19 @@ struct MlCore {
         __syncthreads();
     }
     // all layers for one site; returns the head logit difference of the top layer
-    static __device__ __forceinline__ float step(const char* lds, int sig_in, float (&h)[NL][KT], int lane) {
-        C0::step(lds, sig_in, h[0], lane);
+    static __device__ __forceinline__ T step(const char* lds, int sig_in, T (&h)[NL][KT], int lane) {
+        C0::step_plain(lds, sig_in, h[0], lane);
 #pragma unroll
         for (int l = 1; l < NL; ++l) CU::step(lds + C0::L::BYTES + (size_t)(l - 1) * CU::U::BYTES, h[l - 1], h[l], lane);
-        float z[1];
+        T z[1];
         C0::head(lds, h[NL - 1], lane, z);
         return z[0];
     }
 };
 
-template <int NFULL, int NL, int WAVES>
+template <typename T, int NFULL, int NL, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) prnn_ml_base_kernel(PrnnArgs a) {
-    using M = MlCore<NFULL, NL>;
+    using M = MlCore<NFULL, NL, T>;
     constexpr int KT = M::KT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     M::stage(lds, a.wimg);
@@ -49,23 +50,23 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_ml_base_kernel(PrnnArgs a) {
         const int64_t s = sb * kChains + c;
         const bool valid = s < a.ns;
         const int64_t sc = valid ? s : a.ns - 1;
-        float h[NL][KT];
+        T h[NL][KT];
 #pragma unroll
         for (int l = 0; l < NL; ++l)
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) h[l][kt] = 0.0f;
+            for (int kt = 0; kt < KT; ++kt) h[l][kt] = T(0);
         int sig_in = -1;
         uint32_t word = 0;
         double cum = 0.0;
         for (int n = 0; n < N; ++n) {
             if (!a.sampling && (n & 31) == 0) word = a.bits[(int64_t)(n >> 5) * a.ns + sc];
-            const float d = M::step(lds, sig_in, h, lane);
-            float lp0, lp1;
+            const T d = M::step(lds, sig_in, h, lane);
+            T lp0, lp1;
             log_softmax2(d, lp0, lp1);
             int sig;
             if (a.sampling) {
                 const float u = philox_uniform(a.seed, a.step, (uint64_t)(a.sample_offset + sc), n);
-                sig = (u < prob0(d)) ? 0 : 1;
+                sig = ((T)u < prob0(d)) ? 0 : 1;
                 word |= (uint32_t)sig << (n & 31);
                 if (((n & 31) == 31 || n == N - 1) && valid && q == 0) a.bits[(int64_t)(n >> 5) * a.ns + s] = word;
                 if ((n & 31) == 31) word = 0;
@@ -79,7 +80,7 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_ml_base_kernel(PrnnArgs a) {
             }
             cum += lsel;
             if (a.hck) {
-                float* dst = reinterpret_cast<float*>(a.hck) + (((int64_t)n * a.nsb + sb) * NL * KT) * 64 + lane;
+                T* dst = reinterpret_cast<T*>(a.hck) + (((int64_t)n * a.nsb + sb) * NL * KT) * 64 + lane;
 #pragma unroll
                 for (int l = 0; l < NL; ++l)
 #pragma unroll
@@ -94,9 +95,9 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_ml_base_kernel(PrnnArgs a) {
     }
 }
 
-template <int NFULL, int NL, int WAVES>
+template <typename T, int NFULL, int NL, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) prnn_ml_flip_kernel(PrnnArgs a) {
-    using M = MlCore<NFULL, NL>;
+    using M = MlCore<NFULL, NL, T>;
     constexpr int KT = M::KT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     M::stage(lds, a.wimg);
@@ -110,9 +111,9 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_ml_flip_kernel(PrnnArgs a) {
         const int64_t s = sb * kChains + c;
         const bool valid = s < a.ns;
         const int64_t sc = valid ? s : a.ns - 1;
-        float h[NL][KT];
+        T h[NL][KT];
         {
-            const float* src = reinterpret_cast<const float*>(a.hck) + (((int64_t)i * a.nsb + sb) * NL * KT) * 64 + lane;
+            const T* src = reinterpret_cast<const T*>(a.hck) + (((int64_t)i * a.nsb + sb) * NL * KT) * 64 + lane;
 #pragma unroll
             for (int l = 0; l < NL; ++l)
 #pragma unroll
@@ -123,8 +124,8 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_ml_flip_kernel(PrnnArgs a) {
         double lp = 0.0;
         for (int n = i + 1; n < N; ++n) {
             const int sig = spin(n);
-            const float d = M::step(lds, sig_in, h, lane);
-            float lp0, lp1;
+            const T d = M::step(lds, sig_in, h, lane);
+            T lp0, lp1;
             log_softmax2(d, lp0, lp1);
             lp += (double)(sig ? lp1 : lp0);
             sig_in = sig;

@@ -132,10 +132,10 @@ inline void fill_f64_tables(double* t) {
     }
 }
 
-// Image of GRU layer `layer` >= 1 (input = state of the layer below, dimension H), UpperLayout<NFULL>.
-template <int NFULL>
+// Image of GRU layer `layer` >= 1 (input = state of the layer below, dimension H), UpperLayout<NFULL, T>.
+template <int NFULL, typename T = float>
 std::vector<char> pack_upper_image(const rnnwf_handle* h, int layer) {
-    using U = UpperLayout<NFULL>;
+    using U = UpperLayout<NFULL, T>;
     const int H = h->H;
     std::vector<char> img(U::BYTES, 0);
     const std::string pre = "multi_rnn_cell/cell_" + std::to_string(layer) + "/cudnn_compatible_gru_cell/";
@@ -145,7 +145,7 @@ std::vector<char> pack_upper_image(const rnnwf_handle* h, int layer) {
     const auto& bci = pv(h, pre + "candidate/input_projection/bias");
     const auto& Wch = pv(h, pre + "candidate/hidden_projection/kernel");  // [H, H]
     const auto& bch = pv(h, pre + "candidate/hidden_projection/bias");
-    const double sg = PackScale<float>::gate, sc = PackScale<float>::cand;
+    const double sg = PackScale<T>::gate, sc = PackScale<T>::cand;
     // gate ids: 0 r, 1 u, 2 q (hidden candidate), 3 y (input candidate)
     auto decode = [&](bool xblock, int tile, int q, int r, int& gate, int& unit) -> bool {
         if (tile < 3 * NFULL) {
@@ -169,23 +169,23 @@ std::vector<char> pack_upper_image(const rnnwf_handle* h, int layer) {
     };
     for (int blk = 0; blk < 2; ++blk) {
         const bool xb = blk == 0;
-        float* avec = reinterpret_cast<float*>(img.data() + (xb ? U::OFF_AX : U::OFF_AH));
-        float* arem = reinterpret_cast<float*>(img.data() + (xb ? U::OFF_AXR : U::OFF_AHR));
+        T* avec = reinterpret_cast<T*>(img.data() + (xb ? U::OFF_AX : U::OFF_AH));
+        T* arem = reinterpret_cast<T*>(img.data() + (xb ? U::OFF_AXR : U::OFF_AHR));
         for (int tile = 0; tile < U::NT; ++tile)
             for (int row = 0; row < 16; ++row) {
                 int q, r, gate, unit;
-                row_to_qr<float>(row, q, r);
+                row_to_qr<T>(row, q, r);
                 if (!decode(xb, tile, q, r, gate, unit)) continue;
                 for (int kq = 0; kq < 4; ++kq) {
                     const int lane = (kq << 4) | row;
                     for (int g = 0; g < U::NG; ++g)
-                        for (int j = 0; j < 4; ++j)
-                            avec[(((size_t)tile * U::NG + g) * 64 + lane) * 4 + j] = (float)wt(xb, gate, unit, 4 * (g * 4 + j) + kq);
-                    arem[(size_t)tile * 64 + lane] = (float)wt(xb, gate, unit, 4 * (U::KT - 1) + kq);
+                        for (int j = 0; j < U::VW; ++j)
+                            avec[(((size_t)tile * U::NG + g) * 64 + lane) * U::VW + j] = (T)wt(xb, gate, unit, 4 * (g * U::VW + j) + kq);
+                    arem[(size_t)tile * 64 + lane] = (T)wt(xb, gate, unit, 4 * (U::KT - 1) + kq);
                 }
             }
     }
-    float* b = reinterpret_cast<float*>(img.data() + U::OFF_B);
+    T* b = reinterpret_cast<T*>(img.data() + U::OFF_B);
     for (int t = 0; t < U::NT2; ++t)
         for (int q = 0; q < 4; ++q)
             for (int r = 0; r < 4; ++r) {
@@ -193,7 +193,7 @@ std::vector<char> pack_upper_image(const rnnwf_handle* h, int layer) {
                 const int unit = t < 4 * NFULL ? 16 * (t % NFULL) + 4 * r + q : 16 * NFULL + q;
                 if (unit >= H) continue;
                 const double v = gate == 0 ? sg * bg[unit] : gate == 1 ? sg * bg[H + unit] : gate == 2 ? sc * bch[unit] : sc * bci[unit];
-                b[t * 16 + q * 4 + r] = (float)v;
+                b[t * 16 + q * 4 + r] = (T)v;
             }
     return img;
 }

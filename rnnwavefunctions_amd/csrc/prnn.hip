@@ -63,42 +63,42 @@ struct Launch {
     static double mfma_flops_per_step() { return (double)L::NT * L::KT * 2048.0; }
 };
 
-// stacked layers (f32): same interface, kernels of ml_kernels.h
-template <int NFULL, int NL, int WAVES>
+// stacked layers: same interface, kernels of ml_kernels.h
+template <typename T, int NFULL, int NL, int WAVES>
 struct MLaunchL {
-    using M = MlCore<NFULL, NL>;
+    using M = MlCore<NFULL, NL, T>;
     static int blocks_per_cu(rnnwf_handle* h, const void* fn, int* out) { return rnnwf::blocks_per_cu(h, fn, WAVES * 64, M::BYTES, out); }
     static int base(rnnwf_handle* h, const PrnnArgs& a) {
-        const void* fn = (const void*)prnn_ml_base_kernel<NFULL, NL, WAVES>;
+        const void* fn = (const void*)prnn_ml_base_kernel<T, NFULL, NL, WAVES>;
         int bpc = 0;
         if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
         const int64_t need = (a.nsb + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
         TimedLaunch tl(h, 0);
-        prnn_ml_base_kernel<NFULL, NL, WAVES><<<grid, WAVES * 64, M::BYTES, h->stream>>>(a);
+        prnn_ml_base_kernel<T, NFULL, NL, WAVES><<<grid, WAVES * 64, M::BYTES, h->stream>>>(a);
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }
     static int flip(rnnwf_handle* h, const PrnnArgs& a) {
-        const void* fn = (const void*)prnn_ml_flip_kernel<NFULL, NL, WAVES>;
+        const void* fn = (const void*)prnn_ml_flip_kernel<T, NFULL, NL, WAVES>;
         int bpc = 0;
         if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
         const int64_t need = (a.ntiles + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
         TimedLaunch tl(h, 1);
-        prnn_ml_flip_kernel<NFULL, NL, WAVES><<<grid, WAVES * 64, M::BYTES, h->stream>>>(a);
+        prnn_ml_flip_kernel<T, NFULL, NL, WAVES><<<grid, WAVES * 64, M::BYTES, h->stream>>>(a);
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }
     static std::vector<char> pack(const rnnwf_handle* h) {
-        std::vector<char> img = pack_gru_image<float, NFULL, 1>(h);
+        std::vector<char> img = pack_gru_image<T, NFULL, 1>(h);
         for (int l = 1; l < NL; ++l) {
-            const std::vector<char> up = pack_upper_image<NFULL>(h, l);
+            const std::vector<char> up = pack_upper_image<NFULL, T>(h, l);
             img.insert(img.end(), up.begin(), up.end());
         }
         return img;
     }
-    static size_t hck_bytes_per_block() { return (size_t)NL * M::KT * 64 * sizeof(float); }
+    static size_t hck_bytes_per_block() { return (size_t)NL * M::KT * 64 * sizeof(T); }
     static double mfma_flops_per_step() {
         return ((double)M::C0::L::NT + 2.0 * (NL - 1) * M::CU::U::NT) * M::KT * 2048.0;
     }
@@ -107,16 +107,25 @@ struct MLaunchL {
 // one place that maps (dtype, NFULL, layers) to an instantiation
 #define PRNN_DISPATCH(h, EXPR)                                                              \
     do {                                                                                    \
-        if ((h)->NL == 2) {                                                                 \
+        if ((h)->NL == 2 && (h)->f64) {                                                     \
             switch ((h)->NFULL) {                                                           \
-                case 1: { using K = MLaunchL<1, 2, 4>; EXPR; }                              \
-                case 2: { using K = MLaunchL<2, 2, 4>; EXPR; }                              \
-                case 3: { using K = MLaunchL<3, 2, 8>; EXPR; }                              \
+                case 1: { using K = MLaunchL<double, 1, 2, 4>; EXPR; }                      \
+                case 2: { using K = MLaunchL<double, 2, 2, 8>; EXPR; }                      \
+            }                                                                               \
+        } else if ((h)->NL == 3 && (h)->f64) {                                              \
+            switch ((h)->NFULL) {                                                           \
+                case 1: { using K = MLaunchL<double, 1, 3, 4>; EXPR; }                      \
+            }                                                                               \
+        } else if ((h)->NL == 2) {                                                          \
+            switch ((h)->NFULL) {                                                           \
+                case 1: { using K = MLaunchL<float, 1, 2, 4>; EXPR; }                       \
+                case 2: { using K = MLaunchL<float, 2, 2, 4>; EXPR; }                       \
+                case 3: { using K = MLaunchL<float, 3, 2, 8>; EXPR; }                       \
             }                                                                               \
         } else if ((h)->NL == 3) {                                                          \
             switch ((h)->NFULL) {                                                           \
-                case 1: { using K = MLaunchL<1, 3, 4>; EXPR; }                              \
-                case 2: { using K = MLaunchL<2, 3, 8>; EXPR; }                              \
+                case 1: { using K = MLaunchL<float, 1, 3, 4>; EXPR; }                       \
+                case 2: { using K = MLaunchL<float, 2, 3, 8>; EXPR; }                       \
             }                                                                               \
         } else if (!(h)->f64) {                                                             \
             switch ((h)->NFULL) {                                                           \

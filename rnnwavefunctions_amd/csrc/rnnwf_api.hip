@@ -128,16 +128,18 @@ extern "C" int rnnwf_create(const rnnwf_config* cfg, rnnwf_handle** out) {
         return bad("rnnwf_create: len(units) must be 1..3");
     if (cfg->units[0] < 1) return bad("rnnwf_create: units[0] must be positive");
     if (cfg->num_layers > 1) {
-        // MultiRNNCell stacks (1DTFIM/RNNwavefunction.py:32, J1J2/ComplexRNNwavefunction.py:40): f32 models, equal widths,
-        // image must fit LDS
-        if (cfg->model != RNNWF_MODEL_GRU1D && cfg->model != RNNWF_MODEL_GRU1D_PARITY && cfg->model != RNNWF_MODEL_CRNN_U1)
-            return bad("rnnwf_create: stacked layers (len(units) > 1) are implemented for the 1D GRU wave functions in float32 "
-                       "(positive, parity-symmetric, complex) only");
+        // MultiRNNCell stacks (1DTFIM/RNNwavefunction.py:32, J1J2/ComplexRNNwavefunction.py:40,
+        // 2DTFIM_1DRNN/RNNwavefunction.py): GRU models, equal widths, the images of all layers must fit LDS
+        if (cfg->model == RNNWF_MODEL_MDRNN2D)
+            return bad("rnnwf_create: the 2D RNN has one layer (the reference: 'num_layers is not supported yet', 2DTFIM_2DRNN/run_2dTFIM.py:9)");
         for (int l = 1; l < cfg->num_layers; ++l)
             if (cfg->units[l] != cfg->units[0]) return bad("rnnwf_create: stacked layers must have equal num_units");
-        const int limit = cfg->num_layers == 2 ? 52 : 36;
-        if (cfg->units[0] > limit)
+        if (cfg->model == RNNWF_MODEL_GRU1D_F64) {
+            if (cfg->units[0] > (cfg->num_layers == 2 ? 36 : 20))
+                return bad("rnnwf_create: stacked float64 layers: num_units <= 36 (2 layers) / 20 (3 layers), the LDS budget of the weight images");
+        } else if (cfg->units[0] > (cfg->num_layers == 2 ? 52 : 36)) {
             return bad("rnnwf_create: stacked layers: num_units <= 52 (2 layers) / 36 (3 layers), the LDS budget of the weight images");
+        }
     }
     const bool two_d = cfg->model == RNNWF_MODEL_MDRNN2D || cfg->model == RNNWF_MODEL_GRU1D_F64;
     if (!two_d && cfg->ny != 1) return bad("rnnwf_create: ny must be 1 for the 1D models");

@@ -271,8 +271,8 @@ def run_2DTFIM_1DRNN(numsteps=2 * 10 ** 4, systemsize_x=5, systemsize_y=5, Bx=+2
     """Train the float64 1D GRU wave function over the raster path of the square lattice; learning rate
     1 / (1/lr + it/10)  (Training1DRNN_2DTFIM.py:231).  The reference seeds numpy / TF with `seed` but builds the
     wave function with its class default seed 111 (:104); the initial weights here follow the latter."""
-    if num_layers != 1:
-        raise ValueError("only num_layers = 1 is implemented on gfx950 (the reference's run scripts use 1)")
+    if not 1 <= num_layers <= 3:
+        raise ValueError("num_layers must be 1..3 (stacked float64 layers: num_units <= 36 for 2, <= 20 for 3)")
     Nx, Ny = systemsize_x, systemsize_y
     lr = np.float64(learningrate)
     units = [num_units] * num_layers

@@ -173,6 +173,29 @@ def test_gru_f64_on_2d_lattice_matches_reference_golden(golden_estimators):
     assert np.allclose(e, g["g4c_eloc"], rtol=1e-10)
 
 
+@pytest.mark.parametrize("Nx,Ny,H,L", [(3, 4, 7, 2), (4, 4, 20, 2), (3, 3, 36, 2), (4, 3, 10, 3), (3, 3, 20, 3)])
+def test_stacked_gru_f64_on_2d_lattice_matches_oracle(Nx, Ny, H, L):
+    """2DTFIM_1DRNN with units=[num_units]*num_layers (Training1DRNN_2DTFIM.py:94): log-probabilities, the sampler's
+    stream and the 2D local energies against the float64 oracle."""
+    from rnnwavefunctions_amd import _lib
+    N = Nx * Ny
+    prm = P.randomize_biases(P.scale_kernels(P.init_gru_params([H] * L, seed=H + L, dtype=np.float64), 1.5), H)
+    wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D_F64, Nx, Ny, (H,) * L)
+    wf.set_params(prm, scope=SCOPE)
+    rng = np.random.RandomState(H)
+    s = rng.randint(0, 2, size=(37, N))
+    lp = wf.log_prob(s)
+    ref = M.prnn_log_probability(prm, s, dtype=np.float64)
+    print("stacked f64 L=%d H=%d: max |lp - oracle| = %.2e" % (L, H, np.abs(lp - ref).max()))
+    assert np.allclose(lp, ref, rtol=0, atol=1e-11 * N)
+    smp = wf.sample(200, seed=9, step=1).reshape(200, N)
+    assert np.allclose(wf.log_prob(smp), M.prnn_log_probability(prm, smp, dtype=np.float64), rtol=0, atol=1e-11 * N)
+    Jz = np.ones((Nx, Ny))
+    e = wf.tfim_eloc(smp, Jz, 2.0)
+    e_ref = E.ising2d_local_energies(Jz, 2.0, Nx, Ny, smp, lambda x: M.prnn_log_probability(prm, x, dtype=np.float64))
+    assert np.allclose(e, e_ref, rtol=1e-9)
+
+
 def test_vmc_step_is_sample_plus_eloc_plus_moments():
     from rnnwavefunctions_amd import _lib
     N, H, ns = 30, 50, 333
@@ -402,8 +425,10 @@ def test_stacked_layers_limits_and_facade():
         _lib.NativeWavefunction(_lib.MODEL_GRU1D, 10, 1, (20, 10))
     with pytest.raises(ValueError, match="LDS budget"):
         _lib.NativeWavefunction(_lib.MODEL_GRU1D, 10, 1, (64, 64))
-    with pytest.raises(ValueError, match="float32"):            # the float64 raster GRU and the MDRNN: one layer
-        _lib.NativeWavefunction(_lib.MODEL_GRU1D_F64, 4, 4, (10, 10))
+    with pytest.raises(ValueError, match="one layer"):          # the reference: "num_layers is not supported yet"
+        _lib.NativeWavefunction(_lib.MODEL_MDRNN2D, 4, 4, (10, 10))
+    with pytest.raises(ValueError, match="float64 layers"):
+        _lib.NativeWavefunction(_lib.MODEL_GRU1D_F64, 4, 4, (40, 40))
     wf = RNNwavefunction(10, cell="CudnnCompatibleGRUCell", units=[10, 10], seed=111)
     # layer 0: 12*20 + 20 + 2*10 + 10 + 10*10 + 10 = 400; layer 1: 20*20 + 20 + 10*10 + 10 + 10*10 + 10 = 640; head 22
     assert wf.num_params() == 400 + 640 + 22

@@ -185,6 +185,41 @@ def test_gru_f64_gradient_matches_finite_differences_of_the_oracle(Nx, Ny, H, ns
     assert worst < 1e-6
 
 
+@pytest.mark.parametrize("Nx,Ny,H,L,ns", [(3, 3, 6, 2, 64), (4, 3, 20, 2, 48), (3, 3, 36, 2, 32), (3, 3, 10, 3, 40), (3, 2, 20, 3, 24)])
+def test_stacked_gru_f64_gradient_matches_finite_differences_of_the_oracle(Nx, Ny, H, L, ns):
+    from rnnwavefunctions_amd import _lib
+    from rnnwavefunctions_amd.training import cost_gradient
+    prm = P.randomize_biases(P.scale_kernels(P.init_gru_params([H] * L, seed=H + L, dtype=np.float64), 1.5), H + 1)
+    wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D_F64, Nx, Ny, (H,) * L)
+    wf.set_params(prm, scope=SCOPE)
+    out = wf.vmc_step(ns, seed=3, step=0, couplings=np.append(np.ones(Nx * Ny), 2.0), want_samples=True, want_eloc=True)
+    s, e = out["samples"].reshape(ns, Nx * Ny), out["eloc"]
+    grads = cost_gradient(wf, prm, SCOPE, e.mean(), ns)
+    assert set(grads) == set(prm)
+    prm64 = {k: v.copy() for k, v in prm.items()}
+
+    def cost():
+        lp = M.prnn_log_probability(prm64, s, dtype=np.float64)
+        return np.mean(lp * e) - np.mean(e) * np.mean(lp)
+
+    worst = _fd_check(grads, prm64, cost)
+    print("stacked GRU f64 L=%d %dx%d H=%d: max |grad - FD| / max|grad| = %.2e" % (L, Nx, Ny, H, worst))
+    assert worst < 1e-6
+
+
+def test_run_2dtfim_1drnn_with_two_layers_trains():
+    """run_2DTFIM(num_layers=2) of 2DTFIM_1DRNN (Training1DRNN_2DTFIM.py:85,94) on the 3x3 lattice."""
+    from rnnwavefunctions_amd.TFIM2D_1DRNN.Training1DRNN_2DTFIM import run_2DTFIM
+    meanE, varE = run_2DTFIM(numsteps=400, systemsize_x=3, systemsize_y=3, Bx=3, num_units=20, num_layers=2,
+                             numsamples=200, learningrate=5e-3, seed=333, verbose=False)
+    ed = _ed_2d(3, 3, 3)
+    final = np.mean(meanE[-30:])
+    print("2DTFIM_1DRNN 2 layers 3x3: E(first)=%.4f  mean of last 30 = %.5f (ED %.5f)" % (meanE[0], final, ed))
+    assert final > ed - 0.05
+    assert final < ed + 0.35
+    assert meanE[0] > final + 0.5
+
+
 def test_f64_gradient_rejects_hidden_sizes_beyond_the_lds_budget():
     from rnnwavefunctions_amd import _lib
     prm = P.init_gru_params([60], seed=1, dtype=np.float64)
