@@ -113,6 +113,7 @@ struct CMLaunch {
             switch ((h)->NFULL) {                               \
                 case 1: { using K = CMLaunch<1, 3, 4>; EXPR; }  \
                 case 2: { using K = CMLaunch<2, 3, 8>; EXPR; }  \
+                case 3: { using K = CMLaunch<3, 3, 8>; EXPR; }  \
             }                                                   \
             break;                                              \
         }                                                       \

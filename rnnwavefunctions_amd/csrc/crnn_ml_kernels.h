@@ -16,7 +16,8 @@ struct CrnnMlCore {
     using C0 = GruCore<float, NFULL, 3>;
     using CU = UpperCore<NFULL>;
     static constexpr int KT = C0::KT;
-    static constexpr size_t BYTES = C0::L::BYTES + (size_t)(NL - 1) * CU::U::BYTES;
+    static constexpr int SPILL = MlSpill<NFULL, NL, float, 3>::value;        // layout.h: top layer read through L2
+    static constexpr size_t BYTES = C0::L::BYTES + (size_t)(NL - 1 - SPILL) * CU::U::BYTES;
 
     static __device__ __forceinline__ void stage(char* lds, const void* wimg) {
         const uint4* src = reinterpret_cast<const uint4*>(wimg);
@@ -25,10 +26,14 @@ struct CrnnMlCore {
         __syncthreads();
     }
     // all layers for one site; z = (amplitude logit difference, phase logit 0, phase logit 1) of the top layer
-    static __device__ __forceinline__ void step(const char* lds, int sig_in, float (&h)[NL][KT], int lane, float (&z)[3]) {
+    static __device__ __forceinline__ void step(const char* lds, const void* wimg, int sig_in, float (&h)[NL][KT], int lane, float (&z)[3]) {
         C0::step(lds, sig_in, h[0], lane);
 #pragma unroll
-        for (int l = 1; l < NL; ++l) CU::step(lds + C0::L::BYTES + (size_t)(l - 1) * CU::U::BYTES, h[l - 1], h[l], lane);
+        for (int l = 1; l < NL; ++l) {
+            const size_t off = C0::L::BYTES + (size_t)(l - 1) * CU::U::BYTES;
+            if (l < NL - SPILL) CU::step(lds + off, h[l - 1], h[l], lane);
+            else CU::step(reinterpret_cast<const char*>(wimg) + off, h[l - 1], h[l], lane);
+        }
         C0::head(lds, h[NL - 1], lane, z);
     }
 };
@@ -58,7 +63,7 @@ __global__ void __launch_bounds__(WAVES * 64) crnn_ml_base_kernel(CrnnArgs a) {
         for (int n = 0; n < N; ++n) {
             if (!a.sampling && (n & 31) == 0) word = a.bits[(int64_t)(n >> 5) * a.ns + sc];
             float z[3];
-            M::step(lds, sig_in, h, lane, z);
+            M::step(lds, a.wimg, sig_in, h, lane, z);
             float la0, la1, w0, ph0, ph1;
             crnn_site(z, n, N, num_up, la0, la1, w0, ph0, ph1);
             int sig;
@@ -137,7 +142,7 @@ __global__ void __launch_bounds__(WAVES * 64) crnn_ml_swap_kernel(CrnnArgs a) {
         for (int n = lo + 1; n < N; ++n) {
             if ((n & 31) == 0) word = a.bits[(int64_t)(n >> 5) * a.ns + s];
             float z[3];
-            M::step(lds, sig_in, h, lane, z);
+            M::step(lds, a.wimg, sig_in, h, lane, z);
             float la0, la1, w0, ph0, ph1;
             crnn_site(z, n, N, num_up, la0, la1, w0, ph0, ph1);
             const int sig = (int)((word >> (n & 31)) & 1) ^ (n == it.hi ? 1 : 0);

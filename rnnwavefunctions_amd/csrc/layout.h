@@ -82,6 +82,15 @@ struct UpperLayout {
     static constexpr size_t BYTES = ((OFF_B + (size_t)NT2 * 16 * sizeof(T) + 15) / 16) * 16;
 };
 
+// Where the images of all layers exceed the 160 KB of LDS (three layers of 50 units: 171 KB; run_1dTFIM.py's width with
+// num_layers = 3) the top layer's image stays in global memory (MlSpill<...>::value = 1): its A fragments are then read
+// through L2 every step (67 KB per wave-step, every wave the same lines) - slower, but the configuration runs.
+template <int NFULL, int NL, typename T, int NOUT = 1>
+struct MlSpill {
+    static constexpr size_t ALL = GruLayout<T, NFULL, NOUT>::BYTES + (size_t)(NL - 1) * UpperLayout<NFULL, T>::BYTES;
+    static constexpr int value = ALL > 160 * 1024 ? 1 : 0;
+};
+
 // row index inside a 16-row tile  <->  (lane quarter q of the C/D fragment, register r)
 //   f32 16x16x4 : row = 4 q + r          f64 16x16x4 : row = q + 4 r
 template <typename T> inline void row_to_qr(int row, int& q, int& r);

@@ -17,7 +17,8 @@ struct MlCore {
     using C0 = GruCore<T, NFULL, 1>;
     using CU = UpperCore<NFULL, T>;
     static constexpr int KT = C0::KT;
-    static constexpr size_t BYTES = C0::L::BYTES + (size_t)(NL - 1) * CU::U::BYTES;
+    static constexpr int SPILL = MlSpill<NFULL, NL, T>::value;
+    static constexpr size_t BYTES = C0::L::BYTES + (size_t)(NL - 1 - SPILL) * CU::U::BYTES;     // LDS-resident part
 
     static __device__ __forceinline__ void stage(char* lds, const void* wimg) {
         const uint4* src = reinterpret_cast<const uint4*>(wimg);
@@ -26,10 +27,14 @@ struct MlCore {
         __syncthreads();
     }
     // all layers for one site; returns the head logit difference of the top layer
-    static __device__ __forceinline__ T step(const char* lds, int sig_in, T (&h)[NL][KT], int lane) {
+    static __device__ __forceinline__ T step(const char* lds, const void* wimg, int sig_in, T (&h)[NL][KT], int lane) {
         C0::step_plain(lds, sig_in, h[0], lane);
 #pragma unroll
-        for (int l = 1; l < NL; ++l) CU::step(lds + C0::L::BYTES + (size_t)(l - 1) * CU::U::BYTES, h[l - 1], h[l], lane);
+        for (int l = 1; l < NL; ++l) {
+            const size_t off = C0::L::BYTES + (size_t)(l - 1) * CU::U::BYTES;
+            if (l < NL - SPILL) CU::step(lds + off, h[l - 1], h[l], lane);
+            else CU::step(reinterpret_cast<const char*>(wimg) + off, h[l - 1], h[l], lane);
+        }
         T z[1];
         C0::head(lds, h[NL - 1], lane, z);
         return z[0];
@@ -60,7 +65,7 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_ml_base_kernel(PrnnArgs a) {
         double cum = 0.0;
         for (int n = 0; n < N; ++n) {
             if (!a.sampling && (n & 31) == 0) word = a.bits[(int64_t)(n >> 5) * a.ns + sc];
-            const T d = M::step(lds, sig_in, h, lane);
+            const T d = M::step(lds, a.wimg, sig_in, h, lane);
             T lp0, lp1;
             log_softmax2(d, lp0, lp1);
             int sig;
@@ -124,7 +129,7 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_ml_flip_kernel(PrnnArgs a) {
         double lp = 0.0;
         for (int n = i + 1; n < N; ++n) {
             const int sig = spin(n);
-            const T d = M::step(lds, sig_in, h, lane);
+            const T d = M::step(lds, a.wimg, sig_in, h, lane);
             T lp0, lp1;
             log_softmax2(d, lp0, lp1);
             lp += (double)(sig ? lp1 : lp0);

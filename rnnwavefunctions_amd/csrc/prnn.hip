@@ -115,6 +115,7 @@ struct MLaunchL {
         } else if ((h)->NL == 3 && (h)->f64) {                                              \
             switch ((h)->NFULL) {                                                           \
                 case 1: { using K = MLaunchL<double, 1, 3, 4>; EXPR; }                      \
+                case 2: { using K = MLaunchL<double, 2, 3, 4>; EXPR; }                      \
             }                                                                               \
         } else if ((h)->NL == 2) {                                                          \
             switch ((h)->NFULL) {                                                           \
@@ -126,6 +127,7 @@ struct MLaunchL {
             switch ((h)->NFULL) {                                                           \
                 case 1: { using K = MLaunchL<float, 1, 3, 4>; EXPR; }                       \
                 case 2: { using K = MLaunchL<float, 2, 3, 8>; EXPR; }                       \
+                case 3: { using K = MLaunchL<float, 3, 3, 8>; EXPR; }                       \
             }                                                                               \
         } else if (!(h)->f64) {                                                             \
             switch ((h)->NFULL) {                                                           \

@@ -134,11 +134,13 @@ extern "C" int rnnwf_create(const rnnwf_config* cfg, rnnwf_handle** out) {
             return bad("rnnwf_create: the 2D RNN has one layer (the reference: 'num_layers is not supported yet', 2DTFIM_2DRNN/run_2dTFIM.py:9)");
         for (int l = 1; l < cfg->num_layers; ++l)
             if (cfg->units[l] != cfg->units[0]) return bad("rnnwf_create: stacked layers must have equal num_units");
+        // two layer images (one forward + its two backward operands in the gradient pass) must fit the 160 KB of LDS;
+        // a third layer's image is read through L2 where three do not fit (layout.h: MlSpill)
         if (cfg->model == RNNWF_MODEL_GRU1D_F64) {
-            if (cfg->units[0] > (cfg->num_layers == 2 ? 36 : 20))
-                return bad("rnnwf_create: stacked float64 layers: num_units <= 36 (2 layers) / 20 (3 layers), the LDS budget of the weight images");
-        } else if (cfg->units[0] > (cfg->num_layers == 2 ? 52 : 36)) {
-            return bad("rnnwf_create: stacked layers: num_units <= 52 (2 layers) / 36 (3 layers), the LDS budget of the weight images");
+            if (cfg->units[0] > 36)
+                return bad("rnnwf_create: stacked float64 layers: num_units <= 36, the LDS budget of the weight images");
+        } else if (cfg->units[0] > 52) {
+            return bad("rnnwf_create: stacked layers: num_units <= 52, the LDS budget of the weight images");
         }
     }
     const bool two_d = cfg->model == RNNWF_MODEL_MDRNN2D || cfg->model == RNNWF_MODEL_GRU1D_F64;

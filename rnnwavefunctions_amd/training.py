@@ -176,7 +176,7 @@ def run_1DTFIM(numsteps=10 ** 4, systemsize=20, num_units=50, Bx=1, num_layers=1
     torch.distributed.run) shards the batch over one process per GPU; `save_dir` turns on the reference's saving
     (energies every 10 steps, TF checkpoint every 500), `restore=True` its restore branch (:172-183)."""
     if not 1 <= num_layers <= 3:
-        raise ValueError("num_layers must be 1..3 (stacked layers: num_units <= 52 for 2, <= 36 for 3)")
+        raise ValueError("num_layers must be 1..3 (stacked layers: num_units <= 52)")
     N = systemsize
     scope = "RNNwavefunction"
     Jz = +np.ones(N)
@@ -209,7 +209,7 @@ def run_J1J2(numsteps=10 ** 5, systemsize=20, J1_=1.0, J2_=0.0, Marshall_sign=Fa
     (J1J2/TrainingRNN_J1J2.py:118): Marshall_sign=True therefore selects the PERIODIC chain
     without a Marshall sign - reproduced here on purpose so that runs compare with the reference's."""
     if not 1 <= num_layers <= 3:
-        raise ValueError("num_layers must be 1..3 (stacked layers: num_units <= 52 for 2, <= 36 for 3)")
+        raise ValueError("num_layers must be 1..3 (stacked layers: num_units <= 52)")
     N = systemsize
     scope = "RNNwavefunction"
     lr = np.float64(learningrate)
@@ -272,7 +272,7 @@ def run_2DTFIM_1DRNN(numsteps=2 * 10 ** 4, systemsize_x=5, systemsize_y=5, Bx=+2
     1 / (1/lr + it/10)  (Training1DRNN_2DTFIM.py:231).  The reference seeds numpy / TF with `seed` but builds the
     wave function with its class default seed 111 (:104); the initial weights here follow the latter."""
     if not 1 <= num_layers <= 3:
-        raise ValueError("num_layers must be 1..3 (stacked float64 layers: num_units <= 36 for 2, <= 20 for 3)")
+        raise ValueError("num_layers must be 1..3 (stacked float64 layers: num_units <= 36)")
     Nx, Ny = systemsize_x, systemsize_y
     lr = np.float64(learningrate)
     units = [num_units] * num_layers

@@ -203,7 +203,8 @@ def stacked_like(H, L, seed):
     return P.randomize_biases(P.scale_kernels(P.init_gru_params([H] * L, seed=seed, heads=HEADS), 1.6), seed + 1)
 
 
-@pytest.mark.parametrize("N,H,L,B", [(12, 10, 2, 40), (10, 20, 3, 33), (20, 50, 2, 24), (8, 36, 3, 17), (16, 52, 2, 16)])
+@pytest.mark.parametrize("N,H,L,B", [(12, 10, 2, 40), (10, 20, 3, 33), (20, 50, 2, 24), (8, 36, 3, 17), (16, 52, 2, 16),
+                                      (12, 50, 3, 24)])
 def test_stacked_layers_log_amplitude_sampling_and_eloc_match_oracle(N, H, L, B):
     from rnnwavefunctions_amd import _lib
     prm = stacked_like(H, L, seed=N + H)

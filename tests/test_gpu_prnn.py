@@ -173,7 +173,7 @@ def test_gru_f64_on_2d_lattice_matches_reference_golden(golden_estimators):
     assert np.allclose(e, g["g4c_eloc"], rtol=1e-10)
 
 
-@pytest.mark.parametrize("Nx,Ny,H,L", [(3, 4, 7, 2), (4, 4, 20, 2), (3, 3, 36, 2), (4, 3, 10, 3), (3, 3, 20, 3)])
+@pytest.mark.parametrize("Nx,Ny,H,L", [(3, 4, 7, 2), (4, 4, 20, 2), (3, 3, 36, 2), (4, 3, 10, 3), (3, 3, 20, 3), (4, 3, 36, 3)])
 def test_stacked_gru_f64_on_2d_lattice_matches_oracle(Nx, Ny, H, L):
     """2DTFIM_1DRNN with units=[num_units]*num_layers (Training1DRNN_2DTFIM.py:94): log-probabilities, the sampler's
     stream and the 2D local energies against the float64 oracle."""
@@ -371,7 +371,7 @@ def make_stacked(model, N, H, L, prm):
 
 
 @pytest.mark.parametrize("N,H,L,B", [(12, 20, 2, 40), (9, 10, 3, 33), (20, 50, 2, 24), (7, 36, 3, 17), (10, 4, 2, 16),
-                                      (16, 52, 2, 16)])
+                                      (16, 52, 2, 16), (20, 50, 3, 24), (9, 52, 3, 70)])     # 3 x 50: top layer's image read through L2
 def test_stacked_layers_log_prob_and_eloc_match_oracle(N, H, L, B):
     from rnnwavefunctions_amd import _lib
     prm = stacked_like(H, L, seed=H + L)
@@ -429,6 +429,7 @@ def test_stacked_layers_limits_and_facade():
         _lib.NativeWavefunction(_lib.MODEL_MDRNN2D, 4, 4, (10, 10))
     with pytest.raises(ValueError, match="float64 layers"):
         _lib.NativeWavefunction(_lib.MODEL_GRU1D_F64, 4, 4, (40, 40))
+    _lib.NativeWavefunction(_lib.MODEL_GRU1D, 20, 1, (50, 50, 50))      # run_1dTFIM.py's width with num_layers = 3
     wf = RNNwavefunction(10, cell="CudnnCompatibleGRUCell", units=[10, 10], seed=111)
     # layer 0: 12*20 + 20 + 2*10 + 10 + 10*10 + 10 = 400; layer 1: 20*20 + 20 + 10*10 + 10 + 10*10 + 10 = 640; head 22
     assert wf.num_params() == 400 + 640 + 22
