@@ -13,17 +13,21 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "librnnwf_hip.so")
-SOURCES = ["rnnwf_api.hip", "prnn.hip", "crnn.hip", "split.hip", "mdrnn.hip", "grad.hip", "comm.hip"]
+SOURCES = ["rnnwf_api.hip", "prnn.hip", "crnn.hip", "split.hip", "split_stream.hip", "mdrnn.hip", "grad.hip", "comm.hip"]
 # no SLP packing of adjacent f32 adds / fmas into v_pk_*_f32 in the bf16x3 engine's translation unit: packed-f32 (and v_dot2)
 # instructions stall behind bf16 MFMAs - their own wave's AND the SIMD partner's (measured: tools/microbench/issue_model,
 # a VALU segment with packed ops beside an MFMA partner 5 170 vs 3 337 cycles).  The f32-input-MFMA kernels keep it.
-PER_SOURCE_FLAGS = {"split.hip": ["-fno-slp-vectorize"]}
+PER_SOURCE_FLAGS = {"split.hip": ["-fno-slp-vectorize"], "split_stream.hip": ["-fno-slp-vectorize"]}
+# the 100-unit bf16x3 kernel keeps its 160 accumulator registers in AGPRs (a wave addresses 256 VGPRs + 256 AGPRs; its
+# other live values need ~210 VGPRs): no -amdgpu-mfma-vgpr-form for its translation unit
+AGPR_FORM_SOURCES = {"split_stream.hip"}
+MFMA_VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
-         "-ffp-contract=fast",
-         # keep MFMA accumulators in VGPRs: no v_accvgpr_read/write around the gate arithmetic and 4 waves/SIMD
-         # at num_units=50 (the option exists for every target of this clang, so the host pass accepts it too)
-         "-mllvm", "-amdgpu-mfma-vgpr-form"]
+         "-ffp-contract=fast"]
+# MFMA_VGPR_FORM (all sources but AGPR_FORM_SOURCES): keep MFMA accumulators in VGPRs: no v_accvgpr_read/write around the
+# gate arithmetic and 4 waves/SIMD at num_units=50 (the option exists for every target of this clang, so the host pass
+# accepts it too)
 
 
 def _newest_header():
@@ -37,7 +41,7 @@ def _compile(src, extra, objdir=None):
     path = os.path.join(CSRC, src)
     if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), _newest_header()) and (not extra or objdir):
         return obj, ""
-    cmd = [HIPCC] + FLAGS + PER_SOURCE_FLAGS.get(src, []) + extra + ["-c", path, "-o", obj]
+    cmd = [HIPCC] + FLAGS + ([] if src in AGPR_FORM_SOURCES else MFMA_VGPR_FORM) + PER_SOURCE_FLAGS.get(src, []) + extra + ["-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, " ".join(cmd), r.stderr[-6000:]))

@@ -22,13 +22,14 @@ struct SLaunch {
     using L = SplitLayout<NF32, RJ, 1, MODE>;
     static int flip(rnnwf_handle* h, const PrnnArgs& a, int kt16) {
         const void* fn = (const void*)prnn_flip_split_kernel<NF32, RJ, WAVES, MODE>;
+        if (L::HP > 4 * kt16) return h->fail(RNNWF_ERR_INVALID, "bf16x3 layout wider than the checkpoint rows (%d > %d)", L::HP, 4 * kt16);
         int bpc = 0;
-        if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, L::BYTES, &bpc)) return rc;
+        if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, L::LDS_BYTES, &bpc)) return rc;
         const int64_t ntiles = (int64_t)(a.N - 1) * ((a.ns + 31) / 32);
         const int64_t need = (ntiles + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
         TimedLaunch tl(h, 1);
-        prnn_flip_split_kernel<NF32, RJ, WAVES, MODE><<<grid, WAVES * 64, L::BYTES, h->stream>>>(a, h->wsplit.p, kt16);
+        prnn_flip_split_kernel<NF32, RJ, WAVES, MODE><<<grid, WAVES * 64, L::LDS_BYTES, h->stream>>>(a, h->wsplit.p, kt16);
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }
@@ -142,17 +143,20 @@ struct CSLaunch {
 
 int rnnwf::prnn_split_flip(rnnwf_handle* h, const PrnnArgs& a) {
     const int kt16 = 4 * h->NFULL + 1;
+    if (h->NFULL == 6) return prnn_split_flip_stream(h, a, kt16);
     if (h->knobs.engine == 3) { SPLIT_DISPATCH(h, return K::flip(h, a, kt16)); }      // RNNWF_ENGINE=bf16x3-serial: A/B only
     else { SPLIT_DISPATCH(h, return K::flip_pp(h, a, kt16)); }
     return h->fail(RNNWF_ERR_INVALID, "no bf16x3 kernel for NFULL=%d", h->NFULL);
 }
 double rnnwf::prnn_split_flops_per_step(rnnwf_handle* h) {
+    if (h->NFULL == 6) return prnn_split_stream_flops_per_step();
     SPLIT_DISPATCH(h, return K::mfma_flops_per_step());
     return 0;
 }
 
 
 int rnnwf::prnn_split_pack(rnnwf_handle* h, std::vector<char>& simg) {
+    if (h->NFULL == 6) return prnn_split_stream_pack(h, simg);
     SPLIT_DISPATCH(h, { simg = K::pack(h); return 0; });
     return h->fail(RNNWF_ERR_INVALID, "no bf16x3 layout for NFULL=%d", h->NFULL);
 }

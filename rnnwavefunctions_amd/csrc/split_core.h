@@ -69,6 +69,13 @@ struct SplitLayout {
     static constexpr size_t OFF_WD = OFF_XC + (size_t)2 * 2 * NUP * 4;         // [2 hh][NUP][NOUT] f32 head weights
     static constexpr size_t OFF_BD = OFF_WD + (size_t)2 * NUP * NOUT * 4;      // [4] f32 head biases (padded)
     static constexpr size_t BYTES = OFF_BD + 16;
+    // Classic images beyond the 160 KB of LDS (100 units: 210 KB of fragments): the w3 fragments - used by ONE of the six
+    // products - stay in global memory and are read through L2 (STREAM); LDS holds [NT][2][NQ] fragments and the tables,
+    // the latter LSHIFT bytes lower than in the global image.
+    static constexpr bool STREAM = MODE == 0 && BYTES > 160 * 1024;
+    static constexpr size_t LDS_A = STREAM ? (size_t)NT * 2 * NQ * 64 * 16 : SZ_A;
+    static constexpr size_t LSHIFT = SZ_A - LDS_A;
+    static constexpr size_t LDS_BYTES = BYTES - LSHIFT;
     // unit owned by entry e of lane half hh
     static constexpr int unit_of(int e, int hh) {
         if (e < 16 * NF32) return 32 * (e / 16) + ((e % 16) & 3) + 8 * ((e % 16) >> 2) + 4 * hh;
@@ -97,7 +104,18 @@ struct SplitCore {
     static __device__ __forceinline__ void stage(char* lds, const void* wimg) {
         const uint4* src = reinterpret_cast<const uint4*>(wimg);
         uint4* dst = reinterpret_cast<uint4*>(lds);
-        for (int i = threadIdx.x; i < (int)(L::BYTES / 16); i += blockDim.x) dst[i] = src[i];
+        if constexpr (L::STREAM) {
+            // fragments of parts 0, 1 compacted to [NT][2][NQ][64], then the tables
+            constexpr int PER = NQ * 64;                           // uint4 per (tile, part)
+            for (int i = threadIdx.x; i < NT * 2 * PER; i += blockDim.x) {
+                const int tp = i / PER, r = i - tp * PER;
+                dst[i] = src[((tp >> 1) * 3 + (tp & 1)) * PER + r];
+            }
+            for (int i = threadIdx.x; i < (int)((L::BYTES - L::OFF_CI) / 16); i += blockDim.x)
+                dst[L::LDS_A / 16 + i] = src[L::OFF_CI / 16 + i];
+        } else {
+            for (int i = threadIdx.x; i < (int)(L::BYTES / 16); i += blockDim.x) dst[i] = src[i];
+        }
         __syncthreads();
     }
 
@@ -150,7 +168,7 @@ struct SplitCore {
 #pragma unroll
         for (int k = 0; k < 16; ++k) zero[k] = 0.0f;       // folds into the MFMA's inline-constant C operand
         const u32x4* av = reinterpret_cast<const u32x4*>(lds + L::OFF_A) + lane;
-        const float* xc = reinterpret_cast<const float*>(lds + L::OFF_XC) + (size_t)((sig * 2 + hh) * L::NUP);
+        const float* xc = reinterpret_cast<const float*>(lds + L::OFF_XC - L::LSHIFT) + (size_t)((sig * 2 + hh) * L::NUP);
         // gate arithmetic of one owned unit (entry e) from its three accumulator slots
         auto gate = [&](int e) {
             float ar, au, ac;
@@ -181,7 +199,7 @@ struct SplitCore {
         constexpr int NK = KS;
         constexpr int TF = 3 * NF32;                       // full tiles [0, TF), mixed tiles [TF, NT)
         // modes 1, 2: bias + one-hot input rows are the accumulators' initial value (loaded per pass: short live ranges)
-        const f32x16* ci = reinterpret_cast<const f32x16*>(lds + L::OFF_CI) + (size_t)sig * NT * 2 + hh;
+        const f32x16* ci = reinterpret_cast<const f32x16*>(lds + L::OFF_CI - L::LSHIFT) + (size_t)sig * NT * 2 + hh;
         // fragment address and B registers of k-step k
         auto a_index = [&](int t, int k) {
             if constexpr (MODE == 1) return (k * NT + t) * 64;
@@ -245,6 +263,126 @@ struct SplitCore {
         }
     }
 
+    // ---- STREAM images (classic layout, 100 units): the step with the w3 fragments read through L2 -------------------
+    // Two passes over the tiles (unit blocks 0, 1 | block 2 + remainder units), each followed by the gate arithmetic of
+    // its units: 96 accumulator registers live instead of 160 (a wave addresses 256 VGPRs; with all ten tiles in one pass
+    // hipcc spilled 724 bytes per lane), and the first pass's gates can sit between the second pass's MFMAs.
+    // K-step order inside a pass: the seven k-steps of the product (w3, h1) - whose fragments come from global memory -
+    // are spread over the pass, one in front of every five LDS-fed k-steps, and the fragments of streamed k-step j + 1
+    // are requested as soon as those of k-step j have been multiplied (five k-steps ahead); the last request of a pass
+    // fetches the first set of the NEXT pass (`sf` carries pass 1's first set from site to site).  1 wave per SIMD.
+    static constexpr int SPLIT_T = NF32 >= 2 ? 3 * (NF32 - 1) : 0;             // pass 1: tiles [0, SPLIT_T), pass 2: the rest
+    static constexpr int SFN = SPLIT_T > NT - SPLIT_T ? SPLIT_T : NT - SPLIT_T;
+    // Buffer loads: one resource descriptor (4 SGPRs) for the image, the lane's 16-byte slot as the VGPR offset, the
+    // fragment's position as the scalar offset - flat global loads made hipcc keep 70 loop-invariant 64-bit addresses
+    // (140 VGPRs) and spill them.
+    typedef __amdgpu_buffer_rsrc_t StreamSrc;
+    static __device__ __forceinline__ StreamSrc stream_source(const void* gimg) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(gimg) + L::OFF_A), 0, (int)L::SZ_A, 0x00020000);
+    }
+    template <int T0, int T1>
+    static __device__ __forceinline__ void stream_request(StreamSrc gimg, int k, u32x4 (&sf)[SFN], int lane) {
+#pragma unroll
+        for (int t = T0; t < T1; ++t)
+            sf[t - T0] = __builtin_amdgcn_raw_buffer_load_b128(gimg, lane * 16, ((t * 3 + 2) * NQ + k) * 64 * 16, 0);
+    }
+    static __device__ __forceinline__ void stream_first(StreamSrc gimg, u32x4 (&sf)[SFN], int lane) {
+        stream_request<0, SPLIT_T>(gimg, 0, sf, lane);
+    }
+    static __device__ __forceinline__ void step_stream(const char* lds, StreamSrc gimg, int sig, const unsigned (&R)[3][NR],
+                                                       float (&h)[NU], u32x4 (&sf)[SFN], int lane) {
+        static_assert(L::STREAM && SPLIT_T > 0, "step_stream: classic layout with streamed w3 fragments");
+        const int hh = lane >> 5;
+        asm volatile("" ::: "memory");
+        f32x16 zero;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) zero[k] = 0.0f;
+        // fragment (tile, part, quad) at byte ((t * 2 + part) * NQ + q) * 1024 + lane * 16 of LDS: three opaque base
+        // addresses 64 KB apart + the DS instruction's 16-bit immediate (left alone, hipcc keeps one address register per
+        // fragment - 350 of them, parked in AGPRs and fetched back with a v_accvgpr_read per ds_read)
+        typedef const __attribute__((address_space(3))) char* LdsPtr;
+        LdsPtr abase[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            abase[b] = (LdsPtr)(lds + lane * 16 + b * 65536);
+            asm volatile("" : "+v"(abase[b]));
+        }
+        const float* xc = reinterpret_cast<const float*>(lds + L::OFF_XC - L::LSHIFT) + (size_t)((sig * 2 + hh) * L::NUP);
+        // LDS-fed products (weight part, state part), smallest first; the streamed one is (2, 0)
+        constexpr int ORD[5][2] = {{1, 1}, {0, 2}, {1, 0}, {0, 1}, {0, 0}};
+        constexpr int NL = 5 * NQ;                                  // LDS-fed k-steps
+        auto frag = [&](int t, int kl) -> u32x4 {
+            const int off = ((t * 2 + ORD[kl / NQ][0]) * NQ + kl % NQ) * 1024;
+            return *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(abase[off >> 16] + (off & 0xffff));
+        };
+        auto gate = [&](int e, const f32x16* acc, int T0) {         // acc: this pass's tiles, tile t at acc[t - T0]
+            float ar, au, ac;
+            if (e < 16 * NF32) {
+                ar = acc[3 * (e / 16) - T0][e % 16];
+                au = acc[3 * (e / 16) + 1 - T0][e % 16];
+                ac = acc[3 * (e / 16) + 2 - T0][e % 16];
+            } else {
+                const int j = e - 16 * NF32;
+                ar = acc[3 * NF32 + (j) / 16 - T0][(j) % 16];
+                au = acc[3 * NF32 + (RJ + j) / 16 - T0][(RJ + j) % 16];
+                ac = acc[3 * NF32 + (2 * RJ + j) / 16 - T0][(2 * RJ + j) % 16];
+            }
+            const float rg = Act<float>::sigmoid_scaled(ar);
+            const float ug = Act<float>::sigmoid_scaled(au);
+            const float cc = Act<float>::tanh_scaled(xc[e] + rg * ac);
+            h[e] = cc + ug * (h[e] - cc);
+        };
+        auto pass = [&](auto t0_c, auto t1_c, auto nt0_c, auto nt1_c, f32x16* acc, auto fill) {
+            constexpr int T0 = decltype(t0_c)::value, T1 = decltype(t1_c)::value, NTP = T1 - T0;
+            constexpr int N0 = decltype(nt0_c)::value, N1 = decltype(nt1_c)::value;       // tiles of the pass that follows
+            auto mfma_all = [&](const u32x4* fr, const unsigned (&Rp)[NR], int q, bool first) {
+                const u32x4 bq = {Rp[4 * q], Rp[4 * q + 1], Rp[4 * q + 2], Rp[4 * q + 3]};
+                const bf16x8 b = __builtin_bit_cast(bf16x8, bq);
+#pragma unroll
+                for (int t = 0; t < NTP; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[t]), b, first ? zero : acc[t], 0, 0, 0);
+            };
+            u32x4 cur[NTP], nxt[NTP];
+#pragma unroll
+            for (int t = 0; t < NTP; ++t) cur[t] = frag(T0 + t, 0);
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                mfma_all(sf, R[0], j, j == 0);                      // streamed k-step j: w3 x h1
+                fill(6 * j);
+                if (j + 1 < NQ) stream_request<T0, T1>(gimg, j + 1, sf, lane);
+                else stream_request<N0, N1>(gimg, 0, sf, lane);     // first set of the next pass (or of the next site)
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    const int kl = 5 * j + i;
+                    if (kl + 1 < NL) {
+#pragma unroll
+                        for (int t = 0; t < NTP; ++t) nxt[t] = frag(T0 + t, kl + 1);
+                    }
+                    mfma_all(cur, R[ORD[kl / NQ][1]], kl % NQ, false);
+                    fill(6 * j + 1 + i);
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int t = 0; t < NTP; ++t) cur[t] = nxt[t];
+                }
+            }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using IS = std::integral_constant<int, SPLIT_T>;
+        using IN = std::integral_constant<int, NT>;
+        f32x16 acc1[SPLIT_T];
+        pass(I0{}, IS{}, IS{}, IN{}, acc1, [](int) {});
+        // pass 1's gate arithmetic rides between pass 2's MFMAs, one unit per k-step (R, not h, feeds pass 2: these units
+        // may move on; with one wave per SIMD a bf16 MFMA leaves room for ~5 VALU instructions of its own wave)
+        f32x16 acc2[NT - SPLIT_T];
+        pass(IS{}, IN{}, I0{}, IS{}, acc2, [&](int pos) {
+            if (pos < 16 * (NF32 - 1)) gate(pos, acc1, 0);
+        });
+#pragma unroll
+        for (int e = 6 * NQ; e < 16 * (NF32 - 1); ++e) gate(e, acc1, 0);     // (none at NQ = 7: 42 k-steps >= 32 units)
+#pragma unroll
+        for (int e = 16 * (NF32 - 1); e < NU; ++e) gate(e, acc2, SPLIT_T);
+    }
+
     // ---- the step in two segments, for the ping-pong kernels (split_kernels.h: prnn_flip_pp_kernel) -----------------
     // A SIMD issues one vector instruction per ~4 cycles and an MFMA holds the matrix pipe for 32: run back to back by
     // one wave, the 95 MFMAs and the ~470 VALU instructions of a step add up (measured: tools/microbench/issue_model,
@@ -258,7 +396,7 @@ struct SplitCore {
         const u32x4* av = reinterpret_cast<const u32x4*>(lds + L::OFF_A) + lane;
         constexpr int ORD[6][2] = {{2, 0}, {1, 1}, {0, 2}, {1, 0}, {0, 1}, {0, 0}};
         constexpr int NK = KS;
-        const f32x16* ci = reinterpret_cast<const f32x16*>(lds + L::OFF_CI) + (size_t)sig * NT * 2 + hh;
+        const f32x16* ci = reinterpret_cast<const f32x16*>(lds + L::OFF_CI - L::LSHIFT) + (size_t)sig * NT * 2 + hh;
         auto a_index = [&](int t, int k) {
             if constexpr (MODE == 1) return (k * NT + t) * 64;
             else return k < 6 * NQ ? ((t * 3 + ORD[k / NQ][0]) * NQ + k % NQ) * 64 : (NT * 3 * NQ + t) * 64;
@@ -299,7 +437,7 @@ struct SplitCore {
     // gates_seg: new state of this lane's units from the accumulators (pure VALU + the candidate's input table)
     static __device__ __forceinline__ void gates_seg(const char* lds, int sig, const f32x16 (&acc)[NT], float (&h)[NU], int lane) {
         const int hh = lane >> 5;
-        const float* xc = reinterpret_cast<const float*>(lds + L::OFF_XC) + (size_t)((sig * 2 + hh) * L::NUP);
+        const float* xc = reinterpret_cast<const float*>(lds + L::OFF_XC - L::LSHIFT) + (size_t)((sig * 2 + hh) * L::NUP);
 #pragma unroll
         for (int e = 0; e < NU; ++e) {
             float ar, au, ac;
@@ -324,14 +462,14 @@ struct SplitCore {
     static __device__ __forceinline__ void head(const char* lds, const float (&h)[NU], int lane, float (&z)[NOUT]) {
         const int hh = lane >> 5;
         asm volatile("" ::: "memory");
-        const float* wd = reinterpret_cast<const float*>(lds + L::OFF_WD) + hh * L::NUP * NOUT;
+        const float* wd = reinterpret_cast<const float*>(lds + L::OFF_WD - L::LSHIFT) + hh * L::NUP * NOUT;
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) z[o] = 0.0f;
 #pragma unroll
         for (int e = 0; e < NU; ++e)
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) z[o] = fmaf(h[e], wd[e * NOUT + o], z[o]);
-        const float* bd = reinterpret_cast<const float*>(lds + L::OFF_BD);
+        const float* bd = reinterpret_cast<const float*>(lds + L::OFF_BD - L::LSHIFT);
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) z[o] += __shfl_xor(z[o], 32) + bd[o];
     }

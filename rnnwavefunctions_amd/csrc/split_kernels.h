@@ -43,10 +43,13 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_flip_split_kernel(PrnnArgs a,
         int sig_in = 1 - spin(i);
         double lp = 0.0;
         unsigned R[3][NR];
+        u32x4 sf[L::STREAM ? C::SFN : 1];
+        if constexpr (L::STREAM) C::stream_first(C::stream_source(wsplit), sf, lane);
         for (int n = i + 1; n < N; ++n) {
             const int sig = spin(n);
             C::split(h, sig_in, R);
-            C::step(lds, sig_in, R, h, lane);
+            if constexpr (L::STREAM) C::step_stream(lds, C::stream_source(wsplit), sig_in, R, h, sf, lane);
+            else C::step(lds, sig_in, R, h, lane);
             float z[1];
             C::head(lds, h, lane, z);
             float lp0, lp1;
@@ -116,62 +119,59 @@ __global__ void __launch_bounds__(512) prnn_flip_pp_kernel(PrnnArgs a, const voi
     u32x4 B[NB];
     f32x16 acc[NT];
     auto load_word = [&](int w) -> uint32_t { return w * 32 < N ? a.bits[(int64_t)w * a.ns + sc] : 0u; };
-    auto next_tile = [&]() {                                  // advance to this wave's next tile (a round may hold none for it)
+    // this wave's next tile after round r (a round may hold none for it): returns false when the walk is over
+    auto peek_tile = [&](int64_t r, int64_t& r_out, int64_t& t_out) -> bool {
         for (;;) {
-            ++round;
-            if (round * nw >= ntiles) { active = false; return; }
-            tile = tile_of(round);
-            if (tile < ntiles) { active = true; return; }
+            ++r;
+            if (r * nw >= ntiles) return false;
+            const int64_t t = tile_of(r);
+            if (t < ntiles) { r_out = r; t_out = t; return true; }
         }
     };
-    // Pulls tile tn's checkpoint lines towards L2 (2 x kt16 x 256 B per 32 chains, one 128-byte line per lane) with an
-    // ORDINARY load whose value stays live in `touched` until the next begin_tile consumes it: an asm load whose
-    // result register the compiler believes dead may land in a register that has been handed to something else.
-    float touched = 0.0f;
-    auto touch = [&](int64_t tn) {
-        if (tn < ntiles) {
-            const int in = (int)(tn / nsb32);
-            const int64_t sbn = tn - (int64_t)in * nsb32;
-            const int64_t blk = sbn * 2 + 1 < a.nsb ? sbn * 2 + 1 : a.nsb - 1;
-            const float* nx = hck + (((int64_t)in * a.nsb + sbn * 2) * kt16) * 64;
-            const int64_t span = ((blk - sbn * 2 + 1) * kt16) * 64;       // floats
-            touched = (int64_t)lane * 32 < span ? nx[lane * 32] : 0.0f;
-        }
-    };
-    auto begin_tile = [&]() {
-        asm volatile("" :: "v"(touched));                     // the previous touch has landed (or was never issued)
-        i = (int)(tile / nsb32);
-        const int64_t sb = tile - (int64_t)i * nsb32;
-        s = (int)sb * 32 + c;
-        valid = s < a.ns;
-        sc = valid ? s : (int)a.ns - 1;
+    // A tile switch sits inside a VALU segment with the SIMD partner - and through the barrier the whole workgroup -
+    // waiting, so it must not wait for memory.  The next tile's checkpoint (this lane's NU state values) and spin words
+    // are therefore requested at the TOP of the chain's last VALU segment, into registers of their own, and consumed at
+    // its end: gates + head (~3 000 cycles) cover the latency.  The values live inside one segment only - carried around
+    // the loop, hipcc shuffles them through ~60 copies per iteration and waits for them at once (measured, round 2).
+    float hn[NU];
+    uint32_t wn0 = 0, wn1 = 0;
+    auto fetch_tile = [&](int64_t tn) {
+        const int in = (int)(tn / nsb32);
+        const int64_t sbn = tn - (int64_t)in * nsb32;
+        const int sn = (int)sbn * 32 + c;
+        const int scn = sn < a.ns ? sn : (int)a.ns - 1;
         // unit u of chain sc sits at float (u >> 2) * 64 + (u & 3) * 16 of the chain's 16-chain block; the upper lane half
         // owns units shifted by a constant per group (full tiles +4, remainder +(RJ-1), special +1): three per-lane
         // base pointers and immediate offsets, instead of one 64-bit address per load (HP <= 4 kt16: host-checked)
-        const float* src = hck + (((int64_t)i * a.nsb + (sc >> 4)) * kt16) * 64 + (sc & 15);
+        const float* src = hck + (((int64_t)in * a.nsb + (scn >> 4)) * kt16) * 64 + (scn & 15);
         auto off = [](int u) { return (u >> 2) * 64 + ((u & 3) << 4); };
 #pragma unroll
         for (int e = 0; e < NU; ++e) {
             const int u0 = L::unit_of(e, 0), u1 = L::unit_of(e, 1);
             const int d = off(u1) - off(u0);                   // compile-time constant per entry
-            h[e] = (src + (hh ? d : 0))[off(u0)];
+            hn[e] = (src + (hh ? d : 0))[off(u0)];
         }
-        word = load_word(i >> 5);
-        word_next = load_word((i >> 5) + 1);
+        const int w = in >> 5;
+        wn0 = a.bits[(int64_t)w * a.ns + scn];
+        wn1 = (w + 1) * 32 < N ? a.bits[(int64_t)(w + 1) * a.ns + scn] : 0u;
+    };
+    auto begin_tile = [&]() {                                 // tile's data are in hn / wn0 / wn1
+        i = (int)(tile / nsb32);
+        const int64_t sb = tile - (int64_t)i * nsb32;
+        s = (int)sb * 32 + c;
+        valid = s < a.ns;
+        sc = valid ? s : (int)a.ns - 1;
+#pragma unroll
+        for (int e = 0; e < NU; ++e) h[e] = hn[e];
+        word = wn0;
+        word_next = wn1;
         sig_in = 1 - (int)((word >> (i & 31)) & 1);
         n = i + 1;
         if ((n & 31) == 0) { word = word_next; word_next = load_word((n >> 5) + 1); }
         lp = 0.0;
-        // this wave's next tile: touch its checkpoint lines now (last memory operation of the switch, so that nothing
-        // here waits for it), and its begin_tile - inside a VALU segment, SIMD partner waiting at the barrier - finds
-        // them in L2
-        {
-            int64_t r2 = round + 1;
-            while (r2 * nw < ntiles && tile_of(r2) >= ntiles) ++r2;
-            if (r2 * nw < ntiles) touch(tile_of(r2));
-        }
     };
     if (active) {
+        fetch_tile(tile);
         begin_tile();
         PP::preload(lds, sig_in, lane, acc);
         PP::split(h, B);
@@ -194,9 +194,16 @@ __global__ void __launch_bounds__(512) prnn_flip_pp_kernel(PrnnArgs a, const voi
         __builtin_amdgcn_sched_barrier(0);
         RNNWF_STAMP(t_b1);
         if (active) {
+            const int sig = (int)((word >> (n & 31)) & 1);    // before the requests below: nothing of this step waits behind them
+            const bool last = n + 1 == N;
+            int64_t round_nx = 0, tile_nx = 0;
+            bool more = false;
+            if (last) {
+                more = peek_tile(round, round_nx, tile_nx);
+                if (more) fetch_tile(tile_nx);
+            }
             if (!RNNWF_ABLATED(a.ablate, 2)) PP::gates(lds, sig_in, acc, h, lane);
             RNNWF_STAMP(t_g);
-            const int sig = (int)((word >> (n & 31)) & 1);
             float z[1] = {0.5f};
             if (!RNNWF_ABLATED(a.ablate, 4)) PP::head(lds, h, lane, z);
             float lp0, lp1;
@@ -205,14 +212,14 @@ __global__ void __launch_bounds__(512) prnn_flip_pp_kernel(PrnnArgs a, const voi
             sig_in = sig;
             ++n;
             RNNWF_STAMP(t_h);
-            if (n == N) {
-                if (valid && hh == 0) {
+            if (last) {
+                if (valid && hh == 0) {                        // one add per element per pass: no-return atomic, nothing to wait for
                     const int64_t row = a.row_of_pos ? a.row_of_pos[i] : i + 1;
-                    a.lpq[row * a.ns + (int64_t)s] += lp;
+                    unsafeAtomicAdd(&a.lpq[row * a.ns + (int64_t)s], lp);
                 }
                 RNNWF_STAMP(t_v);
-                next_tile();
-                if (active) begin_tile();
+                active = more;
+                if (more) { round = round_nx; tile = tile_nx; begin_tile(); }
                 RNNWF_STAMP(t_sw);
             } else if ((n & 31) == 0) {
                 word = word_next;

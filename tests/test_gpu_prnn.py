@@ -323,7 +323,8 @@ def test_edge_sizes(N, H, ns):
 
 
 @pytest.mark.parametrize("N,H,ns", [(20, 10, 100), (33, 20, 50), (40, 36, 64), (65, 50, 37), (30, 64, 33), (25, 44, 40),
-                                     (25, 49, 40), (25, 52, 40), (25, 37, 33), (18, 17, 33), (18, 21, 33)])
+                                     (25, 49, 40), (25, 52, 40), (25, 37, 33), (18, 17, 33), (18, 21, 33),
+                                     (20, 100, 40), (14, 70, 33), (12, 85, 70)])          # > 68 units: w3 fragments through L2
 def test_both_flip_engines_agree_with_the_f64_oracle(N, H, ns, monkeypatch):
     """The flip pass runs on the bf16x3 engine by default (three-way exact bf16 split of both operands, f32
     accumulate; csrc/split_core.h) and on the f32-input MFMA with RNNWF_ENGINE=f32.  Both must match the float64

@@ -1,7 +1,8 @@
 #!/bin/bash
 # usage: tools/kernel_resources.sh prnn   -> compact VGPR/AGPR/scratch/occupancy table for one TU
 f=${1:-prnn}
-/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wno-unused-value -ffp-contract=fast $([ "$f" = split ] && echo -fno-slp-vectorize) -mllvm -amdgpu-mfma-vgpr-form \
+VF="-mllvm -amdgpu-mfma-vgpr-form"; [ "$f" = split_stream ] && VF=""
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wno-unused-value -ffp-contract=fast $([ "$f" = split -o "$f" = split_stream ] && echo -fno-slp-vectorize) $VF \
   -Rpass-analysis=kernel-resource-usage -c rnnwavefunctions_amd/csrc/$f.hip -o /tmp/$f.o 2>&1 |
 python3 -c '
 import sys,re,subprocess
