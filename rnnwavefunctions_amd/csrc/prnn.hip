@@ -271,9 +271,9 @@ int64_t max_chains_per_pass(rnnwf_handle* h) {
 }  // namespace
 
 int rnnwf::prnn_pack_image(rnnwf_handle* h, std::vector<char>& img) {
-    // flip-pass engine: bf16x3 on the matrix core for the f32 models up to 68 units (RNNWF_ENGINE=f32 keeps the
-    // f32-input MFMA everywhere); the base pass, sampling and log_probability always run the f32-MFMA kernels
-    h->engine_split = !h->f64 && h->NL == 1 && (h->NFULL <= 4 || (h->NFULL == 6 && h->knobs.engine >= 2)) && h->knobs.engine != 1;
+    // flip-pass engine: bf16x3 on the matrix core for the f32 models (RNNWF_ENGINE=f32 keeps the f32-input MFMA
+    // everywhere; above 68 units the w3 fragments of the image are read through L2, split_stream.hip); the base pass, sampling and log_probability always run the f32-MFMA kernels
+    h->engine_split = !h->f64 && h->NL == 1 && h->knobs.engine != 1;
     h->engine_forced = h->knobs.engine >= 2;
     if (h->engine_split) {
         std::vector<char> simg;

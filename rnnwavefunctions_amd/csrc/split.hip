@@ -16,7 +16,7 @@ using namespace rnnwf;
 
 namespace {
 
-// ---- bf16x3 engine for the flip pass (f32 models, num_units <= 68) ---------------------------------------
+// ---- bf16x3 engine for the flip pass (f32 models; above 68 units: split_stream.hip) ----------------------
 template <int NF32, int RJ, int WAVES, int MODE>
 struct SLaunch {
     using L = SplitLayout<NF32, RJ, 1, MODE>;

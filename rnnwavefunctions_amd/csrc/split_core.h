@@ -264,15 +264,20 @@ struct SplitCore {
     }
 
     // ---- STREAM images (classic layout, 100 units): the step with the w3 fragments read through L2 -------------------
-    // Two passes over the tiles (unit blocks 0, 1 | block 2 + remainder units), each followed by the gate arithmetic of
-    // its units: 96 accumulator registers live instead of 160 (a wave addresses 256 VGPRs; with all ten tiles in one pass
-    // hipcc spilled 724 bytes per lane), and the first pass's gates can sit between the second pass's MFMAs.
-    // K-step order inside a pass: the seven k-steps of the product (w3, h1) - whose fragments come from global memory -
-    // are spread over the pass, one in front of every five LDS-fed k-steps, and the fragments of streamed k-step j + 1
-    // are requested as soon as those of k-step j have been multiplied (five k-steps ahead); the last request of a pass
-    // fetches the first set of the NEXT pass (`sf` carries pass 1's first set from site to site).  1 wave per SIMD.
-    static constexpr int SPLIT_T = NF32 >= 2 ? 3 * (NF32 - 1) : 0;             // pass 1: tiles [0, SPLIT_T), pass 2: the rest
-    static constexpr int SFN = SPLIT_T > NT - SPLIT_T ? SPLIT_T : NT - SPLIT_T;
+    // One wave per SIMD (accumulators in AGPRs, ~256 VGPRs), so a bf16 MFMA leaves room for ~5 VALU instructions of its
+    // OWN wave: the step is software-pipelined around its three tile passes
+    //     split stage 1 (h1)  |  pass b = 0 .. NF32-1: unit block b (3 tiles)  <- rides: split stages 2, 3 (b = 0), gates of block b-1
+    //                         |  last pass: remainder units (1 tile)          <- rides: gates of block NF32-1
+    //     gates of the remainder units, head.
+    // The riders are laid out stage by stage - one stage of four units (or two state pairs) per k-step - so that
+    // neighbouring VALU instructions are independent: a wave issues in order, and a dependent exp -> add -> rcp chain
+    // between two MFMAs would hold the next MFMA back for its whole latency.
+    // K-step order inside a pass: products that need h1 only come first ((w2,h1), (w1,h1)), then (w2,h2), (w1,h2), then
+    // (w1,h3); the seven k-steps of (w3,h1) - whose fragments come from global memory - are spread over the pass, one in
+    // front of every five LDS-fed k-steps, and the fragments of streamed k-step j + 1 are requested as soon as those of
+    // k-step j have been multiplied; the last request of a pass fetches the first set of the NEXT pass (`sf` carries
+    // pass 1's first set from site to site).
+    static constexpr int SFN = 3;                                              // tiles per pass (a unit block's r, u, c tiles)
     // Buffer loads: one resource descriptor (4 SGPRs) for the image, the lane's 16-byte slot as the VGPR offset, the
     // fragment's position as the scalar offset - flat global loads made hipcc keep 70 loop-invariant 64-bit addresses
     // (140 VGPRs) and spill them.
@@ -281,17 +286,17 @@ struct SplitCore {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(gimg) + L::OFF_A), 0, (int)L::SZ_A, 0x00020000);
     }
     template <int T0, int T1>
-    static __device__ __forceinline__ void stream_request(StreamSrc gimg, int k, u32x4 (&sf)[SFN], int lane) {
+    static __device__ __forceinline__ void stream_request(StreamSrc gimg, int k, u32x4 (&sf)[SFN], int lane) {   // one set
 #pragma unroll
         for (int t = T0; t < T1; ++t)
             sf[t - T0] = __builtin_amdgcn_raw_buffer_load_b128(gimg, lane * 16, ((t * 3 + 2) * NQ + k) * 64 * 16, 0);
     }
-    static __device__ __forceinline__ void stream_first(StreamSrc gimg, u32x4 (&sf)[SFN], int lane) {
-        stream_request<0, SPLIT_T>(gimg, 0, sf, lane);
+    static __device__ __forceinline__ void stream_first(StreamSrc gimg, u32x4 (&sf)[2][SFN], int lane) {
+        stream_request<0, 3>(gimg, 0, sf[0], lane);
+        stream_request<0, 3>(gimg, 1, sf[1], lane);
     }
-    static __device__ __forceinline__ void step_stream(const char* lds, StreamSrc gimg, int sig, const unsigned (&R)[3][NR],
-                                                       float (&h)[NU], u32x4 (&sf)[SFN], int lane) {
-        static_assert(L::STREAM && SPLIT_T > 0, "step_stream: classic layout with streamed w3 fragments");
+    static __device__ __forceinline__ void step_stream(const char* lds, StreamSrc gimg, int sig, float (&h)[NU], u32x4 (&sf)[2][SFN], int lane) {
+        static_assert(L::STREAM && NF32 == 3 && NT == 3 * NF32 + 1 && 6 * NQ >= 40, "step_stream: classic layout with streamed w3 fragments, three unit blocks + one mixed tile");
         const int hh = lane >> 5;
         asm volatile("" ::: "memory");
         f32x16 zero;
@@ -308,15 +313,46 @@ struct SplitCore {
             asm volatile("" : "+v"(abase[b]));
         }
         const float* xc = reinterpret_cast<const float*>(lds + L::OFF_XC - L::LSHIFT) + (size_t)((sig * 2 + hh) * L::NUP);
-        // LDS-fed products (weight part, state part), smallest first; the streamed one is (2, 0)
-        constexpr int ORD[5][2] = {{1, 1}, {0, 2}, {1, 0}, {0, 1}, {0, 0}};
+        // LDS-fed products (weight part, state part) in the order the state parts become available
+        constexpr int ORD[5][2] = {{1, 0}, {0, 0}, {1, 1}, {0, 1}, {0, 2}};
         constexpr int NL = 5 * NQ;                                  // LDS-fed k-steps
         auto frag = [&](int t, int kl) -> u32x4 {
             const int off = ((t * 2 + ORD[kl / NQ][0]) * NQ + kl % NQ) * 1024;
             return *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(abase[off >> 16] + (off & 0xffff));
         };
-        auto gate = [&](int e, const f32x16* acc, int T0) {         // acc: this pass's tiles, tile t at acc[t - T0]
-            float ar, au, ac;
+        // ---- the split, pair by pair (entries 2 i, 2 i + 1 -> register i of every part); every step is exact
+        constexpr int NPR = (NU + 1) / 2;                           // pairs of owned units
+        unsigned R[3][NR];
+        float res0[NPR], res1[NPR];
+        auto hval = [&](int e) { return e < NU ? h[e] : 0.0f; };
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            R[0][i] = i < NPR ? cvt_pk_bf16(hval(2 * i), hval(2 * i + 1)) : 0u;
+            R[1][i] = 0u;
+            R[2][i] = 0u;
+        }
+        {   // bias / input entries (bf16 1.0 = 0x3F80) behind the units
+            constexpr int eb = NU, es = NU + 1;
+            const unsigned one = 0x3F80u, sg = sig ? 0x3F80u : 0u;
+            R[0][eb / 2] |= (eb & 1) ? (one << 16) : one;
+            R[0][es / 2] |= (es & 1) ? (sg << 16) : sg;
+        }
+        auto split2 = [&](int i) {                                  // h2 of pair i
+            if (i < NPR) {
+                const unsigned p1 = R[0][i] & ((2 * i + 1 < NU) ? 0xffffffffu : 0x0000ffffu);     // (not the bias / input entries)
+                res0[i] = hval(2 * i) - __uint_as_float(p1 << 16);
+                res1[i] = hval(2 * i + 1) - __uint_as_float(p1 & 0xffff0000u);
+                R[1][i] = cvt_pk_bf16(res0[i], res1[i]);
+            }
+        };
+        auto split3 = [&](int i) {                                  // h3 of pair i
+            if (i < NPR) {
+                const float s0 = res0[i] - __uint_as_float(R[1][i] << 16);
+                const float s1 = res1[i] - __uint_as_float(R[1][i] & 0xffff0000u);
+                R[2][i] = cvt_pk_bf16(s0, s1);
+            }
+        };
+        auto slots = [&](int e, const f32x16* acc, int T0, float& ar, float& au, float& ac) {     // acc: the pass's tiles, tile t at acc[t - T0]
             if (e < 16 * NF32) {
                 ar = acc[3 * (e / 16) - T0][e % 16];
                 au = acc[3 * (e / 16) + 1 - T0][e % 16];
@@ -327,14 +363,42 @@ struct SplitCore {
                 au = acc[3 * NF32 + (RJ + j) / 16 - T0][(RJ + j) % 16];
                 ac = acc[3 * NF32 + (2 * RJ + j) / 16 - T0][(2 * RJ + j) % 16];
             }
-            const float rg = Act<float>::sigmoid_scaled(ar);
-            const float ug = Act<float>::sigmoid_scaled(au);
-            const float cc = Act<float>::tanh_scaled(xc[e] + rg * ac);
-            h[e] = cc + ug * (h[e] - cc);
         };
-        auto pass = [&](auto t0_c, auto t1_c, auto nt0_c, auto nt1_c, f32x16* acc, auto fill) {
+        // gate arithmetic of four units (entries e0 .. e0 + 3) in ten stages: r = sigmoid, u = sigmoid, c = tanh(xc + r q),
+        // h' = c + u (h - c) on the pre-scaled accumulators (Act<float>)
+        float gr[4], gu[4], gc[4], gx[4];
+        auto gate_stage = [&](int e0, int st, const f32x16* acc, int T0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u;
+                if (e >= NU) continue;
+                switch (st) {
+                    case 0: slots(e, acc, T0, gr[u], gu[u], gc[u]); gx[u] = xc[e]; break;
+                    case 1: gr[u] = __builtin_amdgcn_exp2f(gr[u]); gu[u] = __builtin_amdgcn_exp2f(gu[u]); break;
+                    case 2: gr[u] = 1.0f + gr[u]; gu[u] = 1.0f + gu[u]; break;
+                    case 3: gr[u] = __builtin_amdgcn_rcpf(gr[u]); gu[u] = __builtin_amdgcn_rcpf(gu[u]); break;
+                    case 4: gc[u] = fmaf(gr[u], gc[u], gx[u]); break;
+                    case 5: gc[u] = __builtin_amdgcn_exp2f(gc[u]); break;
+                    case 6: gc[u] = 1.0f + gc[u]; break;
+                    case 7: gc[u] = __builtin_amdgcn_rcpf(gc[u]); break;
+                    case 8: gc[u] = fmaf(2.0f, gc[u], -1.0f); break;
+                    case 9: h[e] = fmaf(gu[u], h[e] - gc[u], gc[u]); break;
+                }
+            }
+        };
+        // the gates of unit block b (16 units, accumulators `acc` of the pass [T0, T0 + 3)) as riders of a later pass
+        auto ride_block = [&](int b, int pos, const f32x16* acc, int T0) {
+            if (pos < 40) gate_stage(16 * b + 4 * (pos / 10), pos % 10, acc, T0);
+        };
+        // One pass = the 6 NQ k-steps of tiles [T0, T1) in the position order  S L L L L L  S L L L L L ...  (S: a streamed
+        // k-step of (w3, h1), L: LDS-fed).  Fragments are requested ahead of their use: LDS-fed sets LA k-steps ahead (a
+        // three-tile k-step is only ~96 cycles of matrix pipe, an LDS read under load takes longer), streamed sets two S
+        // k-steps (~1 100 cycles) ahead - so `sf` carries the first TWO streamed sets of the next pass / next site.
+        auto pass = [&](auto t0_c, auto t1_c, auto nt0_c, auto nt1_c, auto ph_c, f32x16* acc, auto fill) {
             constexpr int T0 = decltype(t0_c)::value, T1 = decltype(t1_c)::value, NTP = T1 - T0;
             constexpr int N0 = decltype(nt0_c)::value, N1 = decltype(nt1_c)::value;       // tiles of the pass that follows
+            constexpr int PH = decltype(ph_c)::value;                                     // which of the two sets holds streamed k-step 0
+            constexpr int LA = 3;                                                          // LDS look-ahead in k-steps
             auto mfma_all = [&](const u32x4* fr, const unsigned (&Rp)[NR], int q, bool first) {
                 const u32x4 bq = {Rp[4 * q], Rp[4 * q + 1], Rp[4 * q + 2], Rp[4 * q + 3]};
                 const bf16x8 b = __builtin_bit_cast(bf16x8, bq);
@@ -342,45 +406,53 @@ struct SplitCore {
                 for (int t = 0; t < NTP; ++t)
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[t]), b, first ? zero : acc[t], 0, 0, 0);
             };
-            u32x4 cur[NTP], nxt[NTP];
+            u32x4 ring[LA + 1][NTP];
 #pragma unroll
-            for (int t = 0; t < NTP; ++t) cur[t] = frag(T0 + t, 0);
+            for (int a = 0; a < LA; ++a)
+#pragma unroll
+                for (int t = 0; t < NTP; ++t) ring[a][t] = frag(T0 + t, a);
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
-                mfma_all(sf, R[0], j, j == 0);                      // streamed k-step j: w3 x h1
+                mfma_all(sf[(j + PH) & 1], R[0], j, j == 0);        // streamed k-step j: w3 x h1
                 fill(6 * j);
-                if (j + 1 < NQ) stream_request<T0, T1>(gimg, j + 1, sf, lane);
-                else stream_request<N0, N1>(gimg, 0, sf, lane);     // first set of the next pass (or of the next site)
+                if (j + 2 < NQ) stream_request<T0, T1>(gimg, j + 2, sf[(j + PH) & 1], lane);
+                else stream_request<N0, N1>(gimg, j + 2 - NQ, sf[(j + PH) & 1], lane);    // sets 0, 1 of the next pass (or of the next site)
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
                     const int kl = 5 * j + i;
-                    if (kl + 1 < NL) {
+                    if (kl + LA < NL) {
 #pragma unroll
-                        for (int t = 0; t < NTP; ++t) nxt[t] = frag(T0 + t, kl + 1);
+                        for (int t = 0; t < NTP; ++t) ring[(kl + LA) % (LA + 1)][t] = frag(T0 + t, kl + LA);
                     }
-                    mfma_all(cur, R[ORD[kl / NQ][1]], kl % NQ, false);
+                    mfma_all(ring[kl % (LA + 1)], R[ORD[kl / NQ][1]], kl % NQ, false);
                     fill(6 * j + 1 + i);
                     asm volatile("" ::: "memory");
-#pragma unroll
-                    for (int t = 0; t < NTP; ++t) cur[t] = nxt[t];
                 }
             }
         };
-        using I0 = std::integral_constant<int, 0>;
-        using IS = std::integral_constant<int, SPLIT_T>;
-        using IN = std::integral_constant<int, NT>;
-        f32x16 acc1[SPLIT_T];
-        pass(I0{}, IS{}, IS{}, IN{}, acc1, [](int) {});
-        // pass 1's gate arithmetic rides between pass 2's MFMAs, one unit per k-step (R, not h, feeds pass 2: these units
-        // may move on; with one wave per SIMD a bf16 MFMA leaves room for ~5 VALU instructions of its own wave)
-        f32x16 acc2[NT - SPLIT_T];
-        pass(IS{}, IN{}, I0{}, IS{}, acc2, [&](int pos) {
-            if (pos < 16 * (NF32 - 1)) gate(pos, acc1, 0);
+        using T0c = std::integral_constant<int, 0>;
+        using T3c = std::integral_constant<int, 3>;
+        using T6c = std::integral_constant<int, 6>;
+        using T9c = std::integral_constant<int, 9>;
+        using TNc = std::integral_constant<int, NT>;
+        // pass 1: h2 is first needed by LDS k-step 2 NQ (position 2 NQ + 2 NQ / 5 + 1 of the pass), h3 by k-step 4 NQ
+        constexpr int S2 = (NPR + 2 * NQ - 1) / (2 * NQ);           // pairs per position, a stage done within 2 NQ positions
+        f32x16 accA[3], accB[3];
+        static_assert(NQ % 2 == 1, "the set parity below assumes an odd number of streamed k-steps per pass and four passes per site");
+        using PH0 = std::integral_constant<int, 0>;
+        using PH1 = std::integral_constant<int, 1>;
+        pass(T0c{}, T3c{}, T3c{}, T6c{}, PH0{}, accA, [&](int pos) {
+#pragma unroll
+            for (int u = 0; u < S2; ++u) {
+                if (pos < 2 * NQ) split2(pos * S2 + u);
+                else if (pos < 4 * NQ) split3((pos - 2 * NQ) * S2 + u);
+            }
         });
+        pass(T3c{}, T6c{}, T6c{}, T9c{}, PH1{}, accB, [&](int pos) { ride_block(0, pos, accA, 0); });
+        pass(T6c{}, T9c{}, T9c{}, TNc{}, PH0{}, accA, [&](int pos) { ride_block(1, pos, accB, 3); });
+        pass(T9c{}, TNc{}, T0c{}, T3c{}, PH1{}, accB, [&](int pos) { ride_block(2, pos, accA, 6); });
 #pragma unroll
-        for (int e = 6 * NQ; e < 16 * (NF32 - 1); ++e) gate(e, acc1, 0);     // (none at NQ = 7: 42 k-steps >= 32 units)
-#pragma unroll
-        for (int e = 16 * (NF32 - 1); e < NU; ++e) gate(e, acc2, SPLIT_T);
+        for (int st = 0; st < 10; ++st) gate_stage(16 * NF32, st, accB, 9);       // the remainder units (RJ <= 4)
     }
 
     // ---- the step in two segments, for the ping-pong kernels (split_kernels.h: prnn_flip_pp_kernel) -----------------

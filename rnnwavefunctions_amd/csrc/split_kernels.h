@@ -43,13 +43,16 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_flip_split_kernel(PrnnArgs a,
         int sig_in = 1 - spin(i);
         double lp = 0.0;
         unsigned R[3][NR];
-        u32x4 sf[L::STREAM ? C::SFN : 1];
+        u32x4 sf[2][L::STREAM ? C::SFN : 1];
         if constexpr (L::STREAM) C::stream_first(C::stream_source(wsplit), sf, lane);
         for (int n = i + 1; n < N; ++n) {
             const int sig = spin(n);
-            C::split(h, sig_in, R);
-            if constexpr (L::STREAM) C::step_stream(lds, C::stream_source(wsplit), sig_in, R, h, sf, lane);
-            else C::step(lds, sig_in, R, h, lane);
+            if constexpr (L::STREAM) {
+                C::step_stream(lds, C::stream_source(wsplit), sig_in, h, sf, lane);
+            } else {
+                C::split(h, sig_in, R);
+                C::step(lds, sig_in, R, h, lane);
+            }
             float z[1];
             C::head(lds, h, lane, z);
             float lp0, lp1;

@@ -519,7 +519,8 @@ def test_cooperative_base_pass_is_bit_identical(N, H, ns, monkeypatch):
 
 
 def test_config5_shard_at_full_size():
-    """BASELINE config 5, one GPU's shard (N=200, h=100, 32 768 samples; f32-input MFMA engine): the per-site energy
+    """BASELINE config 5, one GPU's shard (N=200, h=100, 32 768 samples; bf16x3 engine with the w3 fragments read
+    through L2, csrc/split_stream.hip): the per-site energy
     against the oracle on a subset of the same samples, and the size-independent properties - the two half shards
     drawn with their sample offsets are the full shard (samples AND local energies, bit for bit), the moments are the
     sums of the local energies."""
@@ -531,7 +532,7 @@ def test_config5_shard_at_full_size():
     c = np.append(Jz, 1.0)
     out = wf.vmc_step(ns, seed=111, step=2, couplings=c, want_samples=True, want_eloc=True)
     s, e, m = out["samples"], out["eloc"], out["moments"]
-    assert wf.engine_name() == "f32mfma"
+    assert wf.engine_name() == "bf16x3"
     assert np.all(np.isfinite(e)) and m[2] == ns
     assert np.isclose(m[0], e.sum(), rtol=1e-12) and np.isclose(m[1], (e * e).sum(), rtol=1e-12)
     lo = wf.vmc_step(ns // 2, seed=111, step=2, couplings=c, want_samples=True, want_eloc=True)
