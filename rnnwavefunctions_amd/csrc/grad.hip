@@ -15,7 +15,8 @@ template <typename T, int NFULL, int WAVES, int NOUT>
 struct GLaunch {
     using L = GruLayout<T, NFULL, NOUT>;
     using G = GradLayout<NFULL, T>;
-    static constexpr size_t LDS = L::BYTES + G::BWD_BYTES;
+    static constexpr bool STREAM = GradStream<T, NFULL, NOUT>::value;       // backward operand read through L2 (grad_kernels.h)
+    static constexpr size_t LDS = L::BYTES + (STREAM ? 0 : G::BWD_BYTES);
 
     static std::vector<char> pack_bwd(const rnnwf_handle* h) {
         const int H = h->H;
@@ -145,12 +146,14 @@ struct GLaunch {
                 case 2: { using K = GLaunch<float, 2, 4, 3>; EXPR; }    \
                 case 3: { using K = GLaunch<float, 3, 4, 3>; EXPR; }    \
                 case 4: { using K = GLaunch<float, 4, 4, 3>; EXPR; }    \
+                case 6: { using K = GLaunch<float, 6, 4, 3>; EXPR; }    \
             }                                                           \
         } else if ((h)->model == RNNWF_MODEL_GRU1D_F64) {               \
             switch ((h)->NFULL) {                                       \
                 case 1: { using K = GLaunch<double, 1, 4, 1>; EXPR; }   \
                 case 2: { using K = GLaunch<double, 2, 4, 1>; EXPR; }   \
                 case 3: { using K = GLaunch<double, 3, 4, 1>; EXPR; }   \
+                case 4: { using K = GLaunch<double, 4, 4, 1>; EXPR; }   \
             }                                                           \
         } else {                                                        \
             switch ((h)->NFULL) {                                       \
@@ -158,6 +161,7 @@ struct GLaunch {
                 case 2: { using K = GLaunch<float, 2, 4, 1>; EXPR; }    \
                 case 3: { using K = GLaunch<float, 3, 4, 1>; EXPR; }    \
                 case 4: { using K = GLaunch<float, 4, 4, 1>; EXPR; }    \
+                case 6: { using K = GLaunch<float, 6, 4, 1>; EXPR; }    \
             }                                                           \
         }                                                               \
     } while (0)
@@ -400,8 +404,6 @@ extern "C" int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double me
     const bool cplx = h->model == RNNWF_MODEL_CRNN_U1;
     const bool f64 = h->model == RNNWF_MODEL_GRU1D_F64;
     const size_t es = f64 ? 8 : 4;
-    if (h->NFULL > (f64 ? 3 : 4))
-        return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: num_units > %d not implemented (LDS budget of the backward image)", f64 ? 52 : 68);
     if (h->last_ns <= 0 || !h->last_has_ckpt)
         return h->fail(RNNWF_ERR_STATE, "rnnwf_vmc_gradient: call rnnwf_vmc_step first (its samples, states and E_loc are reused)");
     if (!(norm > 0)) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: norm must be positive");

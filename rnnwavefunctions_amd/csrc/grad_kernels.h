@@ -30,6 +30,12 @@ struct GradLayout {
     static constexpr size_t BWD_BYTES = (size_t)NTO * KBG * 64 * 16;   // [NTO][KBG][64] x 16 B
     static constexpr int HEAD_ROW = 4 * KT + 4;           // per head row: gradient per unit slot (4 KT) + bias (+ pad)
 };
+// Forward + backward image beyond the 160 KB of LDS (f32 above 68 units, f64 above 52): the backward operand stays in
+// global memory and its fragments are read through L2 with buffer loads, one k-group ahead (28 MFMAs ~ 900 cycles).
+template <typename T, int NFULL, int NOUT>
+struct GradStream {
+    static constexpr bool value = GruLayout<T, NFULL, NOUT>::BYTES + GradLayout<NFULL, T>::BWD_BYTES > 160 * 1024;
+};
 
 struct GradArgs {
     const void* wimg;          // forward image (GruLayout<float, NFULL, 1>)
@@ -62,8 +68,9 @@ __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
     constexpr int VW = G::VW;
     constexpr int KT = C::KT, NT = C::NT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr bool STREAM = GradStream<T, NFULL, NOUT>::value;
     C::stage(lds, a.wimg);
-    {
+    if constexpr (!STREAM) {
         char* lb = lds + C::L::BYTES;
         const uint4* src = reinterpret_cast<const uint4*>(a.wbwd);
         uint4* dst = reinterpret_cast<uint4*>(lb);
@@ -71,6 +78,16 @@ __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
         __syncthreads();
     }
     const char* lbwd = lds + C::L::BYTES;
+    const __amdgpu_buffer_rsrc_t gbwd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wbwd), 0, (int)G::BWD_BYTES, 0x00020000);
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    auto bwd_frag = [&](int t, int kg) -> VA {          // fragment (tile t, k-group kg) of the backward operand
+        if constexpr (STREAM) {
+            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(gbwd, (threadIdx.x & 63) * 16, (t * G::KBG + kg) * 64 * 16, 0);
+            return __builtin_bit_cast(VA, v);
+        } else {
+            return (reinterpret_cast<const VA*>(lbwd) + (threadIdx.x & 63))[(t * G::KBG + kg) * 64];
+        }
+    };
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int64_t gw = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * WAVES;
@@ -197,17 +214,24 @@ __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
 #pragma unroll
             for (int t = 0; t < G::NTO; ++t) accb[t] = V4{T(0), T(0), T(0), T(0)};
             asm volatile("" ::: "memory");
-            const VA* ab = reinterpret_cast<const VA*>(lbwd) + lane;
+            VA af[G::NTO], afn[G::NTO];
+#pragma unroll
+            for (int t = 0; t < G::NTO; ++t) af[t] = bwd_frag(t, 0);
 #pragma unroll
             for (int kg = 0; kg < G::KBG; ++kg) {
-                VA af[G::NTO];
+                if (STREAM && kg + 1 < G::KBG) {
 #pragma unroll
-                for (int t = 0; t < G::NTO; ++t) af[t] = ab[(t * G::KBG + kg) * 64];
+                    for (int t = 0; t < G::NTO; ++t) afn[t] = bwd_frag(t, kg + 1);
+                }
 #pragma unroll
                 for (int j = 0; j < VW; ++j)
 #pragma unroll
                     for (int t = 0; t < G::NTO; ++t)
                         accb[t] = Frag<T>::mfma(af[t][j], dp[VW * kg + j], accb[t]);
+                if (kg + 1 < G::KBG) {
+#pragma unroll
+                    for (int t = 0; t < G::NTO; ++t) af[t] = STREAM ? afn[t] : bwd_frag(t, kg + 1);
+                }
             }
 #pragma unroll
             for (int m = 0; m < NFULL; ++m)

@@ -398,7 +398,7 @@ struct SplitCore {
             constexpr int T0 = decltype(t0_c)::value, T1 = decltype(t1_c)::value, NTP = T1 - T0;
             constexpr int N0 = decltype(nt0_c)::value, N1 = decltype(nt1_c)::value;       // tiles of the pass that follows
             constexpr int PH = decltype(ph_c)::value;                                     // which of the two sets holds streamed k-step 0
-            constexpr int LA = 3;                                                          // LDS look-ahead in k-steps
+            constexpr int LA = 2;                     // LDS look-ahead in k-steps (measured 1 / 2 / 3 / 4: 204.5 / 199.9 / 200.8 / 202.3 ms at config 5)
             auto mfma_all = [&](const u32x4* fr, const unsigned (&Rp)[NR], int q, bool first) {
                 const u32x4 bq = {Rp[4 * q], Rp[4 * q + 1], Rp[4 * q + 2], Rp[4 * q + 3]};
                 const bf16x8 b = __builtin_bit_cast(bf16x8, bq);

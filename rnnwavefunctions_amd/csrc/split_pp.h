@@ -163,11 +163,7 @@ struct SplitPP {
         // three-address form spelled out: left to itself hipcc copies c into the state's register and issues the two-address
         // v_fmac (25 v_mov per wave-step).  Plain VALU producer, VALU consumers (head, re-split): no software hazard.
 #pragma unroll
-#ifdef RNNWF_AB_NOASM
-        for (int j = 0; j < n; ++j) h[E0 + j] = fmaf(au[j], ar[j], ac[j]);
-#else
         for (int j = 0; j < n; ++j) asm("v_fma_f32 %0, %1, %2, %3" : "=v"(h[E0 + j]) : "v"(au[j]), "v"(ar[j]), "v"(ac[j]));
-#endif
         RNNWF_STAGE();
     }
 

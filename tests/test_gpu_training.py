@@ -16,7 +16,7 @@ def oracle_cost(prm64, samples, eloc):
     return np.mean(lp * eloc) - np.mean(eloc) * np.mean(lp)          # TrainingRNN_1DTFIM.py:156
 
 
-@pytest.mark.parametrize("N,H,ns", [(6, 6, 64), (9, 20, 48), (7, 50, 32)])
+@pytest.mark.parametrize("N,H,ns", [(6, 6, 64), (9, 20, 48), (7, 50, 32), (6, 64, 32), (6, 100, 24), (5, 80, 40)])   # > 68 units: backward operand through L2
 def test_gradient_matches_finite_differences_of_the_oracle(N, H, ns):
     from rnnwavefunctions_amd import _lib
     from rnnwavefunctions_amd.training import cost_gradient
@@ -76,7 +76,7 @@ def oracle_cost_complex(prm64, samples, eloc):
     return 2 * np.real(np.mean(np.conj(la) * eloc) - np.conj(np.mean(la)) * np.mean(eloc))   # TrainingRNN_J1J2.py:197
 
 
-@pytest.mark.parametrize("N,H,ns", [(8, 6, 64), (12, 20, 48), (10, 50, 32)])
+@pytest.mark.parametrize("N,H,ns", [(8, 6, 64), (12, 20, 48), (10, 50, 32), (8, 100, 24)])
 def test_complex_gradient_matches_finite_differences_of_the_oracle(N, H, ns):
     from rnnwavefunctions_amd import _lib
     from rnnwavefunctions_amd.training import cost_gradient
@@ -164,7 +164,7 @@ def test_mdrnn_gradient_matches_finite_differences_of_the_oracle(Nx, Ny, H, ns):
     assert worst < 1e-6
 
 
-@pytest.mark.parametrize("Nx,Ny,H,ns", [(3, 3, 6, 64), (4, 3, 20, 48), (3, 4, 50, 32)])
+@pytest.mark.parametrize("Nx,Ny,H,ns", [(3, 3, 6, 64), (4, 3, 20, 48), (3, 4, 50, 32), (3, 3, 60, 24), (3, 2, 68, 24)])
 def test_gru_f64_gradient_matches_finite_differences_of_the_oracle(Nx, Ny, H, ns):
     from rnnwavefunctions_amd import _lib
     from rnnwavefunctions_amd.training import cost_gradient
@@ -221,14 +221,16 @@ def test_run_2dtfim_1drnn_with_two_layers_trains():
     assert meanE[0] > final + 0.5
 
 
-def test_f64_gradient_rejects_hidden_sizes_beyond_the_lds_budget():
-    from rnnwavefunctions_amd import _lib
-    prm = P.init_gru_params([60], seed=1, dtype=np.float64)
-    wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D_F64, 3, 3, (60,))
-    wf.set_params(prm, scope=SCOPE)
-    wf.vmc_step(16, seed=1, step=0, couplings=np.append(np.ones(9), 1.0))
-    with pytest.raises(ValueError, match="num_units"):
-        wf.vmc_gradient(0.0, 16, {"wf_dense/bias": (2,)})
+def test_run_1dtfim_trains_at_100_units():
+    """num_units = 100 (BASELINE config 5's width): forward + backward image are 263 KB, the backward operand is read
+    through L2 (grad_kernels.h: GradStream)."""
+    from rnnwavefunctions_amd.TFIM1D.TrainingRNN_1DTFIM import run_1DTFIM
+    meanE, varE = run_1DTFIM(numsteps=300, systemsize=10, num_units=100, Bx=1, num_layers=1, numsamples=200,
+                             learningrate=2e-3, seed=111, verbose=False)
+    ed = -12.38148999965476
+    final = np.mean(meanE[-30:])
+    print("run_1DTFIM 100 units N=10: E(first)=%.4f  last-30 mean=%.5f (ED %.5f)" % (meanE[0], final, ed))
+    assert final > ed - 0.03 and final < ed + 0.15
 
 
 def _ed_2d(Nx, Ny, Bx):
