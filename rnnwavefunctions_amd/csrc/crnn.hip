@@ -239,8 +239,9 @@ int64_t collect_totals(rnnwf_handle* h, int64_t ns) {
 }  // namespace
 
 int rnnwf::crnn_pack_image(rnnwf_handle* h, std::vector<char>& img) {
-    // swap-pass engine: bf16x3 on the matrix core up to 68 units (RNNWF_ENGINE=f32: f32-input MFMA everywhere)
-    h->engine_split = h->NL == 1 && h->NFULL <= 4 && h->knobs.engine != 1;     // stacked layers: f32-input MFMA
+    // swap-pass engine: bf16x3 on the matrix core (RNNWF_ENGINE=f32: f32-input MFMA everywhere; above 68 units the w3
+    // fragments are read through L2, split_stream.hip)
+    h->engine_split = h->NL == 1 && h->knobs.engine != 1;                      // stacked layers: f32-input MFMA
     if (h->engine_split) {
         std::vector<char> simg;
         if (int rc = crnn_split_pack(h, simg)) return rc;

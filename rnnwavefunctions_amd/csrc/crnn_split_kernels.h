@@ -52,10 +52,16 @@ __global__ void __launch_bounds__(WAVES * 64, (3 * NF32 + (3 * RJ + 15) / 16) <=
         num_up += sig_in;
         double re = 0.0, im = 0.0;
         unsigned R[3][NR];
+        u32x4 sf[2][L::STREAM ? C::SFN : 1];                // (> 68 units: w3 fragments read through L2, split_core.h)
+        if constexpr (L::STREAM) C::stream_first(C::stream_source(wsplit), sf, lane);
         for (int n = lo + 1; n < N; ++n) {
             if ((n & 31) == 0) word = a.bits[(int64_t)(n >> 5) * a.ns + s];
-            C::split(h, sig_in, R);
-            C::step(lds, sig_in, R, h, lane);
+            if constexpr (L::STREAM) {
+                C::step_stream(lds, C::stream_source(wsplit), sig_in, h, sf, lane);
+            } else {
+                C::split(h, sig_in, R);
+                C::step(lds, sig_in, R, h, lane);
+            }
             float z[3];
             C::head(lds, h, lane, z);
             float la0, la1, w0, ph0, ph1;

@@ -163,17 +163,20 @@ int rnnwf::prnn_split_pack(rnnwf_handle* h, std::vector<char>& simg) {
 
 int rnnwf::crnn_split_swap(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles) {
     const int kt16 = 4 * h->NFULL + 1;
+    if (h->NFULL == 6) return crnn_split_swap_stream(h, a, max_tiles, kt16);
     if (h->knobs.engine == 3) { CSPLIT_DISPATCH(h, return K::swap(h, a, max_tiles, kt16)); }      // RNNWF_ENGINE=bf16x3-serial: A/B only
     else { CSPLIT_DISPATCH(h, return K::swap_pp(h, a, max_tiles, kt16)); }
     return h->fail(RNNWF_ERR_INVALID, "no bf16x3 cRNN kernel for NFULL=%d", h->NFULL);
 }
 double rnnwf::crnn_split_flops_per_step(rnnwf_handle* h) {
+    if (h->NFULL == 6) return crnn_split_stream_flops_per_step();
     CSPLIT_DISPATCH(h, return K::mfma_flops_per_step());
     return 0;
 }
 
 
 int rnnwf::crnn_split_pack(rnnwf_handle* h, std::vector<char>& simg) {
+    if (h->NFULL == 6) return crnn_split_stream_pack(h, simg);
     CSPLIT_DISPATCH(h, { simg = K::pack(h); return 0; });
     return h->fail(RNNWF_ERR_INVALID, "no bf16x3 layout for NFULL=%d", h->NFULL);
 }

@@ -102,6 +102,31 @@ def test_j1j2_eloc_flags(periodic, marshall, J2v):
     assert np.allclose(e, e_ref, rtol=5e-5, atol=5e-5)
 
 
+@pytest.mark.parametrize("N,H,ns", [(16, 20, 60), (14, 50, 48), (12, 64, 40), (12, 100, 40), (10, 80, 33)])
+def test_both_swap_engines_agree_with_the_f64_oracle(N, H, ns, monkeypatch):
+    """The J1-J2 swap pass on the bf16x3 engine (default; above 68 units with the w3 fragments read through L2) and on the
+    f32-input MFMA (RNNWF_ENGINE=f32): both against the float64 oracle at the f32 tolerance, and each other."""
+    prm = trained_like(H, seed=N + H)
+    prm64 = {k: v.astype(np.float64) for k, v in prm.items()}
+    s = zero_mag_batch(ns, N, 5)
+    rng = np.random.RandomState(4)
+    J1 = 1.0 + 0.1 * rng.standard_normal(N)
+    J2 = 0.4 * np.ones(N)
+    Bz = np.zeros(N)
+    e64 = E.j1j2_local_energies(J1, J2, Bz, s, lambda x: M.crnn_log_amplitude(prm64, x, dtype=np.float64), False, False)
+    got = {}
+    for engine in ("f32", "bf16x3"):
+        monkeypatch.setenv("RNNWF_ENGINE", engine)
+        wf = make_wf(N, H, prm)
+        e, _ = wf.j1j2_eloc(s, J1, J2, Bz, False, False)
+        assert wf.engine_name() == ("bf16x3" if engine == "bf16x3" else "f32mfma")
+        got[engine] = e
+        err = np.abs(e - e64).max() / max(1.0, np.abs(e64).max())
+        print("cRNN N=%d H=%d %-6s: max |E_loc - f64| / max|E| = %.2e" % (N, H, engine, err))
+        assert err < 3e-5
+    assert np.allclose(got["f32"], got["bf16x3"], rtol=5e-5, atol=5e-5)
+
+
 def test_j1j2_reference_style_loop_through_the_facade():
     """J1J2/TrainingRNN_J1J2.py:247-282 written against this package, compared with the fused call."""
     from rnnwavefunctions_amd import compat as tf
