@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root):  tools/refresh_profiles.sh <tag>     e.g.  r01_e
 # Writes gpurun_out/<tag>_*: bench lines of the five BASELINE configs, rocprofv3 kernel stats (cfg2, cfg3, cfg4),
-# FETCH_SIZE / WRITE_SIZE passes of cfg2 and cfg4 (separate --pmc runs, as the gfx950 guide prescribes).
+# FETCH_SIZE / WRITE_SIZE passes of cfg2, cfg4 and cfg5 (separate --pmc runs, as the gfx950 guide prescribes).
 tag=${1:-r01_x}
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out
@@ -22,7 +22,7 @@ for w in cfg1 cfg2 cfg3 cfg4 cfg5; do
   cp $out/${tag}_prof_$w/*/*kernel_stats.csv $out/${tag}_kernel_stats_$w.csv
   echo "stats $w done"
 done
-for w in cfg2 cfg4; do
+for w in cfg2 cfg4 cfg5; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/${tag}_pmc_${w}_$c -- python3 $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-alt-engine > $out/${tag}_pmc_${w}_$c.log 2>&1 || { echo "pmc $w $c failed"; exit 1; }
   done
@@ -50,7 +50,7 @@ python3 - <<PY
 import csv, glob, json, collections
 out = "$out"; tag = "$tag"
 res = {}
-for w in ("cfg2", "cfg4"):
+for w in ("cfg2", "cfg4", "cfg5"):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for f in glob.glob("%s/%s_pmc_%s_%s/**/*counter_collection.csv" % (out, tag, w, c), recursive=True):
@@ -69,7 +69,7 @@ def pick(w, sub):
             return k, d
     return None, None
 traffic = {}
-for w, sub in (("cfg2", "flip"), ("cfg4", "mdrnn_flip")):
+for w, sub in (("cfg2", "flip"), ("cfg4", "mdrnn_flip"), ("cfg5", "flip")):
     k, d = pick(w, sub)
     if k:
         fetch, write = d["FETCH_SIZE"] * 1024.0, d["WRITE_SIZE"] * 1024.0       # counter unit KiB
