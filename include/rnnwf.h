@@ -172,8 +172,8 @@ int rnnwf_vmc_step(rnnwf_handle* h, int64_t numsamples, uint64_t seed, uint64_t 
  *   (J1J2/TrainingRNN_J1J2.py:197), i.e. grad = 2/norm sum_s [(Re E_s - mean_energy) d Re log psi +
  *   (Im E_s - mean_energy_im) d Im log psi]; mean_energy_im is ignored for the positive RNNs.
  *   The 2D drivers (2DTFIM_2DRNN/Training2DRNN_2DTFIM.py:163, 2DTFIM_1DRNN/Training1DRNN_2DTFIM.py:160) use the
- *   first cost in float64.  Limits: num_units <= 68 (f32, MDRNN), <= 52 (GRU1D_F64); else RNNWF_ERR_INVALID.
- *   Stacked layers (GRU1D, len(units) 2..3): one backward pass per layer, top first.
+ *   first cost in float64.  Every width rnnwf_create accepts (above 68 / 52 units the backward operand is read through
+ *   L2 instead of LDS).  Stacked layers (len(units) 2..3, every GRU model): one backward pass per layer, top first.
  * rnnwf_get_grad     <- the gradient of one TF variable (same names and shapes as rnnwf_set_param).
  * rnnwf_allreduce_grads: one RCCL all-reduce (sum) over all gradient arrays of the handle.             */
 int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double mean_energy_im, double norm);
@@ -215,9 +215,9 @@ int rnnwf_timing_reset(rnnwf_handle* h);
 int rnnwf_timing_get(rnnwf_handle* h, int32_t kernel_id, double* total_ms, int64_t* launches, double* work);
 /* Which matrix engine the dominant (flip / swap) pass of this handle uses, decided at rnnwf_commit_params:
  *   "bf16x3"  - both operands held exactly as three bf16 parts, six bf16 MFMA products, f32 accumulate
- *               (f32 models up to 68 units; f32 accuracy, see csrc/split_core.h);
- *   "f32mfma" - f32-input MFMA (forced with RNNWF_ENGINE=f32; always used above 68 units, for the base pass,
- *               sampling and log_probability);
+ *               (f32 models; f32 accuracy, see csrc/split_core.h; above 68 units one weight part is read through L2);
+ *   "f32mfma" - f32-input MFMA (forced with RNNWF_ENGINE=f32; always used for stacked layers, the base pass, sampling
+ *               and log_probability);
  *   "f64mfma" - the float64 models.                                                                     */
 const char* rnnwf_engine_name(const rnnwf_handle* h);
 /* hipDeviceSynchronize on the handle's device (bench.py brackets its timed region with it). */
