@@ -56,21 +56,33 @@ std::vector<char> pack_split_image(const rnnwf_handle* h) {
             } else {
                 const int s = 16 * (T - 3 * NF32) + rho;
                 if (s < 3 * RJ) { g = s / RJ; uo = L::unit_of(16 * NF32 + s % RJ, hh_row); }
+                // mode 2: the spare slots behind the remainder units carry the HEAD rows (g = 3 + o, both lane halves the
+                // same row): the ping-pong kernels read the head of the state that ENTERED a step from its accumulators
+                else if (MODE == 2 && s < L::HEAD_SLOT + NOUT) { g = 3 + (s - L::HEAD_SLOT); uo = 0; }
             }
             if (g < 0 || uo >= H) continue;
+            auto head_w = [&](int o, int ui) -> double {
+                if (o == 0) return Wd[(size_t)ui * 2 + 1] - Wd[(size_t)ui * 2];
+                const auto& Wp = pv(h, "wf_dense_phase/kernel");
+                return Wp[(size_t)ui * 2 + (o - 1)];
+            };
             auto weight = [&](int ui) -> double {          // (scaled) recurrent weight from unit ui into row (g, uo)
                 if (ui >= H) return 0.0;
                 return g == 0 ? sg * Wg[(size_t)(2 + ui) * 2 * H + uo]
                      : g == 1 ? sg * Wg[(size_t)(2 + ui) * 2 * H + H + uo]
-                              : sc * Wch[(size_t)ui * H + uo];
+                     : g == 2 ? sc * Wch[(size_t)ui * H + uo]
+                              : head_w(g - 3, ui);
             };
             if constexpr (MODE != 0) {
                 // accumulator start value of this row: bias + one-hot input row (the same for both K halves)
                 if (hhk == 0) {
                     float* CI = reinterpret_cast<float*>(img.data() + L::OFF_CI);
                     for (int sgm = 0; sgm < 2; ++sgm) {
+                        double hb = 0.0;
+                        if (g >= 3) hb = g == 3 ? bd[1] - bd[0] : pv(h, "wf_dense_phase/bias")[g - 4];
                         const double v = g == 0 ? sg * (bg[uo] + Wg[(size_t)sgm * 2 * H + uo])
-                                       : g == 1 ? sg * (bg[H + uo] + Wg[(size_t)sgm * 2 * H + H + uo]) : sc * bch[uo];
+                                       : g == 1 ? sg * (bg[H + uo] + Wg[(size_t)sgm * 2 * H + H + uo])
+                                       : g == 2 ? sc * bch[uo] : hb;
                         CI[(((size_t)sgm * L::NT + T) * 2 + hh_row) * 16 + rho] = (float)v;
                     }
                 }

@@ -58,6 +58,8 @@ struct SplitLayout {
     static constexpr int KS = MODE == 1 ? (6 * NRM + 3) / 4 : MODE == 2 ? 6 * NQ + 1 : 6 * NQ;   // k-steps (MFMAs per tile)
     static constexpr int NUP = ((NU + 3) / 4) * 4;
     static constexpr int HP = 32 * NF32 + 2 * RJ;       // padded hidden size
+    static constexpr int HEAD_SLOT = 3 * RJ;            // mode 2: mixed-tile slots [3 RJ, 3 RJ + NOUT) hold the head rows (pack_split.h)
+    static_assert(MODE != 2 || 3 * RJ + NOUT <= 16 * NMIX, "mode 2: the head rows need spare slots in the mixed tiles");
     static_assert(MODE != 2 || (NUA % 8 == 0), "mode 2: the aligned units fill whole k-steps");
     static_assert(MODE != 1 || (NU % 2 == 0), "mode 1: units are packed in pairs");
     // A image: mode 0 [NT][3][NQ][64] x 16 B; mode 1 [KS][NT][64] x 16 B; mode 2 [NT][3][NQ][64] then [NT][64] (special)

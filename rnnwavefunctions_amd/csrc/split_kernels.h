@@ -205,13 +205,25 @@ __global__ void __launch_bounds__(512) prnn_flip_pp_kernel(PrnnArgs a, const voi
                 more = peek_tile(round, round_nx, tile_nx);
                 if (more) fetch_tile(tile_nx);
             }
+            // The head rows ride in spare slots of the mixed tiles (pack_split.h): the accumulators of this step hold the
+            // logits of the state that ENTERED it, i.e. of site n - 1, whose spin is sig_in.  Site i (the flipped one) is
+            // not part of the sum; the chain's last site gets its logits from the VALU head below.
+            if (n > i + 1 && !RNNWF_ABLATED(a.ablate, 4)) {
+                float zp[1];
+                PP::head_lagged(acc, zp);
+                float lq0, lq1;
+                log_softmax2(zp[0], lq0, lq1);
+                lp += (double)(sig_in ? lq1 : lq0);
+            }
             if (!RNNWF_ABLATED(a.ablate, 2)) PP::gates(lds, sig_in, acc, h, lane);
             RNNWF_STAMP(t_g);
-            float z[1] = {0.5f};
-            if (!RNNWF_ABLATED(a.ablate, 4)) PP::head(lds, h, lane, z);
-            float lp0, lp1;
-            log_softmax2(z[0], lp0, lp1);
-            lp += (double)(sig ? lp1 : lp0);
+            if (last) {
+                float z[1] = {0.5f};
+                if (!RNNWF_ABLATED(a.ablate, 4)) PP::head(lds, h, lane, z);
+                float lp0, lp1;
+                log_softmax2(z[0], lp0, lp1);
+                lp += (double)(sig ? lp1 : lp0);
+            }
             sig_in = sig;
             ++n;
             RNNWF_STAMP(t_h);

@@ -123,6 +123,12 @@ struct SplitPP {
         }
     }
 
+    // head rows of the state that ENTERED the step (logits of the previous site), straight from the accumulators
+    static __device__ __forceinline__ void head_lagged(const f32x16 (&acc)[NT], float (&z)[NOUT]) {
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) z[o] = acc[3 * NF32 + (L::HEAD_SLOT + o) / 16][(L::HEAD_SLOT + o) % 16];
+    }
+
     // gate arithmetic of units [E0, E1), one stage at a time: r = sigmoid, u = sigmoid, c = tanh(xc + r q), h' = c + u (h - c)
     template <int E0, int E1>
     static __device__ __forceinline__ void gate_batch(const f32x16 (&acc)[NT], const float* xcp, float (&h)[NU]) {
