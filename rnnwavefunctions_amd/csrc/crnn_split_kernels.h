@@ -178,14 +178,27 @@ __global__ void __launch_bounds__(512) crnn_swap_pp_kernel(CrnnArgs a, const voi
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (active) {
+            // The three head rows ride in spare slots of the mixed tiles (pack_split.h): this step's accumulators hold the
+            // logits of the state that ENTERED it, i.e. of site n - 1 (spin sig_in, up-spins before it num_up - sig_in).
+            // Site lo is not part of the sum; the chain's last site gets its logits from the VALU head below.
+            if (n > lo + 1) {
+                float zp[3];
+                PP::head_lagged(acc, zp);
+                float la0, la1, w0, ph0, ph1;
+                crnn_site(zp, n - 1, N, num_up - sig_in, la0, la1, w0, ph0, ph1);
+                re += (double)(sig_in ? la1 : la0);
+                im += (double)(sig_in ? ph1 : ph0);
+            }
             PP::gates(lds, sig_in, acc, h, lane);
-            float z[3];
-            PP::head(lds, h, lane, z);
-            float la0, la1, w0, ph0, ph1;
-            crnn_site(z, n, N, num_up, la0, la1, w0, ph0, ph1);
             const int sig = (int)((word >> (n & 31)) & 1) ^ (n == it.hi ? 1 : 0);
-            re += (double)(sig ? la1 : la0);
-            im += (double)(sig ? ph1 : ph0);
+            if (n + 1 == N) {
+                float z[3];
+                PP::head(lds, h, lane, z);
+                float la0, la1, w0, ph0, ph1;
+                crnn_site(z, n, N, num_up, la0, la1, w0, ph0, ph1);
+                re += (double)(sig ? la1 : la0);
+                im += (double)(sig ? ph1 : ph0);
+            }
             num_up += sig;
             sig_in = sig;
             ++n;
