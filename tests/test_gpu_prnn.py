@@ -440,6 +440,39 @@ def test_stacked_layers_limits_and_facade():
     assert np.allclose(lp, M.prnn_log_probability(prm, smp), rtol=0, atol=1e-4)
 
 
+def test_stream_engine_edge_cases(monkeypatch):
+    """The bf16x3 engine above 68 units (w3 fragments through L2): ragged batches (ns not a multiple of 32 or 16), the
+    shortest chains (N = 2, 3), the parity-symmetric model, and a multi-pass call - all against the float64 oracle, and
+    multi-pass == single pass bit for bit."""
+    from rnnwavefunctions_amd import _lib
+    rng = np.random.RandomState(5)
+    monkeypatch.setenv("RNNWF_ENGINE", "bf16x3")
+    for N, H, ns, model in ((2, 100, 33, _lib.MODEL_GRU1D), (3, 96, 1, _lib.MODEL_GRU1D), (17, 100, 47, _lib.MODEL_GRU1D),
+                            (9, 72, 95, _lib.MODEL_GRU1D_PARITY)):
+        prm = trained_like(H, seed=N + H)
+        prm64 = {k: v.astype(np.float64) for k, v in prm.items()}
+        wf = make_wf(model, N, H, prm)
+        s = rng.randint(0, 2, (ns, N)).astype(np.int32)
+        Jz = 1.0 + 0.1 * rng.standard_normal(N)
+        e = wf.tfim_eloc(s, Jz, 0.8)
+        assert wf.engine_name() == "bf16x3"
+        fn = M.prnn_paritysym_log_probability if model == _lib.MODEL_GRU1D_PARITY else M.prnn_log_probability
+        e64 = E.ising_local_energies(Jz, 0.8, s, lambda x: fn(prm64, x, dtype=np.float64))
+        err = np.abs(e - e64).max() / max(1.0, np.abs(e64).max())
+        print("stream engine N=%d H=%d ns=%d model=%d: max rel E err %.2e" % (N, H, ns, model, err))
+        assert err < 2e-5
+    N, H, ns = 20, 100, 1500                                  # checkpoints: 19 * 94 * 25 KB = 45 MB
+    prm = trained_like(H, seed=9)
+    s = rng.randint(0, 2, (ns, N)).astype(np.int32)
+    wf = make_wf(_lib.MODEL_GRU1D, N, H, prm)
+    e1 = wf.tfim_eloc(s, np.ones(N), 1.0)
+    monkeypatch.setenv("RNNWF_STATE_BUDGET_MB", "4")
+    wf = make_wf(_lib.MODEL_GRU1D, N, H, prm)
+    monkeypatch.delenv("RNNWF_STATE_BUDGET_MB")
+    e2 = wf.tfim_eloc(s, np.ones(N), 1.0)
+    assert wf.engine_name() == "bf16x3" and np.array_equal(e1, e2)
+
+
 def test_multi_pass_estimators_equal_the_single_pass(monkeypatch):
     """Batches larger than the hidden-state budget run in several passes (RNNWF_STATE_BUDGET_MB, read at rnnwf_create,
     shrinks the budget so that this happens at test sizes); results must not depend on the pass boundaries."""
