@@ -56,21 +56,41 @@ __global__ void __launch_bounds__(WAVES * 64, (3 * NF32 + (3 * RJ + 15) / 16) <=
         if constexpr (L::STREAM) C::stream_first(C::stream_source(wsplit), sf, lane);
         for (int n = lo + 1; n < N; ++n) {
             if ((n & 31) == 0) word = a.bits[(int64_t)(n >> 5) * a.ns + s];
+            const int sig = (int)((word >> (n & 31)) & 1) ^ (n == it.hi ? 1 : 0);
             if constexpr (L::STREAM) {
-                C::step_stream(lds, C::stream_source(wsplit), sig_in, h, sf, lane);
+                // the step's accumulators carry the three head rows of the state that entered it: the logits of site n - 1
+                // (spin sig_in, up-spins before it num_up - sig_in); site lo is not part of the sum, the last site's logits
+                // come from the VALU head
+                // (no branches in this loop body: with them hipcc moves the riders out from between the MFMAs)
+                float zp[3];
+                C::step_stream(lds, C::stream_source(wsplit), sig_in, h, sf, lane, zp);
+                float la0, la1, w0, ph0, ph1;
+                crnn_site(zp, n - 1, N, num_up - sig_in, la0, la1, w0, ph0, ph1);
+                const float are = sig_in ? la1 : la0, aim = sig_in ? ph1 : ph0;
+                re += (double)(n > lo + 1 ? are : 0.0f);
+                im += (double)(n > lo + 1 ? aim : 0.0f);
             } else {
                 C::split(h, sig_in, R);
                 C::step(lds, sig_in, R, h, lane);
+                float z[3];
+                C::head(lds, h, lane, z);
+                float la0, la1, w0, ph0, ph1;
+                crnn_site(z, n, N, num_up, la0, la1, w0, ph0, ph1);
+                re += (double)(sig ? la1 : la0);
+                im += (double)(sig ? ph1 : ph0);
             }
-            float z[3];
-            C::head(lds, h, lane, z);
-            float la0, la1, w0, ph0, ph1;
-            crnn_site(z, n, N, num_up, la0, la1, w0, ph0, ph1);
-            const int sig = (int)((word >> (n & 31)) & 1) ^ (n == it.hi ? 1 : 0);
-            re += (double)(sig ? la1 : la0);
-            im += (double)(sig ? ph1 : ph0);
             num_up += sig;
             sig_in = sig;
+        }
+        if constexpr (L::STREAM) {                            // the last site's logits: VALU head on the final state
+            if (lo + 1 < N) {
+                float z[3];
+                C::head(lds, h, lane, z);
+                float la0, la1, w0, ph0, ph1;
+                crnn_site(z, N - 1, N, num_up - sig_in, la0, la1, w0, ph0, ph1);
+                re += (double)(sig_in ? la1 : la0);
+                im += (double)(sig_in ? ph1 : ph0);
+            }
         }
         if (valid && hh == 0) {
             const double2 b = a.cb[(int64_t)lo * a.ns + s];

@@ -56,9 +56,10 @@ std::vector<char> pack_split_image(const rnnwf_handle* h) {
             } else {
                 const int s = 16 * (T - 3 * NF32) + rho;
                 if (s < 3 * RJ) { g = s / RJ; uo = L::unit_of(16 * NF32 + s % RJ, hh_row); }
-                // mode 2: the spare slots behind the remainder units carry the HEAD rows (g = 3 + o, both lane halves the
-                // same row): the ping-pong kernels read the head of the state that ENTERED a step from its accumulators
-                else if (MODE == 2 && s < L::HEAD_SLOT + NOUT) { g = 3 + (s - L::HEAD_SLOT); uo = 0; }
+                // mode 2 and the streamed classic layout: the spare slots behind the remainder units carry the HEAD rows
+                // (g = 3 + o, both lane halves the same row): their kernels read the head of the state that ENTERED a step
+                // from its accumulators
+                else if ((MODE == 2 || L::STREAM) && s < L::HEAD_SLOT + NOUT) { g = 3 + (s - L::HEAD_SLOT); uo = 0; }
             }
             if (g < 0 || uo >= H) continue;
             auto head_w = [&](int o, int ui) -> double {
@@ -118,7 +119,8 @@ std::vector<char> pack_split_image(const rnnwf_handle* h) {
                     } else if (MODE != 0) {
                         w = 0.0;
                     } else if (e == L::NU && hhk == 0) {                    // bias (+ input row of spin 0)
-                        w = g == 0 ? sg * (bg[uo] + Wg[uo]) : g == 1 ? sg * (bg[H + uo] + Wg[H + uo]) : sc * bch[uo];
+                        w = g == 0 ? sg * (bg[uo] + Wg[uo]) : g == 1 ? sg * (bg[H + uo] + Wg[H + uo]) : g == 2 ? sc * bch[uo]
+                          : g == 3 ? bd[1] - bd[0] : pv(h, "wf_dense_phase/bias")[g - 4];
                     } else if (e == L::NU + 1 && hhk == 0) {                // input row difference, times sigma
                         w = g == 0 ? sg * (Wg[(size_t)2 * H + uo] - Wg[uo])
                           : g == 1 ? sg * (Wg[(size_t)2 * H + H + uo] - Wg[H + uo]) : 0.0;

@@ -58,7 +58,7 @@ struct SplitLayout {
     static constexpr int KS = MODE == 1 ? (6 * NRM + 3) / 4 : MODE == 2 ? 6 * NQ + 1 : 6 * NQ;   // k-steps (MFMAs per tile)
     static constexpr int NUP = ((NU + 3) / 4) * 4;
     static constexpr int HP = 32 * NF32 + 2 * RJ;       // padded hidden size
-    static constexpr int HEAD_SLOT = 3 * RJ;            // mode 2: mixed-tile slots [3 RJ, 3 RJ + NOUT) hold the head rows (pack_split.h)
+    static constexpr int HEAD_SLOT = 3 * RJ;            // mode 2 / STREAM: mixed-tile slots [3 RJ, 3 RJ + NOUT) hold the head rows (pack_split.h)
     static_assert(MODE != 2 || 3 * RJ + NOUT <= 16 * NMIX, "mode 2: the head rows need spare slots in the mixed tiles");
     static_assert(MODE != 2 || (NUA % 8 == 0), "mode 2: the aligned units fill whole k-steps");
     static_assert(MODE != 1 || (NU % 2 == 0), "mode 1: units are packed in pairs");
@@ -297,7 +297,9 @@ struct SplitCore {
         stream_request<0, 3>(gimg, 0, sf[0], lane);
         stream_request<0, 3>(gimg, 1, sf[1], lane);
     }
-    static __device__ __forceinline__ void step_stream(const char* lds, StreamSrc gimg, int sig, float (&h)[NU], u32x4 (&sf)[2][SFN], int lane) {
+    // zlag: head rows of the state that ENTERED the step (the previous site's logits), from spare slots of the mixed tile
+    static __device__ __forceinline__ void step_stream(const char* lds, StreamSrc gimg, int sig, float (&h)[NU], u32x4 (&sf)[2][SFN], int lane,
+                                                       float (&zlag)[NOUT]) {
         static_assert(L::STREAM && NF32 == 3 && NT == 3 * NF32 + 1 && 6 * NQ >= 40, "step_stream: classic layout with streamed w3 fragments, three unit blocks + one mixed tile");
         const int hh = lane >> 5;
         asm volatile("" ::: "memory");
@@ -453,6 +455,8 @@ struct SplitCore {
         pass(T3c{}, T6c{}, T6c{}, T9c{}, PH1{}, accB, [&](int pos) { ride_block(0, pos, accA, 0); });
         pass(T6c{}, T9c{}, T9c{}, TNc{}, PH0{}, accA, [&](int pos) { ride_block(1, pos, accB, 3); });
         pass(T9c{}, TNc{}, T0c{}, T3c{}, PH1{}, accB, [&](int pos) { ride_block(2, pos, accA, 6); });
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) zlag[o] = accB[0][L::HEAD_SLOT + o];
 #pragma unroll
         for (int st = 0; st < 10; ++st) gate_stage(16 * NF32, st, accB, 9);       // the remainder units (RJ <= 4)
     }
