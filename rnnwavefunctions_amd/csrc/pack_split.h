@@ -110,6 +110,20 @@ std::vector<char> pack_split_image(const rnnwf_handle* h) {
                 const int part[6] = {0, 0, 0, 1, 1, 2};
                 for (int jj = 0; jj < 6; ++jj) ASP[((size_t)T * 64 + lane) * 8 + jj] = p[part[jj]];
             }
+            if constexpr (MODE == 3) {
+                // NS special units per K half: entry 6 s + i of the special k-steps = product i of special unit s,
+                // A parts {w1, w1, w1, w2, w2, w3} against the B entries {h1, h2, h3, h1, h2, h1}
+                uint16_t* ASP = reinterpret_cast<uint16_t*>(img.data() + L::OFF_ASP);
+                const int part[6] = {0, 0, 0, 1, 1, 2};
+                for (int sp = 0; sp < L::NS; ++sp) {
+                    uint16_t p[3];
+                    split3(weight(L::unit_of(L::NUA + sp, hhk)), p);
+                    for (int i = 0; i < 6; ++i) {
+                        const int idx = 6 * sp + i;
+                        ASP[(((size_t)T * L::KSP + idx / 8) * 64 + lane) * 8 + idx % 8] = p[part[i]];
+                    }
+                }
+            }
             for (int x = 0; x < L::NQ; ++x)
                 for (int jj = 0; jj < 8; ++jj) {
                     const int e = 8 * x + jj;

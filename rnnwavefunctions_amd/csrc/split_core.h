@@ -50,34 +50,38 @@ struct SplitLayout {
     static constexpr int NMIX = (3 * RJ + 15) / 16;
     static constexpr int NT = 3 * NF32 + NMIX;          // 32-row output tiles
     static constexpr int NU = 16 * NF32 + RJ;           // hidden units owned by one lane (mode 2: the last one is special)
-    static constexpr int NUA = MODE == 2 ? NU - 1 : NU; // units that travel in the regular packed registers
+    static constexpr int NUA = MODE == 2 ? NU - 1 : MODE == 3 ? (NU / 8) * 8 : NU;   // units that travel in the regular packed registers
+    static constexpr int NS = NU - NUA;                 // special units (modes 2, 3): their six products fill K entries of extra k-steps
+    static constexpr int KSP = MODE == 2 ? 1 : MODE == 3 ? (6 * NS + 7) / 8 : 0;     // special k-steps
     static constexpr int NE = MODE == 0 ? NU + 2 : NUA; // mode 0: + bias entry + input entry
-    static constexpr int NQ = (NE + 7) / 8;             // bf16x8 quads per part (modes 0, 2)
+    static constexpr int NQ = (NE + 7) / 8;             // bf16x8 quads per part (modes 0, 2, 3)
     static constexpr int NRM = MODE == 1 ? NU / 2 : 4 * NQ;     // packed 32-bit registers per part
     static constexpr int NR = MODE == 2 ? NRM + 1 : NRM;        // declared per part: mode 2 keeps the special k-step's B registers in slot NRM
-    static constexpr int KS = MODE == 1 ? (6 * NRM + 3) / 4 : MODE == 2 ? 6 * NQ + 1 : 6 * NQ;   // k-steps (MFMAs per tile)
+    static constexpr int KS = MODE == 1 ? (6 * NRM + 3) / 4 : 6 * NQ + KSP;   // k-steps (MFMAs per tile)
     static constexpr int NUP = ((NU + 3) / 4) * 4;
     static constexpr int HP = 32 * NF32 + 2 * RJ;       // padded hidden size
     static constexpr int HEAD_SLOT = 3 * RJ;            // mode 2 / STREAM: mixed-tile slots [3 RJ, 3 RJ + NOUT) hold the head rows (pack_split.h)
     static_assert(MODE != 2 || 3 * RJ + NOUT <= 16 * NMIX, "mode 2: the head rows need spare slots in the mixed tiles");
-    static_assert(MODE != 2 || (NUA % 8 == 0), "mode 2: the aligned units fill whole k-steps");
+    static_assert((MODE != 2 && MODE != 3) || (NUA % 8 == 0), "modes 2, 3: the aligned units fill whole k-steps");
+    static_assert(MODE != 3 || (NS >= 1 && NUA == 16 * NF32), "mode 3: the remainder units are the special ones");
     static_assert(MODE != 1 || (NU % 2 == 0), "mode 1: units are packed in pairs");
     // A image: mode 0 [NT][3][NQ][64] x 16 B; mode 1 [KS][NT][64] x 16 B; mode 2 [NT][3][NQ][64] then [NT][64] (special)
     static constexpr size_t OFF_A = 0;
-    static constexpr size_t SZ_A = MODE == 1 ? (size_t)KS * NT * 64 * 16 : (size_t)NT * (3 * NQ + (MODE == 2 ? 1 : 0)) * 64 * 16;
-    static constexpr size_t OFF_ASP = (size_t)NT * 3 * NQ * 64 * 16;           // mode 2: special fragments
+    static constexpr size_t SZ_A = MODE == 1 ? (size_t)KS * NT * 64 * 16 : (size_t)NT * (3 * NQ + KSP) * 64 * 16;
+    static constexpr size_t OFF_ASP = (size_t)NT * 3 * NQ * 64 * 16;           // modes 2, 3: special fragments [NT][KSP][64] x 16 B
     static constexpr size_t OFF_CI = OFF_A + SZ_A;                             // modes 1, 2: [2 sigma][NT][2 hh][16] f32
     static constexpr size_t OFF_XC = OFF_CI + (MODE != 0 ? (size_t)2 * NT * 2 * 16 * 4 : 0);   // [2 sigma][2 hh][NUP] f32 (scaled)
     static constexpr size_t OFF_WD = OFF_XC + (size_t)2 * 2 * NUP * 4;         // [2 hh][NUP][NOUT] f32 head weights
     static constexpr size_t OFF_BD = OFF_WD + (size_t)2 * NUP * NOUT * 4;      // [4] f32 head biases (padded)
     static constexpr size_t BYTES = OFF_BD + 16;
-    // Classic images beyond the 160 KB of LDS (100 units: 210 KB of fragments): the w3 fragments - used by ONE of the six
-    // products - stay in global memory and are read through L2 (STREAM); LDS holds [NT][2][NQ] fragments and the tables,
-    // the latter LSHIFT bytes lower than in the global image.
-    static constexpr bool STREAM = MODE == 0 && BYTES > 160 * 1024;
-    static constexpr size_t LDS_A = STREAM ? (size_t)NT * 2 * NQ * 64 * 16 : SZ_A;
-    static constexpr size_t LSHIFT = SZ_A - LDS_A;
+    // Mode 3 (69..100 units; 200 KB of fragments for 160 KB of LDS): the regular w3 fragments - used by ONE of the six
+    // products - stay in global memory and are read through L2 (STREAM); LDS holds [NT][2][NQ] regular fragments, then
+    // everything from OFF_ASP on (special fragments, tables) LSHIFT bytes lower than in the global image.
+    static constexpr bool STREAM = MODE == 3;
+    static constexpr size_t LDS_REG = (size_t)NT * 2 * NQ * 64 * 16;           // STREAM: regular fragments of parts 0, 1
+    static constexpr size_t LSHIFT = STREAM ? OFF_ASP - LDS_REG : 0;
     static constexpr size_t LDS_BYTES = BYTES - LSHIFT;
+    static_assert(MODE == 3 || BYTES <= 160 * 1024, "the image must fit LDS (mode 3 streams one weight part)");
     // unit owned by entry e of lane half hh
     static constexpr int unit_of(int e, int hh) {
         if (e < 16 * NF32) return 32 * (e / 16) + ((e % 16) & 3) + 8 * ((e % 16) >> 2) + 4 * hh;
@@ -113,8 +117,8 @@ struct SplitCore {
                 const int tp = i / PER, r = i - tp * PER;
                 dst[i] = src[((tp >> 1) * 3 + (tp & 1)) * PER + r];
             }
-            for (int i = threadIdx.x; i < (int)((L::BYTES - L::OFF_CI) / 16); i += blockDim.x)
-                dst[L::LDS_A / 16 + i] = src[L::OFF_CI / 16 + i];
+            for (int i = threadIdx.x; i < (int)((L::BYTES - L::OFF_ASP) / 16); i += blockDim.x)
+                dst[L::LDS_REG / 16 + i] = src[L::OFF_ASP / 16 + i];
         } else {
             for (int i = threadIdx.x; i < (int)(L::BYTES / 16); i += blockDim.x) dst[i] = src[i];
         }
@@ -265,27 +269,28 @@ struct SplitCore {
         }
     }
 
-    // ---- STREAM images (classic layout, 100 units): the step with the w3 fragments read through L2 -------------------
+    // ---- STREAM images (mode 3, 69..100 units): the step with the regular w3 fragments read through L2 ---------------
     // One wave per SIMD (accumulators in AGPRs, ~256 VGPRs), so a bf16 MFMA leaves room for ~5 VALU instructions of its
-    // OWN wave: the step is software-pipelined around its three tile passes
+    // OWN wave: the step is software-pipelined around its four tile passes
     //     split stage 1 (h1)  |  pass b = 0 .. NF32-1: unit block b (3 tiles)  <- rides: split stages 2, 3 (b = 0), gates of block b-1
     //                         |  last pass: remainder units (1 tile)          <- rides: gates of block NF32-1
-    //     gates of the remainder units, head.
+    //     gates of the remainder units; the head rows of the ENTERING state come out of the remainder tile (zlag).
     // The riders are laid out stage by stage - one stage of four units (or two state pairs) per k-step - so that
     // neighbouring VALU instructions are independent: a wave issues in order, and a dependent exp -> add -> rcp chain
     // between two MFMAs would hold the next MFMA back for its whole latency.
-    // K-step order inside a pass: products that need h1 only come first ((w2,h1), (w1,h1)), then (w2,h2), (w1,h2), then
-    // (w1,h3); the seven k-steps of (w3,h1) - whose fragments come from global memory - are spread over the pass, one in
-    // front of every five LDS-fed k-steps, and the fragments of streamed k-step j + 1 are requested as soon as those of
-    // k-step j have been multiplied; the last request of a pass fetches the first set of the NEXT pass (`sf` carries
-    // pass 1's first set from site to site).
+    // K-step order inside a pass (6 NQ + KSP positions): products that need h1 only come first ((w2,h1), (w1,h1)), then
+    // (w2,h2), (w1,h2), then (w1,h3); the NQ k-steps of (w3,h1) - whose fragments come from global memory - are spread
+    // over the pass, one in front of every five LDS-fed k-steps, requested two streamed k-steps (~1 100 cycles) ahead; the
+    // last two requests of a pass fetch the first two sets of the NEXT pass (`sf` carries pass 1's from site to site);
+    // the special k-steps (the remainder units' 6 products each, K-packed) close the pass.  38 k-steps x 10 tiles = 380
+    // MFMAs per wave-step (the classic layout - every part padded to 7 k-steps - had 420).
     static constexpr int SFN = 3;                                              // tiles per pass (a unit block's r, u, c tiles)
     // Buffer loads: one resource descriptor (4 SGPRs) for the image, the lane's 16-byte slot as the VGPR offset, the
     // fragment's position as the scalar offset - flat global loads made hipcc keep 70 loop-invariant 64-bit addresses
     // (140 VGPRs) and spill them.
     typedef __amdgpu_buffer_rsrc_t StreamSrc;
     static __device__ __forceinline__ StreamSrc stream_source(const void* gimg) {
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(gimg) + L::OFF_A), 0, (int)L::SZ_A, 0x00020000);
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(gimg) + L::OFF_A), 0, (int)L::OFF_ASP, 0x00020000);
     }
     template <int T0, int T1>
     static __device__ __forceinline__ void stream_request(StreamSrc gimg, int k, u32x4 (&sf)[SFN], int lane) {   // one set
@@ -300,15 +305,14 @@ struct SplitCore {
     // zlag: head rows of the state that ENTERED the step (the previous site's logits), from spare slots of the mixed tile
     static __device__ __forceinline__ void step_stream(const char* lds, StreamSrc gimg, int sig, float (&h)[NU], u32x4 (&sf)[2][SFN], int lane,
                                                        float (&zlag)[NOUT]) {
-        static_assert(L::STREAM && NF32 == 3 && NT == 3 * NF32 + 1 && 6 * NQ >= 40, "step_stream: classic layout with streamed w3 fragments, three unit blocks + one mixed tile");
+        static_assert(MODE == 3 && NF32 == 3 && NT == 3 * NF32 + 1 && NQ % 2 == 0 && L::KSP <= 2 && 6 * NQ >= 36,
+                      "step_stream: mode 3, three unit blocks + one mixed tile, even number of streamed k-steps");
+        constexpr int KSP = L::KSP, NS = L::NS;
         const int hh = lane >> 5;
         asm volatile("" ::: "memory");
-        f32x16 zero;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) zero[k] = 0.0f;
-        // fragment (tile, part, quad) at byte ((t * 2 + part) * NQ + q) * 1024 + lane * 16 of LDS: three opaque base
-        // addresses 64 KB apart + the DS instruction's 16-bit immediate (left alone, hipcc keeps one address register per
-        // fragment - 350 of them, parked in AGPRs and fetched back with a v_accvgpr_read per ds_read)
+        // fragment addresses: three opaque LDS base addresses 64 KB apart + the DS instruction's 16-bit immediate (left
+        // alone, hipcc keeps one address register per fragment - 350 of them, parked in AGPRs and fetched back with a
+        // v_accvgpr_read per ds_read).  Regular (tile, part, quad) at ((t * 2 + part) * NQ + q) KB, special (tile, k) behind.
         typedef const __attribute__((address_space(3))) char* LdsPtr;
         LdsPtr abase[3];
 #pragma unroll
@@ -317,35 +321,30 @@ struct SplitCore {
             asm volatile("" : "+v"(abase[b]));
         }
         const float* xc = reinterpret_cast<const float*>(lds + L::OFF_XC - L::LSHIFT) + (size_t)((sig * 2 + hh) * L::NUP);
+        const f32x16* ci = reinterpret_cast<const f32x16*>(lds + L::OFF_CI - L::LSHIFT) + (size_t)sig * NT * 2 + hh;
         // LDS-fed products (weight part, state part) in the order the state parts become available
         constexpr int ORD[5][2] = {{1, 0}, {0, 0}, {1, 1}, {0, 1}, {0, 2}};
-        constexpr int NL = 5 * NQ;                                  // LDS-fed k-steps
+        constexpr int NLR = 5 * NQ;                                 // LDS-fed regular k-steps; k-steps NLR .. NLR + KSP - 1: special
+        constexpr int NL = NLR + KSP;
         auto frag = [&](int t, int kl) -> u32x4 {
-            const int off = ((t * 2 + ORD[kl / NQ][0]) * NQ + kl % NQ) * 1024;
+            const int off = kl < NLR ? ((t * 2 + ORD[kl / NQ][0]) * NQ + kl % NQ) * 1024 : (int)L::LDS_REG + (t * KSP + (kl - NLR)) * 1024;
             return *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(abase[off >> 16] + (off & 0xffff));
         };
         // ---- the split, pair by pair (entries 2 i, 2 i + 1 -> register i of every part); every step is exact
-        constexpr int NPR = (NU + 1) / 2;                           // pairs of owned units
-        unsigned R[3][NR];
+        constexpr int NPR = NUA / 2;                                // pairs of aligned units
+        unsigned R[3][NRM];
+        unsigned RS[KSP][4];                                        // B registers of the special k-steps
         float res0[NPR], res1[NPR];
-        auto hval = [&](int e) { return e < NU ? h[e] : 0.0f; };
 #pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            R[0][i] = i < NPR ? cvt_pk_bf16(hval(2 * i), hval(2 * i + 1)) : 0u;
+        for (int i = 0; i < NRM; ++i) {
+            R[0][i] = i < NPR ? cvt_pk_bf16(h[2 * i], h[2 * i + 1]) : 0u;
             R[1][i] = 0u;
             R[2][i] = 0u;
         }
-        {   // bias / input entries (bf16 1.0 = 0x3F80) behind the units
-            constexpr int eb = NU, es = NU + 1;
-            const unsigned one = 0x3F80u, sg = sig ? 0x3F80u : 0u;
-            R[0][eb / 2] |= (eb & 1) ? (one << 16) : one;
-            R[0][es / 2] |= (es & 1) ? (sg << 16) : sg;
-        }
         auto split2 = [&](int i) {                                  // h2 of pair i
             if (i < NPR) {
-                const unsigned p1 = R[0][i] & ((2 * i + 1 < NU) ? 0xffffffffu : 0x0000ffffu);     // (not the bias / input entries)
-                res0[i] = hval(2 * i) - __uint_as_float(p1 << 16);
-                res1[i] = hval(2 * i + 1) - __uint_as_float(p1 & 0xffff0000u);
+                res0[i] = h[2 * i] - __uint_as_float(R[0][i] << 16);
+                res1[i] = h[2 * i + 1] - __uint_as_float(R[0][i] & 0xffff0000u);
                 R[1][i] = cvt_pk_bf16(res0[i], res1[i]);
             }
         };
@@ -355,6 +354,29 @@ struct SplitCore {
                 const float s1 = res1[i] - __uint_as_float(R[1][i] & 0xffff0000u);
                 R[2][i] = cvt_pk_bf16(s0, s1);
             }
+        };
+        // special units: parts duplicated into both halves of a register, then entry 6 s + i = part {h1,h2,h3,h1,h2,h1}[i]
+        auto split_special = [&]() {
+            unsigned q[NS][3];
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp) {
+                const float x = h[NUA + sp];
+                q[sp][0] = cvt_pk_bf16(x, x);
+                const float r = x - __uint_as_float(q[sp][0] << 16);
+                q[sp][1] = cvt_pk_bf16(r, r);
+                const float t = r - __uint_as_float(q[sp][1] << 16);
+                q[sp][2] = cvt_pk_bf16(t, t);
+            }
+            constexpr int PH_[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+            for (int k = 0; k < KSP; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e0 = 8 * k + 2 * j, e1 = e0 + 1;
+                    const unsigned lo = e0 < 6 * NS ? (q[e0 / 6][PH_[e0 % 6]] & 0xffffu) : 0u;
+                    const unsigned hi = e1 < 6 * NS ? (q[e1 / 6][PH_[e1 % 6]] & 0xffff0000u) : 0u;
+                    RS[k][j] = lo | hi;
+                }
         };
         auto slots = [&](int e, const f32x16* acc, int T0, float& ar, float& au, float& ac) {     // acc: the pass's tiles, tile t at acc[t - T0]
             if (e < 16 * NF32) {
@@ -368,7 +390,7 @@ struct SplitCore {
                 ac = acc[3 * NF32 + (2 * RJ + j) / 16 - T0][(2 * RJ + j) % 16];
             }
         };
-        // gate arithmetic of four units (entries e0 .. e0 + 3) in ten stages: r = sigmoid, u = sigmoid, c = tanh(xc + r q),
+        // gate arithmetic of four units (entries e0 .. e0 + 3) in nine stages: r = sigmoid, u = sigmoid, c = tanh(xc + r q),
         // h' = c + u (h - c) on the pre-scaled accumulators (Act<float>)
         float gr[4], gu[4], gc[4], gx[4];
         auto gate_stage = [&](int e0, int st, const f32x16* acc, int T0) {
@@ -385,80 +407,81 @@ struct SplitCore {
                     case 5: gc[u] = __builtin_amdgcn_exp2f(gc[u]); break;
                     case 6: gc[u] = 1.0f + gc[u]; break;
                     case 7: gc[u] = __builtin_amdgcn_rcpf(gc[u]); break;
-                    case 8: gc[u] = fmaf(2.0f, gc[u], -1.0f); break;
-                    case 9: h[e] = fmaf(gu[u], h[e] - gc[u], gc[u]); break;
+                    case 8: gc[u] = fmaf(2.0f, gc[u], -1.0f); h[e] = fmaf(gu[u], h[e] - gc[u], gc[u]); break;
                 }
             }
         };
         // the gates of unit block b (16 units, accumulators `acc` of the pass [T0, T0 + 3)) as riders of a later pass
         auto ride_block = [&](int b, int pos, const f32x16* acc, int T0) {
-            if (pos < 40) gate_stage(16 * b + 4 * (pos / 10), pos % 10, acc, T0);
+            if (pos < 36) gate_stage(16 * b + 4 * (pos / 9), pos % 9, acc, T0);
         };
-        // One pass = the 6 NQ k-steps of tiles [T0, T1) in the position order  S L L L L L  S L L L L L ...  (S: a streamed
-        // k-step of (w3, h1), L: LDS-fed).  Fragments are requested ahead of their use: LDS-fed sets LA k-steps ahead (a
-        // three-tile k-step is only ~96 cycles of matrix pipe, an LDS read under load takes longer), streamed sets two S
-        // k-steps (~1 100 cycles) ahead - so `sf` carries the first TWO streamed sets of the next pass / next site.
-        auto pass = [&](auto t0_c, auto t1_c, auto nt0_c, auto nt1_c, auto ph_c, f32x16* acc, auto fill) {
+        // One pass = the 6 NQ + KSP k-steps of tiles [T0, T1) in the position order  S L L L L L  S L L L L L ... P P
+        // (S: a streamed k-step of (w3, h1), L: LDS-fed, P: special).  Fragments are requested ahead of their use: LDS-fed
+        // sets LA k-steps ahead (a three-tile k-step is only ~96 cycles of matrix pipe), streamed sets two S k-steps ahead.
+        auto pass = [&](auto t0_c, auto t1_c, auto nt0_c, auto nt1_c, f32x16* acc, auto fill) {
             constexpr int T0 = decltype(t0_c)::value, T1 = decltype(t1_c)::value, NTP = T1 - T0;
             constexpr int N0 = decltype(nt0_c)::value, N1 = decltype(nt1_c)::value;       // tiles of the pass that follows
-            constexpr int PH = decltype(ph_c)::value;                                     // which of the two sets holds streamed k-step 0
             constexpr int LA = 2;                     // LDS look-ahead in k-steps (measured 1 / 2 / 3 / 4: 204.5 / 199.9 / 200.8 / 202.3 ms at config 5)
-            auto mfma_all = [&](const u32x4* fr, const unsigned (&Rp)[NR], int q, bool first) {
+            auto mfma_all = [&](const u32x4* fr, const unsigned* Rp, int q) {
                 const u32x4 bq = {Rp[4 * q], Rp[4 * q + 1], Rp[4 * q + 2], Rp[4 * q + 3]};
                 const bf16x8 b = __builtin_bit_cast(bf16x8, bq);
 #pragma unroll
                 for (int t = 0; t < NTP; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[t]), b, first ? zero : acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[t]), b, acc[t], 0, 0, 0);
             };
+#pragma unroll
+            for (int t = 0; t < NTP; ++t) acc[t] = ci[(T0 + t) * 2];    // bias + one-hot input rows (+ head biases)
             u32x4 ring[LA + 1][NTP];
 #pragma unroll
             for (int a = 0; a < LA; ++a)
 #pragma unroll
                 for (int t = 0; t < NTP; ++t) ring[a][t] = frag(T0 + t, a);
+            auto lds_kstep = [&](int kl, int pos) {
+                if (kl + LA < NL) {
+#pragma unroll
+                    for (int t = 0; t < NTP; ++t) ring[(kl + LA) % (LA + 1)][t] = frag(T0 + t, kl + LA);
+                }
+                if (kl < NLR) mfma_all(ring[kl % (LA + 1)], R[ORD[kl / NQ][1]], kl % NQ);
+                else mfma_all(ring[kl % (LA + 1)], RS[kl - NLR], 0);
+                fill(pos);
+                asm volatile("" ::: "memory");
+            };
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
-                mfma_all(sf[(j + PH) & 1], R[0], j, j == 0);        // streamed k-step j: w3 x h1
+                mfma_all(sf[j & 1], R[0], j);                       // streamed k-step j: w3 x h1
                 fill(6 * j);
-                if (j + 2 < NQ) stream_request<T0, T1>(gimg, j + 2, sf[(j + PH) & 1], lane);
-                else stream_request<N0, N1>(gimg, j + 2 - NQ, sf[(j + PH) & 1], lane);    // sets 0, 1 of the next pass (or of the next site)
+                if (j + 2 < NQ) stream_request<T0, T1>(gimg, j + 2, sf[j & 1], lane);
+                else stream_request<N0, N1>(gimg, j + 2 - NQ, sf[j & 1], lane);    // sets 0, 1 of the next pass (or of the next site)
 #pragma unroll
-                for (int i = 0; i < 5; ++i) {
-                    const int kl = 5 * j + i;
-                    if (kl + LA < NL) {
-#pragma unroll
-                        for (int t = 0; t < NTP; ++t) ring[(kl + LA) % (LA + 1)][t] = frag(T0 + t, kl + LA);
-                    }
-                    mfma_all(ring[kl % (LA + 1)], R[ORD[kl / NQ][1]], kl % NQ, false);
-                    fill(6 * j + 1 + i);
-                    asm volatile("" ::: "memory");
-                }
+                for (int i = 0; i < 5; ++i) lds_kstep(5 * j + i, 6 * j + 1 + i);
             }
+#pragma unroll
+            for (int k = 0; k < KSP; ++k) lds_kstep(NLR + k, 6 * NQ + k);
         };
         using T0c = std::integral_constant<int, 0>;
         using T3c = std::integral_constant<int, 3>;
         using T6c = std::integral_constant<int, 6>;
         using T9c = std::integral_constant<int, 9>;
         using TNc = std::integral_constant<int, NT>;
-        // pass 1: h2 is first needed by LDS k-step 2 NQ (position 2 NQ + 2 NQ / 5 + 1 of the pass), h3 by k-step 4 NQ
+        // pass 1: h2 is first needed by LDS k-step 2 NQ (position 2 NQ + 2 NQ / 5 + 1 of the pass), h3 by k-step 4 NQ, the
+        // special registers by the last positions
         constexpr int S2 = (NPR + 2 * NQ - 1) / (2 * NQ);           // pairs per position, a stage done within 2 NQ positions
         f32x16 accA[3], accB[3];
-        static_assert(NQ % 2 == 1, "the set parity below assumes an odd number of streamed k-steps per pass and four passes per site");
-        using PH0 = std::integral_constant<int, 0>;
-        using PH1 = std::integral_constant<int, 1>;
-        pass(T0c{}, T3c{}, T3c{}, T6c{}, PH0{}, accA, [&](int pos) {
+        pass(T0c{}, T3c{}, T3c{}, T6c{}, accA, [&](int pos) {
 #pragma unroll
             for (int u = 0; u < S2; ++u) {
                 if (pos < 2 * NQ) split2(pos * S2 + u);
                 else if (pos < 4 * NQ) split3((pos - 2 * NQ) * S2 + u);
             }
+            if (pos == 4 * NQ) split_special();
         });
-        pass(T3c{}, T6c{}, T6c{}, T9c{}, PH1{}, accB, [&](int pos) { ride_block(0, pos, accA, 0); });
-        pass(T6c{}, T9c{}, T9c{}, TNc{}, PH0{}, accA, [&](int pos) { ride_block(1, pos, accB, 3); });
-        pass(T9c{}, TNc{}, T0c{}, T3c{}, PH1{}, accB, [&](int pos) { ride_block(2, pos, accA, 6); });
+        pass(T3c{}, T6c{}, T6c{}, T9c{}, accB, [&](int pos) { ride_block(0, pos, accA, 0); });
+        pass(T6c{}, T9c{}, T9c{}, TNc{}, accA, [&](int pos) { ride_block(1, pos, accB, 3); });
+        pass(T9c{}, TNc{}, T0c{}, T3c{}, accB, [&](int pos) { ride_block(2, pos, accA, 6); });
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) zlag[o] = accB[0][L::HEAD_SLOT + o];
 #pragma unroll
-        for (int st = 0; st < 10; ++st) gate_stage(16 * NF32, st, accB, 9);       // the remainder units (RJ <= 4)
+        for (int st = 0; st < 9; ++st) gate_stage(16 * NF32, st, accB, 9);        // the remainder units (RJ <= 4)
     }
 
     // ---- the step in two segments, for the ping-pong kernels (split_kernels.h: prnn_flip_pp_kernel) -----------------
