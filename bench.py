@@ -360,6 +360,12 @@ def main():
                          "traffic_detail": traffic,
                          "hbm_frac_of_8TBps": ((traffic["hbm_bytes_per_launch"] / (flip_ms * 1e-3) / 8e12)
                                                if traffic and flip_ms > 0 else None),
+                         # clock the kernel held in an EARLIER profiler pass (GRBM_GUI_ACTIVE; the guide's peaks are quoted at
+                         # 2.4 GHz): informational, replayed like `traffic`, never the fraction
+                         "held_clock_ghz": (traffic or {}).get("held_clock_ghz"),
+                         "held_clock_source": (traffic or {}).get("held_clock_source"),
+                         "frac_at_held_clock": (achieved / peak * 2.4 / traffic["held_clock_ghz"]
+                                                if traffic and traffic.get("held_clock_ghz") else None),
                          "algorithmic_flops_per_launch": alg_flops_per_launch,
                          "mfma_flops_issued_per_launch": issued,
                          "avg_launch_ms": flip_ms,
