@@ -56,7 +56,7 @@ std::vector<char> pack_split_image(const rnnwf_handle* h) {
             } else {
                 const int s = 16 * (T - 3 * NF32) + rho;
                 if (s < 3 * RJ) { g = s / RJ; uo = L::unit_of(16 * NF32 + s % RJ, hh_row); }
-                // mode 2 and the streamed classic layout: the spare slots behind the remainder units carry the HEAD rows
+                // modes 2 and 3: the spare slots behind the remainder units carry the HEAD rows
                 // (g = 3 + o, both lane halves the same row): their kernels read the head of the state that ENTERED a step
                 // from its accumulators
                 else if ((MODE == 2 || L::STREAM) && s < L::HEAD_SLOT + NOUT) { g = 3 + (s - L::HEAD_SLOT); uo = 0; }

@@ -30,8 +30,12 @@
 //     unit (48 + hh) whose six products {w1 h1, w1 h2, w1 h3, w2 h1, w2 h2, w3 h1} fill six of the eight K entries of
 //     a 19th k-step.  95 MFMAs per 32-chain wave-step instead of 120; A fragments stay shared between products
 //     (image 50 KB instead of 60 KB).
-// Modes 1 and 2 take bias and one-hot input off the K axis: they are the accumulators' initial value, read from a
-// 1.3 KB table [sigma][tile][lane half][16] (rows differ, chains do not).
+//  3  the same K-packing at 69 <= num_units <= 100 (config 5): 48 aligned units per lane half (6 k-steps per part) + TWO
+//     special units whose 12 products fill two extra k-steps: 38 k-steps x 10 tiles = 380 MFMAs (mode 0 would need 420).
+//     Its 200 KB of fragments exceed LDS: the regular w3 fragments stay in global memory (STREAM, step_stream below).
+// Modes 1 - 3 take bias and one-hot input off the K axis: they are the accumulators' initial value, read from a
+// table [sigma][tile][lane half][16] (rows differ, chains do not).  Modes 2 and 3 also carry the head rows in spare
+// slots of the mixed tiles (pack_split.h).
 #pragma once
 #include <type_traits>
 

@@ -15,7 +15,7 @@ namespace {
 constexpr int NF32 = 3, RJ = 2, WAVES = 4;
 using L = SplitLayout<NF32, RJ, 1, 3>;
 using LC = SplitLayout<NF32, RJ, 3, 3>;                      // complex RNN: three head rows
-static_assert(L::STREAM && L::HP == 100 && LC::STREAM, "the streamed classic layout covers 100 units");
+static_assert(L::STREAM && L::HP == 100 && LC::STREAM, "layout mode 3 covers 100 units");
 }  // namespace
 
 int rnnwf::prnn_split_flip_stream(rnnwf_handle* h, const PrnnArgs& a, int kt16) {
