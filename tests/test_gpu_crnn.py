@@ -127,6 +127,23 @@ def test_both_swap_engines_agree_with_the_f64_oracle(N, H, ns, monkeypatch):
     assert np.allclose(got["f32"], got["bf16x3"], rtol=5e-5, atol=5e-5)
 
 
+@pytest.mark.parametrize("H", [20, 50, 64, 100])
+def test_copies_of_one_configuration_get_identical_values(H, monkeypatch):
+    """The complex RNN's swap pass: 80 copies of one zero-magnetisation configuration -> bit-identical local energies on
+    either engine, launch after launch (any difference is a scheduling hazard)."""
+    N = 16
+    prm = trained_like(H, seed=H)
+    s = np.repeat(zero_mag_batch(1, N, H), 80, axis=0)
+    J1, J2, Bz = np.ones(N), 0.3 * np.ones(N), np.zeros(N)
+    for engine in ("bf16x3", "f32"):
+        monkeypatch.setenv("RNNWF_ENGINE", engine)
+        wf = make_wf(N, H, prm)
+        e0, _ = wf.j1j2_eloc(s, J1, J2, Bz, False, False)
+        assert np.unique(e0).size == 1, (engine, np.unique(e0).size)
+        for _ in range(3):
+            assert np.array_equal(wf.j1j2_eloc(s, J1, J2, Bz, False, False)[0], e0)
+
+
 def test_j1j2_reference_style_loop_through_the_facade():
     """J1J2/TrainingRNN_J1J2.py:247-282 written against this package, compared with the fused call."""
     from rnnwavefunctions_amd import compat as tf

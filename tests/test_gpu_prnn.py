@@ -440,6 +440,28 @@ def test_stacked_layers_limits_and_facade():
     assert np.allclose(lp, M.prnn_log_probability(prm, smp), rtol=0, atol=1e-4)
 
 
+@pytest.mark.parametrize("H", [10, 20, 36, 44, 50, 64, 85, 100])
+def test_copies_of_one_configuration_get_identical_values(H, monkeypatch):
+    """96 copies of one spin configuration must give 96 bit-identical local energies on either engine, launch after
+    launch: chains differ only in lane / wave / workgroup, so any difference is a scheduling hazard (round 2 found one this
+    way: an inline-asm conversion in front of an MFMA that hipcc gave no wait states)."""
+    from rnnwavefunctions_amd import _lib
+    N = 24
+    prm = trained_like(H, seed=H)
+    rng = np.random.RandomState(H)
+    one = rng.randint(0, 2, (1, N)).astype(np.int32)
+    s = np.repeat(one, 96, axis=0)
+    for engine in ("bf16x3", "f32"):
+        monkeypatch.setenv("RNNWF_ENGINE", engine)
+        wf = make_wf(_lib.MODEL_GRU1D, N, H, prm)
+        lp = np.zeros((N + 1) * 96)
+        e0 = wf.tfim_eloc(s, np.ones(N), 1.0, log_probs=lp)
+        assert np.unique(e0).size == 1, (engine, np.unique(e0).size)
+        assert all(np.unique(lp.reshape(N + 1, 96)[r]).size == 1 for r in range(N + 1))
+        for _ in range(3):
+            assert np.array_equal(wf.tfim_eloc(s, np.ones(N), 1.0), e0)
+
+
 def test_stream_engine_edge_cases(monkeypatch):
     """The bf16x3 engine above 68 units (w3 fragments through L2): ragged batches (ns not a multiple of 32 or 16), the
     shortest chains (N = 2, 3), the parity-symmetric model, and a multi-pass call - all against the float64 oracle, and
