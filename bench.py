@@ -241,11 +241,31 @@ def main():
             from rnnwavefunctions_amd.distributed import ShardComm
             gloo_reduce = ShardComm.from_torch().allreduce
 
+    transport_note = {"fallback": None}
+
     def init_comm(w):                         # one RCCL communicator per handle: rank 0's unique id travels over gloo
-        if world > 1 and args.transport == "rccl":
+        nonlocal gloo_reduce
+        if world > 1 and args.transport == "rccl" and transport_note["fallback"] is None:
             box = [w.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
-            w.comm_init(box[0], rank, world)
+            err = None
+            try:
+                w.comm_init(box[0], rank, world)
+            except Exception as e:            # noqa: BLE001 - reported in the bench line, never hidden
+                err = "%s: %s" % (type(e).__name__, e)
+            # every rank must take the same road: if ncclCommInitRank failed anywhere, ALL ranks sum the four moments over
+            # the launcher's gloo group instead (32 bytes per step; the data path is unchanged) and the line says so
+            import torch
+            bad = torch.tensor([1.0 if err else 0.0], dtype=torch.float64)
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            if float(bad[0]) > 0:
+                errs = [None] * world
+                dist.all_gather_object(errs, err)
+                transport_note["fallback"] = "RCCL communicator could not be created (%s); moments all-reduced over gloo" % \
+                    "; ".join("rank %d: %s" % (i, e_) for i, e_ in enumerate(errs) if e_)
+                from rnnwavefunctions_amd.distributed import ShardComm
+                gloo_reduce = ShardComm.from_torch().allreduce
+                return
             w.comm_reduce_in_step(True)       # the step's moments come back already summed over the ranks
 
     def reduce_moments(w, m):                 # ONE all-reduce per step: (sum E, sum E^2, n, sum Im E)
@@ -343,7 +363,8 @@ def main():
                        "mean_E": mean_e, "var_E": var_e,
                        "engine": engine},
             # the communicator's own rank count (ncclCommCount), per rank with its device: N x dp1 cannot pass for dp-N
-            "rccl_nranks": min(i["nranks"] for i in infos) if args.transport == "rccl" else None,
+            "rccl_nranks": min(i["nranks"] for i in infos) if args.transport == "rccl" and not transport_note["fallback"] else None,
+            "transport_fallback": transport_note["fallback"],
             "ranks": [{"rank": i["pid_rank"], "comm_rank": i["rank"], "comm_nranks": i["nranks"], "device": i["device"]} for i in infos],
             "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "peak_is": peak_note,

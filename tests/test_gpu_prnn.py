@@ -6,6 +6,8 @@ Tolerances (fp32 cell, north_star: <E>/N within 1e-4 of the reference):
   E_loc             : relative 2e-5 per sample
   samples           : identical rows except near-ties |u - p0| < 1e-5 (rare, counted)
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -302,6 +304,37 @@ def test_rccl_all_reduce_over_two_gpus(tmp_path):
     wf = make_wf(_lib.MODEL_GRU1D, 16, 20, trained_like(20, seed=1))
     m = wf.vmc_step(600, seed=7, step=0, couplings=np.append(np.ones(16), 1.0))["moments"]
     assert g[2] == 600 and np.allclose(g[:4], m, rtol=1e-12)
+
+
+def test_bench_launcher_flow_with_two_ranks():
+    """The driver's multi-GPU command line (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`) with
+    two ranks.  On a one-GPU box both ranks sit on device 0 (--same-device): RCCL refuses that, every rank must then take
+    the gloo road for the 32-byte all-reduce and the line must say so; with two GPUs the line carries rccl_nranks = 2.
+    Either way: rendezvous, barriers, max-over-ranks timing, the sharded config-5 leg and ONE JSON line from rank 0."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    import torch
+    two = torch.cuda.device_count() >= 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-alt-engine", "--numsamples", "2000"] + ([] if two else ["--same-device"])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_numsamples"] == 4000 and d["value"] > 0
+    assert [x["rank"] for x in d["ranks"]] == [0, 1]
+    if two:
+        assert d["rccl_nranks"] == 2 and d["transport_fallback"] is None
+    else:
+        assert d["rccl_nranks"] is None and "gloo" in d["transport_fallback"]
 
 
 @pytest.mark.parametrize("N,H,ns", [(1, 10, 5), (2, 10, 1), (32, 20, 17), (33, 20, 16), (64, 36, 31), (200, 100, 19)])
