@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box): tools/r02_clock.sh <workload> -> GRBM_GUI_ACTIVE (shader-engine clock cycles the GPU was busy) per launch and
+# usage (GPU box): tools/held_clock.sh <workload> -> GRBM_GUI_ACTIVE (shader-engine clock cycles the GPU was busy) per launch and
 # kernel durations of the same run: clock held by the dominant kernel = cycles / duration
 w=${1:-cfg4}
 R=$GRAFT_REPO_ROOT
