@@ -209,7 +209,9 @@ int rnnwf_comm_destroy(rnnwf_handle* h);
  * kernel ids: 0 = base pass (sample / teacher-forced + checkpoints), 1 = flip pass (dominant),
  *             2 = local-energy assembly + moments.  total_ms / launches accumulate since the
  *             last rnnwf_timing_reset.  work[0] = cell evaluations, work[1] = MFMA flops issued
- *             (padding included) by the flip pass since the last reset.                         */
+ *             (padding included) by the flip pass since the last reset.
+ * rnnwf_timing_enable: on = 0 off, 1 all three groups, 2 the dominant pass (id 1) only - two events per step instead of
+ *             ten, which is what a throughput measurement wants beside its roofline figure.       */
 int rnnwf_timing_enable(rnnwf_handle* h, int32_t on);
 int rnnwf_timing_reset(rnnwf_handle* h);
 int rnnwf_timing_get(rnnwf_handle* h, int32_t kernel_id, double* total_ms, int64_t* launches, double* work);

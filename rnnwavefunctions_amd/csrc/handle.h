@@ -78,6 +78,7 @@ struct rnnwf_handle {
     void* pinned = nullptr;  // small pinned staging (moments)
 
     bool timing_on = false;
+    int timing_mask = 7;     // which kernel ids get HIP events (rnnwf_timing_enable: 1 = all, 2 = the dominant pass only)
     rnnwf::KernelTimer timers[3];
     double work[2] = {0.0, 0.0};
 
@@ -142,8 +143,9 @@ struct TimedLaunch {
     rnnwf_handle* h;
     int id;
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    bool on() const { return h->timing_on && ((h->timing_mask >> id) & 1); }
     TimedLaunch(rnnwf_handle* h_, int id_) : h(h_), id(id_) {
-        if (!h->timing_on) return;
+        if (!on()) return;
         KernelTimer& t = h->timers[id];
         if (!t.pool.empty()) {
             ev = t.pool.back();
@@ -155,7 +157,7 @@ struct TimedLaunch {
         hipEventRecord(ev.first, h->stream);
     }
     ~TimedLaunch() {
-        if (!h->timing_on) return;
+        if (!on()) return;
         hipEventRecord(ev.second, h->stream);
         h->timers[id].pending.push_back(ev);
     }

@@ -510,6 +510,7 @@ extern "C" int rnnwf_load_batch(rnnwf_handle* h, const int32_t* samples, int64_t
 extern "C" int rnnwf_timing_enable(rnnwf_handle* h, int32_t on) {
     if (!h) return RNNWF_ERR_INVALID;
     h->timing_on = on != 0;
+    h->timing_mask = on == 2 ? 2 : 7;      // 2: events around the dominant (flip / swap) pass only - two per step instead of ten
     return RNNWF_OK;
 }
 
