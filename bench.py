@@ -37,6 +37,8 @@ WORKLOADS = {
                  desc="2DTFIM_2DRNN 12x12 MDRNNcell num_units=50 numsamples=10000, f64 (BASELINE config 4)"),
     "2d1drnn": dict(kind="tfim2d_gru", Nx=12, Ny=12, N=144, H=50, ns=10000, Bx=3.0,
                     desc="2DTFIM_1DRNN 12x12 GRU over the raster path num_units=50 numsamples=10000, f64 (not a BASELINE config)"),
+    "w64": dict(kind="tfim1d", N=80, H=64, ns=10000, Bx=1.0,
+                desc="1DTFIM pRNN N=80 num_units=64 numsamples=10000 (not a BASELINE config: a width between the ping-pong and the streamed form)"),
     "cfg5": dict(kind="tfim1d", N=200, H=100, ns=32768, Bx=1.0,
                  desc="1DTFIM pRNN N=200 num_units=100 numsamples=32768 per GPU (BASELINE config 5 shard)"),
 }

@@ -52,12 +52,12 @@ __global__ void __launch_bounds__(WAVES * 64, (3 * NF32 + (3 * RJ + 15) / 16) <=
         num_up += sig_in;
         double re = 0.0, im = 0.0;
         unsigned R[3][NR];
-        u32x4 sf[2][L::STREAM ? C::SFN : 1];                // (> 68 units: w3 fragments read through L2, split_core.h)
+        u32x4 sf[2][L::RIDERS ? C::SFN : 1];                // (> 68 units: w3 fragments read through L2, split_core.h)
         if constexpr (L::STREAM) C::stream_first(C::stream_source(wsplit), sf, lane);
         for (int n = lo + 1; n < N; ++n) {
             if ((n & 31) == 0) word = a.bits[(int64_t)(n >> 5) * a.ns + s];
             const int sig = (int)((word >> (n & 31)) & 1) ^ (n == it.hi ? 1 : 0);
-            if constexpr (L::STREAM) {
+            if constexpr (L::RIDERS) {
                 // the step's accumulators carry the three head rows of the state that entered it: the logits of site n - 1
                 // (spin sig_in, up-spins before it num_up - sig_in); site lo is not part of the sum, the last site's logits
                 // come from the VALU head
@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(WAVES * 64, (3 * NF32 + (3 * RJ + 15) / 16) <=
             num_up += sig;
             sig_in = sig;
         }
-        if constexpr (L::STREAM) {                            // the last site's logits: VALU head on the final state
+        if constexpr (L::RIDERS) {                            // the last site's logits: VALU head on the final state
             if (lo + 1 < N) {
                 float z[3];
                 C::head(lds, h, lane, z);

@@ -57,10 +57,10 @@ double prnn_split_flops_per_step(rnnwf_handle* h);      // MFMA flops issued per
 int prnn_split_pack(rnnwf_handle* h, std::vector<char>& simg);
 // split_stream.hip: the same pass at 69..100 units (classic layout, w3 fragments read through L2)
 int prnn_split_flip_stream(rnnwf_handle* h, const PrnnArgs& a, int kt16);
-double prnn_split_stream_flops_per_step();
+double prnn_split_stream_flops_per_step(rnnwf_handle* h);
 int prnn_split_stream_pack(rnnwf_handle* h, std::vector<char>& simg);
 int crnn_split_swap_stream(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles, int kt16);
-double crnn_split_stream_flops_per_step();
+double crnn_split_stream_flops_per_step(rnnwf_handle* h);
 int crnn_split_stream_pack(rnnwf_handle* h, std::vector<char>& simg);
 int crnn_split_swap(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles);
 double crnn_split_flops_per_step(rnnwf_handle* h);

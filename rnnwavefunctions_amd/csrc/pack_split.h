@@ -59,7 +59,7 @@ std::vector<char> pack_split_image(const rnnwf_handle* h) {
                 // modes 2 and 3: the spare slots behind the remainder units carry the HEAD rows
                 // (g = 3 + o, both lane halves the same row): their kernels read the head of the state that ENTERED a step
                 // from its accumulators
-                else if ((MODE == 2 || L::STREAM) && s < L::HEAD_SLOT + NOUT) { g = 3 + (s - L::HEAD_SLOT); uo = 0; }
+                else if ((MODE == 2 || MODE == 3) && s < L::HEAD_SLOT + NOUT) { g = 3 + (s - L::HEAD_SLOT); uo = 0; }
             }
             if (g < 0 || uo >= H) continue;
             auto head_w = [&](int o, int ui) -> double {

@@ -139,44 +139,48 @@ struct CSLaunch {
     } while (0)
 
 
+// widths served by the riders form (split_stream.hip): 53..100 units (53..68: RNNWF_ENGINE=bf16x3-serial selects the padded
+// serial kernel of round 1 instead, for A/B runs: 5.55 against 4.56 ms at N=80, 64 units, 10 000 samples)
+bool riders(const rnnwf_handle* h) { return h->NFULL == 6 || (h->NFULL == 4 && h->knobs.engine != 3); }
+
 }  // namespace
 
 int rnnwf::prnn_split_flip(rnnwf_handle* h, const PrnnArgs& a) {
     const int kt16 = 4 * h->NFULL + 1;
-    if (h->NFULL == 6) return prnn_split_flip_stream(h, a, kt16);
+    if (riders(h)) return prnn_split_flip_stream(h, a, kt16);
     if (h->knobs.engine == 3) { SPLIT_DISPATCH(h, return K::flip(h, a, kt16)); }      // RNNWF_ENGINE=bf16x3-serial: A/B only
     else { SPLIT_DISPATCH(h, return K::flip_pp(h, a, kt16)); }
     return h->fail(RNNWF_ERR_INVALID, "no bf16x3 kernel for NFULL=%d", h->NFULL);
 }
 double rnnwf::prnn_split_flops_per_step(rnnwf_handle* h) {
-    if (h->NFULL == 6) return prnn_split_stream_flops_per_step();
+    if (riders(h)) return prnn_split_stream_flops_per_step(h);
     SPLIT_DISPATCH(h, return K::mfma_flops_per_step());
     return 0;
 }
 
 
 int rnnwf::prnn_split_pack(rnnwf_handle* h, std::vector<char>& simg) {
-    if (h->NFULL == 6) return prnn_split_stream_pack(h, simg);
+    if (riders(h)) return prnn_split_stream_pack(h, simg);
     SPLIT_DISPATCH(h, { simg = K::pack(h); return 0; });
     return h->fail(RNNWF_ERR_INVALID, "no bf16x3 layout for NFULL=%d", h->NFULL);
 }
 
 int rnnwf::crnn_split_swap(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles) {
     const int kt16 = 4 * h->NFULL + 1;
-    if (h->NFULL == 6) return crnn_split_swap_stream(h, a, max_tiles, kt16);
+    if (riders(h)) return crnn_split_swap_stream(h, a, max_tiles, kt16);
     if (h->knobs.engine == 3) { CSPLIT_DISPATCH(h, return K::swap(h, a, max_tiles, kt16)); }      // RNNWF_ENGINE=bf16x3-serial: A/B only
     else { CSPLIT_DISPATCH(h, return K::swap_pp(h, a, max_tiles, kt16)); }
     return h->fail(RNNWF_ERR_INVALID, "no bf16x3 cRNN kernel for NFULL=%d", h->NFULL);
 }
 double rnnwf::crnn_split_flops_per_step(rnnwf_handle* h) {
-    if (h->NFULL == 6) return crnn_split_stream_flops_per_step();
+    if (riders(h)) return crnn_split_stream_flops_per_step(h);
     CSPLIT_DISPATCH(h, return K::mfma_flops_per_step());
     return 0;
 }
 
 
 int rnnwf::crnn_split_pack(rnnwf_handle* h, std::vector<char>& simg) {
-    if (h->NFULL == 6) return crnn_split_stream_pack(h, simg);
+    if (riders(h)) return crnn_split_stream_pack(h, simg);
     CSPLIT_DISPATCH(h, { simg = K::pack(h); return 0; });
     return h->fail(RNNWF_ERR_INVALID, "no bf16x3 layout for NFULL=%d", h->NFULL);
 }

@@ -81,11 +81,13 @@ struct SplitLayout {
     // Mode 3 (69..100 units; 200 KB of fragments for 160 KB of LDS): the regular w3 fragments - used by ONE of the six
     // products - stay in global memory and are read through L2 (STREAM); LDS holds [NT][2][NQ] regular fragments, then
     // everything from OFF_ASP on (special fragments, tables) LSHIFT bytes lower than in the global image.
-    static constexpr bool STREAM = MODE == 3;
+    static constexpr bool RIDERS = MODE == 3;                                  // kernels: SplitCore::step_stream (one wave per SIMD)
+    static constexpr bool STREAM = MODE == 3 && BYTES > 160 * 1024;            // (53..68 units: the whole mode-3 image fits LDS)
     static constexpr size_t LDS_REG = (size_t)NT * 2 * NQ * 64 * 16;           // STREAM: regular fragments of parts 0, 1
     static constexpr size_t LSHIFT = STREAM ? OFF_ASP - LDS_REG : 0;
     static constexpr size_t LDS_BYTES = BYTES - LSHIFT;
     static_assert(MODE == 3 || BYTES <= 160 * 1024, "the image must fit LDS (mode 3 streams one weight part)");
+    static_assert(!STREAM || LDS_BYTES <= 160 * 1024, "mode 3: the resident part of the image must fit LDS");
     // unit owned by entry e of lane half hh
     static constexpr int unit_of(int e, int hh) {
         if (e < 16 * NF32) return 32 * (e / 16) + ((e % 16) & 3) + 8 * ((e % 16) >> 2) + 4 * hh;
@@ -309,9 +311,10 @@ struct SplitCore {
     // zlag: head rows of the state that ENTERED the step (the previous site's logits), from spare slots of the mixed tile
     static __device__ __forceinline__ void step_stream(const char* lds, StreamSrc gimg, int sig, float (&h)[NU], u32x4 (&sf)[2][SFN], int lane,
                                                        float (&zlag)[NOUT]) {
-        static_assert(MODE == 3 && NF32 == 3 && NT == 3 * NF32 + 1 && NQ % 2 == 0 && L::KSP <= 2 && 6 * NQ >= 36,
-                      "step_stream: mode 3, three unit blocks + one mixed tile, even number of streamed k-steps");
+        static_assert(MODE == 3 && (NF32 == 2 || NF32 == 3) && NT == 3 * NF32 + 1 && L::KSP <= 2 && (!L::STREAM || NQ % 2 == 0),
+                      "step_stream: mode 3, two or three unit blocks + one mixed tile; streamed: even number of streamed k-steps");
         constexpr int KSP = L::KSP, NS = L::NS;
+        constexpr bool STREAM = L::STREAM;
         const int hh = lane >> 5;
         asm volatile("" ::: "memory");
         // fragment addresses: three opaque LDS base addresses 64 KB apart + the DS instruction's 16-bit immediate (left
@@ -326,12 +329,17 @@ struct SplitCore {
         }
         const float* xc = reinterpret_cast<const float*>(lds + L::OFF_XC - L::LSHIFT) + (size_t)((sig * 2 + hh) * L::NUP);
         const f32x16* ci = reinterpret_cast<const f32x16*>(lds + L::OFF_CI - L::LSHIFT) + (size_t)sig * NT * 2 + hh;
-        // LDS-fed products (weight part, state part) in the order the state parts become available
-        constexpr int ORD[5][2] = {{1, 0}, {0, 0}, {1, 1}, {0, 1}, {0, 2}};
-        constexpr int NLR = 5 * NQ;                                 // LDS-fed regular k-steps; k-steps NLR .. NLR + KSP - 1: special
+        // LDS-fed products (weight part, state part) in the order the state parts become available; where the whole image is in
+        // LDS (53..68 units) the product (w3, h1) is the first of them, otherwise it is the streamed one
+        constexpr int NPL = STREAM ? 5 : 6;                         // LDS-fed products
+        constexpr int ORD[6][2] = {{STREAM ? 1 : 2, 0}, {STREAM ? 0 : 1, 0}, {STREAM ? 1 : 0, STREAM ? 1 : 0},
+                                   {STREAM ? 0 : 1, 1}, {0, STREAM ? 2 : 1}, {0, 2}};
+        constexpr int NLR = NPL * NQ;                               // LDS-fed regular k-steps; k-steps NLR .. NLR + KSP - 1: special
         constexpr int NL = NLR + KSP;
+        constexpr int PARTS = STREAM ? 2 : 3;                       // weight parts resident in LDS
         auto frag = [&](int t, int kl) -> u32x4 {
-            const int off = kl < NLR ? ((t * 2 + ORD[kl / NQ][0]) * NQ + kl % NQ) * 1024 : (int)L::LDS_REG + (t * KSP + (kl - NLR)) * 1024;
+            const int off = kl < NLR ? ((t * PARTS + ORD[kl / NQ][0]) * NQ + kl % NQ) * 1024
+                                     : (int)(L::OFF_ASP - L::LSHIFT) + (t * KSP + (kl - NLR)) * 1024;
             return *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(abase[off >> 16] + (off & 0xffff));
         };
         // ---- the split, pair by pair (entries 2 i, 2 i + 1 -> register i of every part); every step is exact
@@ -396,10 +404,13 @@ struct SplitCore {
         };
         // gate arithmetic of four units (entries e0 .. e0 + 3) in nine stages: r = sigmoid, u = sigmoid, c = tanh(xc + r q),
         // h' = c + u (h - c) on the pre-scaled accumulators (Act<float>)
-        float gr[4], gu[4], gc[4], gx[4];
+        constexpr int NPOS = (STREAM ? 6 : 6) * NQ + KSP;           // k-step positions of a pass
+        constexpr int GB = NPOS >= 36 ? 4 : 8;                      // units per rider batch: 9 stages x 16 / GB batches must fit a pass
+        static_assert(9 * (16 / GB) <= NPOS, "the gate riders of a unit block must fit the positions of a pass");
+        float gr[GB], gu[GB], gc[GB], gx[GB];
         auto gate_stage = [&](int e0, int st, const f32x16* acc, int T0) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < GB; ++u) {
                 const int e = e0 + u;
                 if (e >= NU) continue;
                 switch (st) {
@@ -417,7 +428,7 @@ struct SplitCore {
         };
         // the gates of unit block b (16 units, accumulators `acc` of the pass [T0, T0 + 3)) as riders of a later pass
         auto ride_block = [&](int b, int pos, const f32x16* acc, int T0) {
-            if (pos < 36) gate_stage(16 * b + 4 * (pos / 9), pos % 9, acc, T0);
+            if (pos < 9 * (16 / GB)) gate_stage(16 * b + GB * (pos / 9), pos % 9, acc, T0);
         };
         // One pass = the 6 NQ + KSP k-steps of tiles [T0, T1) in the position order  S L L L L L  S L L L L L ... P P
         // (S: a streamed k-step of (w3, h1), L: LDS-fed, P: special).  Fragments are requested ahead of their use: LDS-fed
@@ -450,42 +461,57 @@ struct SplitCore {
                 fill(pos);
                 asm volatile("" ::: "memory");
             };
+            if constexpr (STREAM) {
 #pragma unroll
-            for (int j = 0; j < NQ; ++j) {
-                mfma_all(sf[j & 1], R[0], j);                       // streamed k-step j: w3 x h1
-                fill(6 * j);
-                if (j + 2 < NQ) stream_request<T0, T1>(gimg, j + 2, sf[j & 1], lane);
-                else stream_request<N0, N1>(gimg, j + 2 - NQ, sf[j & 1], lane);    // sets 0, 1 of the next pass (or of the next site)
+                for (int j = 0; j < NQ; ++j) {
+                    mfma_all(sf[j & 1], R[0], j);                   // streamed k-step j: w3 x h1
+                    fill(6 * j);
+                    if (j + 2 < NQ) stream_request<T0, T1>(gimg, j + 2, sf[j & 1], lane);
+                    else stream_request<N0, N1>(gimg, j + 2 - NQ, sf[j & 1], lane);    // sets 0, 1 of the next pass (or of the next site)
 #pragma unroll
-                for (int i = 0; i < 5; ++i) lds_kstep(5 * j + i, 6 * j + 1 + i);
+                    for (int i = 0; i < 5; ++i) lds_kstep(5 * j + i, 6 * j + 1 + i);
+                }
+#pragma unroll
+                for (int k = 0; k < KSP; ++k) lds_kstep(NLR + k, 6 * NQ + k);
+            } else {
+#pragma unroll
+                for (int kl = 0; kl < NL; ++kl) lds_kstep(kl, kl);
             }
-#pragma unroll
-            for (int k = 0; k < KSP; ++k) lds_kstep(NLR + k, 6 * NQ + k);
         };
         using T0c = std::integral_constant<int, 0>;
         using T3c = std::integral_constant<int, 3>;
         using T6c = std::integral_constant<int, 6>;
         using T9c = std::integral_constant<int, 9>;
         using TNc = std::integral_constant<int, NT>;
-        // pass 1: h2 is first needed by LDS k-step 2 NQ (position 2 NQ + 2 NQ / 5 + 1 of the pass), h3 by k-step 4 NQ, the
-        // special registers by the last positions
+        // pass 1: the split's stage 2 rides positions [0, 2 NQ), stage 3 [2 NQ, 4 NQ), the special registers position 4 NQ: h2 is
+        // first needed by the third (streamed layout) / fourth (resident layout) LDS-fed product, h3 by the last one
         constexpr int S2 = (NPR + 2 * NQ - 1) / (2 * NQ);           // pairs per position, a stage done within 2 NQ positions
         f32x16 accA[3], accB[3];
-        pass(T0c{}, T3c{}, T3c{}, T6c{}, accA, [&](int pos) {
+        auto split_riders = [&](int pos) {
 #pragma unroll
             for (int u = 0; u < S2; ++u) {
                 if (pos < 2 * NQ) split2(pos * S2 + u);
                 else if (pos < 4 * NQ) split3((pos - 2 * NQ) * S2 + u);
             }
             if (pos == 4 * NQ) split_special();
-        });
-        pass(T3c{}, T6c{}, T6c{}, T9c{}, accB, [&](int pos) { ride_block(0, pos, accA, 0); });
-        pass(T6c{}, T9c{}, T9c{}, TNc{}, accA, [&](int pos) { ride_block(1, pos, accB, 3); });
-        pass(T9c{}, TNc{}, T0c{}, T3c{}, accB, [&](int pos) { ride_block(2, pos, accA, 6); });
+        };
+        f32x16* acc_last;                                           // the remainder tile's accumulators
+        if constexpr (NF32 == 3) {
+            pass(T0c{}, T3c{}, T3c{}, T6c{}, accA, split_riders);
+            pass(T3c{}, T6c{}, T6c{}, T9c{}, accB, [&](int pos) { ride_block(0, pos, accA, 0); });
+            pass(T6c{}, T9c{}, T9c{}, TNc{}, accA, [&](int pos) { ride_block(1, pos, accB, 3); });
+            pass(T9c{}, TNc{}, T0c{}, T3c{}, accB, [&](int pos) { ride_block(2, pos, accA, 6); });
+            acc_last = accB;
+        } else {
+            pass(T0c{}, T3c{}, T3c{}, T6c{}, accA, split_riders);
+            pass(T3c{}, T6c{}, T6c{}, TNc{}, accB, [&](int pos) { ride_block(0, pos, accA, 0); });
+            pass(T6c{}, TNc{}, T0c{}, T3c{}, accA, [&](int pos) { ride_block(1, pos, accB, 3); });
+            acc_last = accA;
+        }
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) zlag[o] = accB[0][L::HEAD_SLOT + o];
+        for (int o = 0; o < NOUT; ++o) zlag[o] = acc_last[0][L::HEAD_SLOT + o];
 #pragma unroll
-        for (int st = 0; st < 9; ++st) gate_stage(16 * NF32, st, accB, 9);        // the remainder units (RJ <= 4)
+        for (int st = 0; st < 9; ++st) gate_stage(16 * NF32, st, acc_last, 3 * NF32);   // the remainder units (RJ <= 4)
     }
 
     // ---- the step in two segments, for the ping-pong kernels (split_kernels.h: prnn_flip_pp_kernel) -----------------

@@ -43,11 +43,11 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_flip_split_kernel(PrnnArgs a,
         int sig_in = 1 - spin(i);
         double lp = 0.0;
         unsigned R[3][NR];
-        u32x4 sf[2][L::STREAM ? C::SFN : 1];
+        u32x4 sf[2][L::RIDERS ? C::SFN : 1];
         if constexpr (L::STREAM) C::stream_first(C::stream_source(wsplit), sf, lane);
         for (int n = i + 1; n < N; ++n) {
             const int sig = spin(n);
-            if constexpr (L::STREAM) {
+            if constexpr (L::RIDERS) {
                 // the step's accumulators carry the logits of the state that entered it (site n - 1, spin sig_in); site i is
                 // not part of the sum, the last site's logits come from the VALU head behind the loop
                 // (no branches in this loop body: with them hipcc moves the riders out from between the MFMAs, +19 %)
@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_flip_split_kernel(PrnnArgs a,
             }
             sig_in = sig;
         }
-        if constexpr (L::STREAM) {                            // the last site's logits: VALU head on the final state
+        if constexpr (L::RIDERS) {                            // the last site's logits: VALU head on the final state
             float z[1];
             C::head(lds, h, lane, z);
             float lp0, lp1;

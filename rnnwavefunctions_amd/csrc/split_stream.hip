@@ -1,6 +1,7 @@
-// split_stream.hip - bf16x3 flip pass (positive RNN, config 5) and swap pass (complex RNN) at 69..100 units: the K-packed layout whose regular w3 fragments are read through L2
-// (split_core.h: SplitLayout mode 3, SplitCore::step_stream).  A translation unit of its own: built WITHOUT
-// -amdgpu-mfma-vgpr-form (build.py), so that the 160 accumulator registers live in AGPRs next to ~210 VGPRs.
+// split_stream.hip - the "riders" form of the bf16x3 engine (split_core.h: SplitLayout mode 3, SplitCore::step_stream): one wave
+// per SIMD whose VALU work rides between its own MFMAs.  Flip pass of the positive RNN and swap pass of the complex RNN at
+// 69..100 units (config 5; regular w3 fragments read through L2) and at 53..68 units (whole image in LDS).  A translation unit
+// of its own: built WITHOUT -amdgpu-mfma-vgpr-form (build.py), so that the accumulators live in AGPRs next to ~250 VGPRs.
 #include <algorithm>
 
 #include "models.h"
@@ -12,46 +13,64 @@
 using namespace rnnwf;
 
 namespace {
-constexpr int NF32 = 3, RJ = 2, WAVES = 4;
-using L = SplitLayout<NF32, RJ, 1, 3>;
-using LC = SplitLayout<NF32, RJ, 3, 3>;                      // complex RNN: three head rows
-static_assert(L::STREAM && L::HP == 100 && LC::STREAM, "layout mode 3 covers 100 units");
+constexpr int WAVES = 4;
+template <int NF32, int RJ>
+struct RLaunch {
+    using L = SplitLayout<NF32, RJ, 1, 3>;
+    using LC = SplitLayout<NF32, RJ, 3, 3>;                  // complex RNN: three head rows
+    static int flip(rnnwf_handle* h, const PrnnArgs& a, int kt16) {
+        const void* fn = (const void*)prnn_flip_split_kernel<NF32, RJ, WAVES, 3>;
+        if (L::HP > 4 * kt16) return h->fail(RNNWF_ERR_INVALID, "bf16x3 layout wider than the checkpoint rows (%d > %d)", L::HP, 4 * kt16);
+        int bpc = 0;
+        if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, L::LDS_BYTES, &bpc)) return rc;
+        const int64_t ntiles = (int64_t)(a.N - 1) * ((a.ns + 31) / 32);
+        const int64_t need = (ntiles + WAVES - 1) / WAVES;
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
+        TimedLaunch tl(h, 1);
+        prnn_flip_split_kernel<NF32, RJ, WAVES, 3><<<grid, WAVES * 64, L::LDS_BYTES, h->stream>>>(a, h->wsplit.p, kt16);
+        RNNWF_HIP(h, hipGetLastError());
+        return 0;
+    }
+    static int swap(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles, int kt16) {
+        const void* fn = (const void*)crnn_swap_split_kernel<NF32, RJ, WAVES, 3>;
+        if (LC::HP > 4 * kt16) return h->fail(RNNWF_ERR_INVALID, "bf16x3 layout wider than the checkpoint rows (%d > %d)", LC::HP, 4 * kt16);
+        int bpc = 0;
+        if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, LC::LDS_BYTES, &bpc)) return rc;
+        const int64_t need = (max_tiles + WAVES - 1) / WAVES;
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
+        TimedLaunch tl(h, 1);
+        crnn_swap_split_kernel<NF32, RJ, WAVES, 3><<<grid, WAVES * 64, LC::LDS_BYTES, h->stream>>>(a, h->wsplit.p, kt16);
+        RNNWF_HIP(h, hipGetLastError());
+        return 0;
+    }
+};
+using R100 = RLaunch<3, 2>;                                  // 69..100 units (NFULL = 6 of the f32 layout)
+using R68 = RLaunch<2, 2>;                                   // 53..68 units (NFULL = 4)
+static_assert(R100::L::STREAM && R100::L::HP == 100 && R100::LC::STREAM, "layout mode 3 at 100 units streams its regular w3 fragments");
+static_assert(!R68::L::STREAM && R68::L::HP == 68 && !R68::LC::STREAM, "layout mode 3 at 68 units is LDS-resident");
 }  // namespace
 
 int rnnwf::prnn_split_flip_stream(rnnwf_handle* h, const PrnnArgs& a, int kt16) {
-    const void* fn = (const void*)prnn_flip_split_kernel<NF32, RJ, WAVES, 3>;
-    if (L::HP > 4 * kt16) return h->fail(RNNWF_ERR_INVALID, "bf16x3 layout wider than the checkpoint rows (%d > %d)", L::HP, 4 * kt16);
-    int bpc = 0;
-    if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, L::LDS_BYTES, &bpc)) return rc;
-    const int64_t ntiles = (int64_t)(a.N - 1) * ((a.ns + 31) / 32);
-    const int64_t need = (ntiles + WAVES - 1) / WAVES;
-    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
-    TimedLaunch tl(h, 1);
-    prnn_flip_split_kernel<NF32, RJ, WAVES, 3><<<grid, WAVES * 64, L::LDS_BYTES, h->stream>>>(a, h->wsplit.p, kt16);
-    RNNWF_HIP(h, hipGetLastError());
-    return 0;
+    return h->NFULL == 6 ? R100::flip(h, a, kt16) : R68::flip(h, a, kt16);
 }
-double rnnwf::prnn_split_stream_flops_per_step() { return (double)L::NT * L::KS * 32768.0; }
+double rnnwf::prnn_split_stream_flops_per_step(rnnwf_handle* h) {
+    return h->NFULL == 6 ? (double)R100::L::NT * R100::L::KS * 32768.0 : (double)R68::L::NT * R68::L::KS * 32768.0;
+}
 int rnnwf::prnn_split_stream_pack(rnnwf_handle* h, std::vector<char>& simg) {
-    simg = pack_split_image<NF32, RJ, 1, 3>(h);
+    if (h->NFULL == 6) simg = pack_split_image<3, 2, 1, 3>(h);
+    else simg = pack_split_image<2, 2, 1, 3>(h);
     return 0;
 }
 
-// ---- swap pass of the complex RNN at 69..100 units ---------------------------------------------------------------
+// ---- swap pass of the complex RNN -----------------------------------------------------------------------------------
 int rnnwf::crnn_split_swap_stream(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles, int kt16) {
-    const void* fn = (const void*)crnn_swap_split_kernel<NF32, RJ, WAVES, 3>;
-    if (LC::HP > 4 * kt16) return h->fail(RNNWF_ERR_INVALID, "bf16x3 layout wider than the checkpoint rows (%d > %d)", LC::HP, 4 * kt16);
-    int bpc = 0;
-    if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, LC::LDS_BYTES, &bpc)) return rc;
-    const int64_t need = (max_tiles + WAVES - 1) / WAVES;
-    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
-    TimedLaunch tl(h, 1);
-    crnn_swap_split_kernel<NF32, RJ, WAVES, 3><<<grid, WAVES * 64, LC::LDS_BYTES, h->stream>>>(a, h->wsplit.p, kt16);
-    RNNWF_HIP(h, hipGetLastError());
-    return 0;
+    return h->NFULL == 6 ? R100::swap(h, a, max_tiles, kt16) : R68::swap(h, a, max_tiles, kt16);
 }
-double rnnwf::crnn_split_stream_flops_per_step() { return (double)LC::NT * LC::KS * 32768.0; }
+double rnnwf::crnn_split_stream_flops_per_step(rnnwf_handle* h) {
+    return h->NFULL == 6 ? (double)R100::LC::NT * R100::LC::KS * 32768.0 : (double)R68::LC::NT * R68::LC::KS * 32768.0;
+}
 int rnnwf::crnn_split_stream_pack(rnnwf_handle* h, std::vector<char>& simg) {
-    simg = pack_split_image<NF32, RJ, 3, 3>(h);
+    if (h->NFULL == 6) simg = pack_split_image<3, 2, 3, 3>(h);
+    else simg = pack_split_image<2, 2, 3, 3>(h);
     return 0;
 }
