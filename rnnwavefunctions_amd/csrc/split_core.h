@@ -275,13 +275,13 @@ struct SplitCore {
         }
     }
 
-    // ---- STREAM images (mode 3, 69..100 units): the step with the regular w3 fragments read through L2 ---------------
+    // ---- mode 3 (53..100 units), the "riders" form of the step; above 68 units with the regular w3 fragments read through L2 ----
     // One wave per SIMD (accumulators in AGPRs, ~256 VGPRs), so a bf16 MFMA leaves room for ~5 VALU instructions of its
-    // OWN wave: the step is software-pipelined around its four tile passes
+    // OWN wave: the step is software-pipelined around its NF32 + 1 tile passes (NF32 = 2: 53..68 units, NF32 = 3: 69..100)
     //     split stage 1 (h1)  |  pass b = 0 .. NF32-1: unit block b (3 tiles)  <- rides: split stages 2, 3 (b = 0), gates of block b-1
     //                         |  last pass: remainder units (1 tile)          <- rides: gates of block NF32-1
     //     gates of the remainder units; the head rows of the ENTERING state come out of the remainder tile (zlag).
-    // The riders are laid out stage by stage - one stage of four units (or two state pairs) per k-step - so that
+    // The riders are laid out stage by stage - one stage of four or eight units (or two state pairs) per k-step - so that
     // neighbouring VALU instructions are independent: a wave issues in order, and a dependent exp -> add -> rcp chain
     // between two MFMAs would hold the next MFMA back for its whole latency.
     // K-step order inside a pass (6 NQ + KSP positions): products that need h1 only come first ((w2,h1), (w1,h1)), then
@@ -289,7 +289,8 @@ struct SplitCore {
     // over the pass, one in front of every five LDS-fed k-steps, requested two streamed k-steps (~1 100 cycles) ahead; the
     // last two requests of a pass fetch the first two sets of the NEXT pass (`sf` carries pass 1's from site to site);
     // the special k-steps (the remainder units' 6 products each, K-packed) close the pass.  38 k-steps x 10 tiles = 380
-    // MFMAs per wave-step (the classic layout - every part padded to 7 k-steps - had 420).
+    // MFMAs per wave-step at 100 units (the classic layout - every part padded to 7 k-steps - had 420).  At 53..68 units
+    // the whole image is in LDS: the six products are all LDS-fed ((w3,h1) first), 26 k-steps x 7 tiles = 182 MFMAs.
     static constexpr int SFN = 3;                                              // tiles per pass (a unit block's r, u, c tiles)
     // Buffer loads: one resource descriptor (4 SGPRs) for the image, the lane's 16-byte slot as the VGPR offset, the
     // fragment's position as the scalar offset - flat global loads made hipcc keep 70 loop-invariant 64-bit addresses
