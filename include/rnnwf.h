@@ -196,6 +196,9 @@ int rnnwf_allreduce_grads(rnnwf_handle* h);
 int rnnwf_comm_unique_id(void* id_out);
 int rnnwf_comm_init(rnnwf_handle* h, const void* id, int32_t rank, int32_t nranks);
 int rnnwf_allreduce_moments(rnnwf_handle* h, double* moments, int32_t count);
+/* The same all-reduce for `count` doubles of any length (gradient partial sums held by the caller, histories ...):
+ * host array -> pinned staging -> device -> ncclAllReduce(sum) on the handle's stream -> back; identity on one rank. */
+int rnnwf_allreduce_f64(rnnwf_handle* h, double* data, int64_t count);
 /* on != 0: rnnwf_vmc_step itself returns the moments summed over all ranks - the all-reduce runs on the handle's stream on
  * the device-resident moments, in front of the step's single host synchronisation (no second round trip per step).   */
 int rnnwf_comm_reduce_in_step(rnnwf_handle* h, int32_t on);

@@ -54,6 +54,7 @@ PROTOTYPES = {
     "rnnwf_comm_unique_id": (C.c_int, [_P]),
     "rnnwf_comm_init": (C.c_int, [_P, _P, _I32, _I32]),
     "rnnwf_allreduce_moments": (C.c_int, [_P, _F64P, _I32]),
+    "rnnwf_allreduce_f64": (C.c_int, [_P, _F64P, _I64]),
     "rnnwf_comm_info": (C.c_int, [_P, _P, _P, _P]),
     "rnnwf_comm_reduce_in_step": (C.c_int, [_P, _I32]),
     "rnnwf_comm_destroy": (C.c_int, [_P]),
@@ -310,6 +311,24 @@ class NativeWavefunction:
         m, mp = _f64(np.array(moments, dtype=np.float64))
         self._check(self.lib.rnnwf_allreduce_moments(self.h, mp, m.size))
         return m
+
+    def allreduce_f64(self, a):
+        """Sum over the ranks of a float64 array of any shape (rnnwf_allreduce_f64; identity without a communicator)."""
+        m = np.array(a, dtype=np.float64, order="C")
+        flat, fp = _f64(m.reshape(-1))
+        self._check(self.lib.rnnwf_allreduce_f64(self.h, fp, flat.size))
+        return flat.reshape(m.shape)
+
+    def allreduce_grads(self, grads):
+        """{name: array} summed over the ranks in ONE all-reduce (names in sorted order on every rank)."""
+        names = sorted(grads)
+        flat = self.allreduce_f64(np.concatenate([np.asarray(grads[k], dtype=np.float64).ravel() for k in names]))
+        out, off = {}, 0
+        for k in names:
+            n = int(np.asarray(grads[k]).size)
+            out[k] = flat[off:off + n].reshape(np.shape(grads[k]))
+            off += n
+        return out
 
     # -- measurement ------------------------------------------------------------------------------
     def timing_enable(self, on=True):

@@ -24,6 +24,7 @@ class Graph:
 
     def __init__(self):
         self.wavefunctions = []
+        self.opt_steps = []           # training ops built in this graph (apply_gradients): what a Saver keeps of the optimizer
 
     @contextlib.contextmanager
     def as_default(self):
@@ -386,30 +387,61 @@ class _Train:
             gv = list(grads_and_vars)
             if not gv or not isinstance(gv[0][0], _Gradient):
                 raise NotImplementedError("apply_gradients: pass what compute_gradients returned")
-            return _OptStep(self, gv[0][0].plan, global_step)
+            step = _OptStep(self, gv[0][0].plan, global_step)
+            g = get_default_graph()
+            if g is not None:
+                g.opt_steps.append(step)
+            return step
 
         def minimize(self, cost, global_step=None, var_list=None):
             return self.apply_gradients(self.compute_gradients(cost, var_list), global_step)
 
     class Saver:
         """tf.train.Saver() (:166): save / restore the wave functions of the graph as TF checkpoints (V2 tensor bundle,
-        tf_checkpoint.py)."""
+        tf_checkpoint.py) - and, like the reference's Saver (built after apply_gradients), the Adam slots, beta powers and
+        global step of the training ops built in the same graph, so that the reference's restore branch (:172-183)
+        resumes with its optimizer state instead of restarting Adam at t = 0."""
 
         def __init__(self, var_list=None):
             g = get_default_graph()
             self.wavefunctions = list(g.wavefunctions) if g is not None else []
+            self.opt_steps = list(g.opt_steps) if g is not None else []
+
+        def _wfs(self, sess):
+            return self.wavefunctions or (sess.graph.wavefunctions if getattr(sess, "graph", None) else [])
+
+        def _step_of(self, wf):
+            for st in self.opt_steps:
+                if st.plan.wf is wf:
+                    return st
+            return None
 
         def save(self, sess, save_path, global_step=None):
             from . import tf_checkpoint as T
+            from .training import Adam
             tensors = {}
-            for wf in self.wavefunctions or (sess.graph.wavefunctions if getattr(sess, "graph", None) else []):
+            for wf in self._wfs(sess):
                 tensors.update(wf.params)
+                st = self._step_of(wf)
+                if st is not None:
+                    adam = st.opt._adam or Adam(st.opt.beta1, st.opt.beta2, st.opt.epsilon)
+                    tensors.update(adam.state_tensors(wf.params, wf.scope))
+                    if isinstance(st.global_step, Variable):
+                        tensors["Variable"] = np.asarray(int(st.global_step.value), dtype=np.int32)
             T.write_checkpoint(str(save_path), tensors)
             return str(save_path)
 
         def restore(self, sess, save_path):
-            for wf in self.wavefunctions or (sess.graph.wavefunctions if getattr(sess, "graph", None) else []):
-                wf.restore(str(save_path))
+            from .training import Adam
+            for wf in self._wfs(sess):
+                opt_state = wf.restore(str(save_path))
+                st = self._step_of(wf)
+                if st is not None and opt_state is not None:
+                    if st.opt._adam is None:
+                        st.opt._adam = Adam(st.opt.beta1, st.opt.beta2, st.opt.epsilon)
+                    st.opt._adam.load_state(opt_state, list(wf.params))
+                    if isinstance(st.global_step, Variable) and opt_state.get("global_step") is not None:
+                        st.global_step.value = np.asarray(int(opt_state["global_step"]))
 
 
 train = _Train()

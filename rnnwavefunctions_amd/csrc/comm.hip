@@ -115,22 +115,49 @@ extern "C" int rnnwf_comm_reduce_in_step(rnnwf_handle* h, int32_t on) {
     return RNNWF_OK;
 }
 
+// Pinned staging of `bytes` (grown on demand, owned by the handle): a pageable source makes hipMemcpyAsync a hidden
+// synchronous copy through the runtime's own bounce buffer.
+static int ensure_staging(rnnwf_handle* h, size_t bytes) {
+    if (bytes <= h->staging_cap) return 0;
+    if (h->staging) RNNWF_HIP(h, hipHostFree(h->staging));
+    h->staging = nullptr;
+    h->staging_cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipHostMalloc(&h->staging, want, hipHostMallocDefault);
+    if (e != hipSuccess) return h->fail(RNNWF_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    h->staging_cap = want;
+    return 0;
+}
+
+// `count` doubles in pinned staging -> device scratch -> ncclAllReduce(sum) on the handle's stream -> staging; one host sync
+static int allreduce_staged(rnnwf_handle* h, size_t count) {
+    RNNWF_HIP(h, hipSetDevice(h->cfg.device));
+    if (int rc = rnnwf::ensure(h, h->reduce_scratch, count * sizeof(double))) return rc;
+    RNNWF_HIP(h, hipMemcpyAsync(h->reduce_scratch.p, h->staging, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    const int rc = g_rccl.all_reduce(h->reduce_scratch.p, h->reduce_scratch.p, count, kNcclFloat64, kNcclSum, h->comm, h->stream);
+    if (rc != 0) return h->fail(RNNWF_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.error_string ? g_rccl.error_string(rc) : "?");
+    RNNWF_HIP(h, hipMemcpyAsync(h->staging, h->reduce_scratch.p, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int rnnwf_allreduce_f64(rnnwf_handle* h, double* data, int64_t count) {
+    if (!h || count < 0 || (count > 0 && !data)) return RNNWF_ERR_INVALID;
+    if (!h->comm) {
+        if (h->nranks == 1) return RNNWF_OK;  // single device: the local sums are the global ones
+        return h->fail(RNNWF_ERR_STATE, "rnnwf_allreduce_f64: communicator not initialised");
+    }
+    if (count == 0) return RNNWF_OK;
+    if (int rc = ensure_staging(h, (size_t)count * sizeof(double))) return rc;
+    memcpy(h->staging, data, (size_t)count * sizeof(double));
+    if (int rc = allreduce_staged(h, (size_t)count)) return rc;
+    memcpy(data, h->staging, (size_t)count * sizeof(double));
+    return RNNWF_OK;
+}
+
 extern "C" int rnnwf_allreduce_moments(rnnwf_handle* h, double* moments, int32_t count) {
     if (!h || !moments || count < 1 || count > 64) return RNNWF_ERR_INVALID;
-    if (!h->comm) {
-        if (h->nranks == 1) return RNNWF_OK;  // single device: the local moments are the global ones
-        return h->fail(RNNWF_ERR_STATE, "rnnwf_allreduce_moments: communicator not initialised");
-    }
-    RNNWF_HIP(h, hipSetDevice(h->cfg.device));
-    if (int rc = rnnwf::ensure(h, h->moments, 64 * sizeof(double))) return rc;
-    memcpy(h->pinned, moments, (size_t)count * sizeof(double));
-    RNNWF_HIP(h, hipMemcpyAsync(h->moments.p, h->pinned, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    const int rc = g_rccl.all_reduce(h->moments.p, h->moments.p, (size_t)count, kNcclFloat64, kNcclSum, h->comm, h->stream);
-    if (rc != 0) return h->fail(RNNWF_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.error_string ? g_rccl.error_string(rc) : "?");
-    RNNWF_HIP(h, hipMemcpyAsync(h->pinned, h->moments.p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    RNNWF_HIP(h, hipStreamSynchronize(h->stream));
-    memcpy(moments, h->pinned, (size_t)count * sizeof(double));
-    return RNNWF_OK;
+    return rnnwf_allreduce_f64(h, moments, count);
 }
 
 extern "C" int rnnwf_allreduce_grads(rnnwf_handle* h) {
@@ -140,20 +167,15 @@ extern "C" int rnnwf_allreduce_grads(rnnwf_handle* h) {
         if (h->nranks == 1) return RNNWF_OK;
         return h->fail(RNNWF_ERR_STATE, "rnnwf_allreduce_grads: communicator not initialised");
     }
-    RNNWF_HIP(h, hipSetDevice(h->cfg.device));
     size_t total = 0;
     for (auto& kv : h->grads) total += kv.second.size();      // std::map: same order on every rank
-    std::vector<double> flat(total);
+    if (int rc = ensure_staging(h, total * sizeof(double))) return rc;
+    double* flat = static_cast<double*>(h->staging);
     size_t off = 0;
-    for (auto& kv : h->grads) { std::copy(kv.second.begin(), kv.second.end(), flat.begin() + off); off += kv.second.size(); }
-    if (int rc = rnnwf::ensure(h, h->gradQ, total * sizeof(double))) return rc;   // scratch (P/Q are dead after the GEMM)
-    RNNWF_HIP(h, hipMemcpyAsync(h->gradQ.p, flat.data(), total * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    const int rc = g_rccl.all_reduce(h->gradQ.p, h->gradQ.p, total, kNcclFloat64, kNcclSum, h->comm, h->stream);
-    if (rc != 0) return h->fail(RNNWF_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.error_string ? g_rccl.error_string(rc) : "?");
-    RNNWF_HIP(h, hipMemcpyAsync(flat.data(), h->gradQ.p, total * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+    for (auto& kv : h->grads) { std::copy(kv.second.begin(), kv.second.end(), flat + off); off += kv.second.size(); }
+    if (int rc = allreduce_staged(h, total)) return rc;
     off = 0;
-    for (auto& kv : h->grads) { std::copy(flat.begin() + off, flat.begin() + off + kv.second.size(), kv.second.begin()); off += kv.second.size(); }
+    for (auto& kv : h->grads) { std::copy(flat + off, flat + off + kv.second.size(), kv.second.begin()); off += kv.second.size(); }
     return RNNWF_OK;
 }
 

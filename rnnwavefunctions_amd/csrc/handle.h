@@ -76,6 +76,9 @@ struct rnnwf_handle {
     int64_t last_ns = 0;          // batch of the last rnnwf_vmc_step still resident (bits, hck, eloc)
     bool last_has_ckpt = false;
     void* pinned = nullptr;  // small pinned staging (moments)
+    void* staging = nullptr; // pinned staging of the host-side all-reduces (comm.hip), grown on demand
+    size_t staging_cap = 0;
+    rnnwf::DevBuf reduce_scratch;
 
     bool timing_on = false;
     int timing_mask = 7;     // which kernel ids get HIP events (rnnwf_timing_enable: 1 = all, 2 = the dominant pass only)

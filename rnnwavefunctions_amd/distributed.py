@@ -74,7 +74,7 @@ class ShardComm:
     ShardComm()                          single process (identity)
     ShardComm.from_torch(group=None)     any initialised torch.distributed group (gloo on CPU tensors; used by the
                                          2-process test on the one-GPU box, where RCCL cannot place two ranks on one device)
-    ShardComm.from_rccl(native)          RCCL through the C ABI (rnnwf_allreduce_moments / rnnwf_allreduce_grads)
+    ShardComm.from_rccl(native, r, w)    RCCL through the C ABI (in-step moments, rnnwf_allreduce_grads / rnnwf_allreduce_f64)
     """
 
     def __init__(self, rank=0, world=1, allreduce=None, native=None):
@@ -96,20 +96,38 @@ class ShardComm:
     @classmethod
     def from_rccl(cls, native, rank, world):
         """RCCL through the handle's communicator.  The moments of a `vmc_step` are summed over the ranks inside the step
-        (rnnwf_comm_reduce_in_step: in-stream all-reduce before the step's one host synchronisation), so `allreduce` of the
-        moments is the identity here; gradients go through rnnwf_allreduce_grads."""
-        native.comm_reduce_in_step(True)
-        return cls(rank, world, lambda a: np.asarray(a, dtype=np.float64), native=native)
+        (rnnwf_comm_reduce_in_step: in-stream all-reduce before the step's one host synchronisation), so `reduce_moments`
+        passes them through; `allreduce` / `allreduce_grads` of anything else go through rnnwf_allreduce_f64."""
+        if int(world) > 1:                # a single process never opened a communicator (init_rccl_from_env): nothing to reduce
+            native.comm_reduce_in_step(True)
+        return cls(rank, world, None, native=native)
+
+    def reduce_moments(self, m):
+        """The four moments of a vmc_step summed over the ranks.  With the RCCL transport the step itself has already
+        summed them on the stream (rnnwf_comm_reduce_in_step), so they pass through; every other array goes through
+        `allreduce`, which never passes anything through un-reduced."""
+        if self.native is not None:
+            return np.asarray(m, dtype=np.float64)
+        return self.allreduce(m)
 
     def allreduce(self, a):
-        if self.world == 1 or self._allreduce is None:
+        """Sum of a float64 array over the ranks."""
+        if self.world == 1:
             return np.asarray(a, dtype=np.float64)
+        if self.native is not None:       # RCCL through the C ABI (rnnwf_allreduce_f64)
+            return self.native.allreduce_f64(a)
+        if self._allreduce is None:
+            raise RuntimeError("ShardComm with world_size %d has no transport" % self.world)
         return self._allreduce(a)
 
     def allreduce_grads(self, grads):
         """{name: array} summed over ranks (one flat all-reduce, names in sorted order on every rank)."""
-        if self.world == 1 or self._allreduce is None:
+        if self.world == 1:
             return grads
+        if self.native is not None:
+            return self.native.allreduce_grads({k: np.ascontiguousarray(v, dtype=np.float64) for k, v in grads.items()})
+        if self._allreduce is None:
+            raise RuntimeError("ShardComm with world_size %d has no transport" % self.world)
         names = sorted(grads)
         flat = np.concatenate([np.asarray(grads[k], dtype=np.float64).ravel() for k in names])
         flat = self._allreduce(flat)

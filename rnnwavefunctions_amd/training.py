@@ -44,30 +44,57 @@ class Adam:
         return params
 
     # -- what tf.train.Saver() keeps of the optimizer (TrainingRNN_1DTFIM.py:163-166): slots <var>/Adam, <var>/Adam_1,
-    #    beta1_power / beta2_power (beta^(t+1) after t steps, float32 scalars) and the un-named global step `Variable`
+    #    beta1_power / beta2_power (beta^(t+1) after t steps, float32 scalars) and the un-named global step `Variable`.
+    #    NAMES ARE UNPINNED (no TF-written checkpoint exists here).  The reference calls apply_gradients INSIDE
+    #    `tf.variable_scope(wf.scope)` (:149-163), where TF-1's slot creator nests the slot under the current variable
+    #    scope again - "<scope>/<scope>/.../kernel/Adam" - and the non-slot beta powers take the NAME scope, which is the
+    #    third entry of that scope (sample :104, log_probability :112, the training block :149): "<scope>_2/beta1_power".
+    #    The writer emits those names; the reader (load_state) accepts any prefix.
     def state_tensors(self, params, scope):
         out = {}
         for k, v in params.items():
-            out[k + "/Adam"] = self.m.get(k, np.zeros(v.shape)).astype(v.dtype)
-            out[k + "/Adam_1"] = self.v.get(k, np.zeros(v.shape)).astype(v.dtype)
-        out[scope + "/beta1_power"] = np.array(self.b1 ** (self.t + 1), dtype=np.float32)
-        out[scope + "/beta2_power"] = np.array(self.b2 ** (self.t + 1), dtype=np.float32)
+            out[scope + "/" + k + "/Adam"] = self.m.get(k, np.zeros(v.shape)).astype(v.dtype)
+            out[scope + "/" + k + "/Adam_1"] = self.v.get(k, np.zeros(v.shape)).astype(v.dtype)
+        out[scope + "_2/beta1_power"] = np.array(self.b1 ** (self.t + 1), dtype=np.float32)
+        out[scope + "_2/beta2_power"] = np.array(self.b2 ** (self.t + 1), dtype=np.float32)
         out["Variable"] = np.array(self.t, dtype=np.int32)
         return out
 
     def load_state(self, opt, names):
-        """`opt` as returned by tf_checkpoint.split_saver_variables; slots are matched to `names` by their tail."""
-        tail = lambda k: k.split("/", 1)[-1]
+        """`opt` as returned by tf_checkpoint.split_saver_variables.  A slot belongs to the model variable whose name it
+        ends with once every leading repeat of the scope ("RNNwavefunction/", "RNNwavefunction_1/", ...) is stripped
+        from both - so "<scope>/<scope>/x/Adam" (TF-1's nesting), "<scope>/x/Adam" and "x/Adam" all find "<scope>/x".
+        Raises tf_checkpoint.CheckpointError when the file holds Adam slots but some variable gets none, or when the step
+        count cannot be recovered: a silent restart with zero moments is never taken."""
+        import re
+
+        def tail(name):
+            parts = name.split("/")
+            first = re.sub(r"_\d+$", "", names[0].split("/")[0]) if names else ""
+            while len(parts) > 1 and re.sub(r"_\d+$", "", parts[0]) == first:
+                parts = parts[1:]
+            return "/".join(parts)
         m = {tail(k): v for k, v in opt["m"].items()}
         v2 = {tail(k): v for k, v in opt["v"].items()}
+        if not m and not v2:
+            return                                             # a model-only checkpoint: fresh optimizer
+        missing = [k for k in names if tail(k) not in m or tail(k) not in v2]
+        if missing:
+            raise T.CheckpointError("the checkpoint holds Adam slots but none for %s (slot names found: %s)" %
+                                    (", ".join(missing), ", ".join(sorted(opt["m"])[:4]) + " ..."))
         for k in names:
-            if tail(k) in m and tail(k) in v2:
-                self.m[k] = np.asarray(m[tail(k)], dtype=np.float64)
-                self.v[k] = np.asarray(v2[tail(k)], dtype=np.float64)
+            self.m[k] = np.asarray(m[tail(k)], dtype=np.float64)
+            self.v[k] = np.asarray(v2[tail(k)], dtype=np.float64)
         if opt.get("global_step") is not None:
             self.t = int(opt["global_step"])
-        elif opt.get("beta1_power"):
-            self.t = max(int(round(np.log(opt["beta1_power"]) / np.log(self.b1))) - 1, 0)
+            return
+        # beta2^(t+1) stays a normal float32 to t ~ 1e5; beta1^(t+1) is zero from t ~ 980 on
+        for key, beta in (("beta2_power", self.b2), ("beta1_power", self.b1)):
+            p = opt.get(key)
+            if p is not None and 0.0 < p < 1.0 and np.log(p) / np.log(beta) < 2 ** 20 and p > 1e-30:
+                self.t = max(int(round(np.log(p) / np.log(beta))) - 1, 0)
+                return
+        raise T.CheckpointError("the checkpoint holds Adam slots but neither a global step nor a usable beta power")
 
 
 def cost_gradient(native, params, scope, mean_energy, norm, allreduce=False):
@@ -90,7 +117,7 @@ def _train(wf, params, scope, couplings, numsteps, numsamples, seed, lr, lr_of_i
     meanEnergy, varEnergy = history if history is not None else ([], [])
     for it in range(len(meanEnergy), numsteps + 1):       # `for it in range(len(meanEnergy),numsteps+1)` (:199): a restored run resumes
         m = wf.vmc_step(count, seed=seed, step=it, couplings=couplings, sample_offset=offset)["moments"]
-        s1, s2, n, si = comm.allreduce(m)
+        s1, s2, n, si = comm.reduce_moments(m)
         meanE = complex(s1 / n, si / n) if complex_energy else s1 / n
         varE = s2 / n - (s1 / n) ** 2
         meanEnergy.append(np.complex64(meanE) if complex_energy else meanE)

@@ -216,3 +216,114 @@ def test_c_side_initialiser_reproduces_numpy_randomstate(tmp_path):
     out = np.empty(5)
     lib.fill(C.c_uint(3), C.c_long(1), C.c_long(5), 1, 0, 2 * (25 + 10), out.ctypes.data_as(C.c_void_p))
     assert np.array_equal(out, b)
+
+
+def test_adam_slots_are_matched_by_suffix_and_never_dropped_silently():
+    """The reference calls apply_gradients inside tf.variable_scope(wf.scope) (TrainingRNN_1DTFIM.py:149-163), where TF-1
+    nests the slot names under the scope again; names are unpinned, so the reader accepts any scope prefix and refuses a
+    file whose slots it cannot place."""
+    from rnnwavefunctions_amd import tf_checkpoint as TC
+    from rnnwavefunctions_amd.training import Adam
+    prm = P.init_gru_params([4], seed=2)
+    names = list(prm)
+    rng = np.random.RandomState(1)
+    m = {k: rng.standard_normal(v.shape) for k, v in prm.items()}
+    v = {k: rng.random_sample(v.shape) for k, v in prm.items()}
+    for style in ("doubled", "plain", "bare", "numbered"):
+        def key(k):
+            bare = k.split("/", 1)[1]
+            return {"doubled": "RNNwavefunction/" + k, "plain": k, "bare": bare, "numbered": "RNNwavefunction_1/" + k}[style]
+        dump = dict(prm)
+        dump.update({key(k) + "/Adam": m[k].astype(np.float32) for k in names})
+        dump.update({key(k) + "/Adam_1": v[k].astype(np.float32) for k in names})
+        dump["RNNwavefunction_1/beta1_power"] = np.float32(0.9 ** 501)
+        dump["RNNwavefunction_1/beta2_power"] = np.float32(0.999 ** 501)
+        dump["RNNwavefunction_1/Variable"] = np.int32(500)
+        model, state = TC.split_saver_variables(dump)
+        assert set(model) == set(prm)
+        opt = Adam()
+        opt.load_state(state, names)
+        assert opt.t == 500
+        for k in names:
+            assert np.allclose(opt.m[k], m[k], rtol=1e-6) and np.allclose(opt.v[k], v[k], rtol=1e-6)
+    # slots for only some variables: loud
+    partial = dict(prm)
+    partial[names[0] + "/Adam"] = m[names[0]]
+    partial[names[0] + "/Adam_1"] = v[names[0]]
+    partial["Variable"] = np.int32(3)
+    _, state = TC.split_saver_variables(partial)
+    with pytest.raises(TC.CheckpointError, match="Adam slots but none for"):
+        Adam().load_state(state, names)
+    # no global step: the step count comes from beta2_power (beta1^(t+1) is zero in float32 from t ~ 980 on)
+    for t in (0, 7, 2000, 50000):
+        dump = dict(prm)
+        dump.update({k + "/Adam": m[k] for k in names})
+        dump.update({k + "/Adam_1": v[k] for k in names})
+        dump["beta1_power"] = np.float32(0.9 ** (t + 1))
+        dump["beta2_power"] = np.float32(0.999 ** (t + 1))
+        _, state = TC.split_saver_variables(dump)
+        assert state["global_step"] is None
+        opt = Adam()
+        opt.load_state(state, names)
+        assert abs(opt.t - t) <= max(1, t // 20000), (t, opt.t)
+    dump.pop("beta2_power")
+    dump["beta1_power"] = np.float32(0.0)
+    _, state = TC.split_saver_variables(dump)
+    with pytest.raises(TC.CheckpointError, match="neither a global step"):
+        Adam().load_state(state, names)
+    # a model-only checkpoint leaves a fresh optimizer
+    _, state = TC.split_saver_variables(dict(prm))
+    opt = Adam()
+    opt.load_state(state, names)
+    assert opt.t == 0 and not opt.m
+
+
+class _FakeNative:
+    def __init__(self):
+        self.calls = []
+
+    def comm_reduce_in_step(self, on=True):
+        self.calls.append(("reduce_in_step", on))
+
+    def comm_unique_id(self):
+        self.calls.append(("unique_id",))
+        return b"\0" * 128
+
+    def allreduce_f64(self, a):
+        self.calls.append(("allreduce_f64", np.size(a)))
+        return 2.0 * np.asarray(a, dtype=np.float64)            # "two ranks holding the same values"
+
+
+def test_comm_env_in_a_single_process_is_the_identity(monkeypatch):
+    """run_*(comm="env") without a launcher (or with --nproc-per-node 1): no communicator is opened, so the in-step
+    reduce must not be switched on (rnnwf_comm_reduce_in_step would answer 'communicator not initialised')."""
+    from rnnwavefunctions_amd import training as T
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    nat = _FakeNative()
+    comm = T._resolve_comm("env", nat)
+    assert (comm.rank, comm.world) == (0, 1) and nat.calls == []
+    m = np.array([1.0, 2.0, 3.0, 0.0])
+    assert np.array_equal(comm.reduce_moments(m), m) and np.array_equal(comm.allreduce(m), m)
+    g = {"a": np.ones(3)}
+    assert comm.allreduce_grads(g) is g and nat.calls == []
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    assert T._resolve_comm("env", nat).world == 1 and nat.calls == []
+
+
+def test_rccl_shardcomm_never_returns_unreduced_arrays():
+    """With the RCCL transport the step's moments arrive already summed (reduce_moments passes them through); every
+    other array - gradients included - goes through rnnwf_allreduce_f64."""
+    from rnnwavefunctions_amd import distributed as D
+    nat = _FakeNative()
+    comm = D.ShardComm.from_rccl(nat, 1, 2)
+    assert nat.calls == [("reduce_in_step", True)]
+    m = np.array([1.0, 2.0, 3.0, 0.0])
+    assert np.array_equal(comm.reduce_moments(m), m)
+    assert np.array_equal(comm.allreduce(m), 2 * m) and nat.calls[-1] == ("allreduce_f64", 4)
+    nat.allreduce_grads = lambda g: {k: 2.0 * v for k, v in g.items()}
+    g = comm.allreduce_grads({"w": np.ones((2, 2)), "b": np.arange(3.0)})
+    assert np.array_equal(g["w"], 2 * np.ones((2, 2))) and np.array_equal(g["b"], 2 * np.arange(3.0))
+    with pytest.raises(RuntimeError, match="no transport"):
+        D.ShardComm(0, 2).allreduce(m)
