@@ -41,6 +41,14 @@ WORKLOADS = {
                 desc="1DTFIM pRNN N=80 num_units=64 numsamples=10000 (not a BASELINE config: a width between the ping-pong and the streamed form)"),
     "cfg5": dict(kind="tfim1d", N=200, H=100, ns=32768, Bx=1.0,
                  desc="1DTFIM pRNN N=200 num_units=100 numsamples=32768 per GPU (BASELINE config 5 shard)"),
+    # SURVEY.md 8 row f4 "at speed": the parity-symmetric class (1DTFIM/RNNwavefunction_paritysym.py:80-145) and stacked layers
+    # units=[num_units]*num_layers (1DTFIM/TrainingRNN_1DTFIM.py:98) at config 2's size; not BASELINE configs
+    "cfg2_parity": dict(kind="tfim1d", N=80, H=50, ns=10000, Bx=1.0, parity=True,
+                        desc="1DTFIM parity-symmetric pRNN N=80 num_units=50 numsamples=10000 (config 2's size; both directions per configuration)"),
+    "cfg2_l2": dict(kind="tfim1d", N=80, H=50, ns=10000, Bx=1.0, layers=2,
+                    desc="1DTFIM pRNN N=80 units=[50,50] numsamples=10000 (config 2's size, two stacked GRU layers)"),
+    "cfg2_l3": dict(kind="tfim1d", N=80, H=50, ns=10000, Bx=1.0, layers=3,
+                    desc="1DTFIM pRNN N=80 units=[50,50,50] numsamples=10000 (config 2's size, three stacked GRU layers)"),
 }
 # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA = f32 vector peak; f64 matrix = f64 vector peak; bf16 MFMA
 # dense 2 500 TF/s.  The bf16x3 engine spends SIX bf16 products per f32 product (csrc/split_core.h), so the roof of
@@ -68,7 +76,8 @@ def f_cell(wl):
         return f_cell_gru(h) + 4 * h          # second Dense(2) head
     if wl["kind"] == "tfim2d":
         return 4 * h * h + 12 * h             # MDRNN: 4h^2 + 4dh + 4h
-    return f_cell_gru(h)
+    # stacked layers: every layer above the first has an h-wide input instead of the 2-wide one-hot: 6h^2 + 6h^2
+    return f_cell_gru(h) + (wl.get("layers", 1) - 1) * 12 * h * h
 
 
 def make_wavefunction(wl, device):
@@ -88,8 +97,9 @@ def make_wavefunction(wl, device):
         wf = _lib.NativeWavefunction(_lib.MODEL_MDRNN2D, wl["Nx"], wl["Ny"], (H,), device=device)
         couplings = np.append(np.ones(N), wl["Bx"])
     else:
-        prm = P.init_gru_params([H], seed=111)
-        wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D, N, 1, (H,), device=device)
+        L = wl.get("layers", 1)
+        prm = P.init_gru_params([H] * L, seed=111)
+        wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D_PARITY if wl.get("parity") else _lib.MODEL_GRU1D, N, 1, (H,) * L, device=device)
         couplings = np.append(np.ones(N), wl["Bx"])
     if scale != 1.0:
         prm = P.scale_kernels(prm, scale)
@@ -137,7 +147,7 @@ def cpu_baseline(wl, prm, target_seconds=15.0):
             "compiler": "gcc -O3 -march=native -fopenmp -fno-math-errno -ffp-contract=off (oracle/cport.py)"}
 
 
-def alt_engine_run(wl, couplings, warmup, steps):
+def alt_engine_run(wl, couplings, warmup, steps, last_step):
     """The same workload with the flip/swap pass forced onto the f32-input MFMA (RNNWF_ENGINE=f32), so that the
     line carries both engines; reported beside `value`, never instead of it."""
     os.environ["RNNWF_ENGINE"] = "f32"
@@ -152,8 +162,8 @@ def alt_engine_run(wl, couplings, warmup, steps):
     wf.timing_reset()
     wf.synchronize()
     t0 = time.perf_counter()
-    for it in range(steps):
-        m = wf.vmc_step(ns, seed=111, step=warmup + it, couplings=couplings)["moments"]
+    for it in range(steps):               # the last step has the index of the headline run's last step: same batch, comparable mean_E
+        m = wf.vmc_step(ns, seed=111, step=last_step - (steps - 1 - it), couplings=couplings)["moments"]
     wf.synchronize()
     dt = (time.perf_counter() - t0) / steps
     k = wf.timing_get(1)
@@ -161,7 +171,90 @@ def alt_engine_run(wl, couplings, warmup, steps):
     ach = k["cell_evals"] / launches * f_cell(wl) / (k["total_ms"] / launches * 1e-3) / 1e12
     return {"engine": wf.engine_name(), "value": ns * N / dt, "ms_per_step": dt * 1e3, "steps": steps,
             "roofline_frac": ach / PEAK_TFLOPS["f32"], "roofline_peak": PEAK_TFLOPS["f32"],
-            "avg_launch_ms": k["total_ms"] / launches, "mean_E": m[0] / m[2]}
+            "avg_launch_ms": k["total_ms"] / launches, "mean_E": m[0] / m[2], "mean_E_at_step": last_step}
+
+
+def oracle_local_energies(wl, prm, couplings, samples):
+    """E_loc of `samples` by the CPU oracle (the checker, never the thing measured): the C restatement of the reference
+    formulation for the one-layer positive RNN, the NumPy restatement (oracle/models.py, oracle/estimators.py) otherwise."""
+    from oracle import cport
+    from oracle import estimators as OE
+    from oracle import models as OM
+    N, kind = wl["N"], wl["kind"]
+    if kind == "tfim1d" and wl.get("layers", 1) == 1 and not wl.get("parity"):
+        return cport.ising_local_energies(prm, np.ones(N), wl["Bx"], samples, nthreads=cport.max_threads()), \
+            "C restatement of the reference formulation (oracle/c/rnnwf_oracle.c)"
+    name = "NumPy restatement (oracle/models.py + oracle/estimators.py)"
+    chunks = [samples[k:k + 256] for k in range(0, len(samples), 256)]
+    if kind == "tfim1d":
+        lp = OM.prnn_paritysym_log_probability if wl.get("parity") else OM.prnn_log_probability
+        return np.concatenate([OE.ising_local_energies(np.ones(N), wl["Bx"], c, lambda x: lp(prm, x)) for c in chunks]), name
+    if kind == "j1j2":
+        return np.concatenate([OE.j1j2_local_energies(np.ones(N), wl["J2"] * np.ones(N), np.zeros(N), c,
+                                                      lambda x: OM.crnn_log_amplitude(prm, x)) for c in chunks]), name
+    Nx, Ny = wl["Nx"], wl["Ny"]
+    if kind == "tfim2d":
+        return np.concatenate([OE.ising2d_local_energies(np.ones((Nx, Ny)), wl["Bx"], Nx, Ny, c,
+                                                         lambda x: OM.mdrnn_log_probability(prm, x)) for c in chunks]), name
+    return np.concatenate([OE.ising2d_local_energies(np.ones((Nx, Ny)), wl["Bx"], Nx, Ny, c,
+                                                     lambda x: OM.prnn_log_probability(prm, x, dtype=np.float64)) for c in chunks]), name
+
+
+# samples of the parity leg per workload: what ~10-15 s of the box's host cores score (config 2: the whole batch)
+PARITY_SAMPLES = {"cfg1": 500, "cfg2": 10000, "cfg3": 2048, "cfg4": 256, "cfg5": 512, "w64": 2000, "2d1drnn": 256,
+                  "cfg2_parity": 256, "cfg2_l2": 256, "cfg2_l3": 192}
+
+
+def parity_leg(workload, wl, wf, prm, couplings, step_index, offset, timed_moments):
+    """Validates the timed path's own output: the LAST timed step is run once more with its samples and local energies
+    returned (same seed / step / offset -> the same batch; its moments must reproduce the timed step's bit for bit), and
+    the oracle scores a spread subset (config 2: all) of that very sample matrix."""
+    ns, N = wl["ns"], wl["N"]
+    out = wf.vmc_step(ns, seed=111, step=step_index, couplings=couplings, sample_offset=offset, want_samples=True, want_eloc=True)
+    n = min(ns, PARITY_SAMPLES.get(workload, 256))
+    sub = np.unique(np.linspace(0, ns - 1, n).astype(np.int64))
+    t0 = time.perf_counter()
+    e_ref, oracle_name = oracle_local_energies(wl, prm, couplings, out["samples"][sub])
+    secs = time.perf_counter() - t0
+    e = np.asarray(out["eloc"])[sub]
+    d = np.abs(e - e_ref)
+    d_mean = abs(complex(np.mean(e.astype(np.complex128))) - complex(np.mean(np.asarray(e_ref).astype(np.complex128))))
+    tol = 1e-4                                # north_star: <E> within 1e-4 per site of the reference
+    return {"samples": int(len(sub)), "of": int(ns), "step": int(step_index),
+            "max_abs_dE_per_site": float(d.max() / N), "d_meanE_per_site": float(d_mean / N),
+            "tolerance_per_site": tol, "pass": bool(d.max() / N < tol and d_mean / N < tol),
+            "reproduces_timed_step": bool(np.array_equal(np.asarray(out["moments"]), np.asarray(timed_moments))),
+            "oracle": oracle_name, "oracle_seconds": secs}
+
+
+def train_leg(wl, wf, prm, couplings, steps, offset):
+    """the other third of a VMC iteration - rnnwf_vmc_gradient (back-propagation through time on the
+    MFMA + the weight-gradient GEMM) on the batch of the step before it; Adam itself runs on the host and is not timed."""
+    ns = wl["ns"]
+    shapes = {k.split("/", 1)[1]: v.shape for k, v in prm.items()}
+    wf.timing_enable(1)
+    wf.timing_reset()
+    t_step, t_grad = [], []
+    for it in range(steps + 1):
+        wf.synchronize()
+        t0 = time.perf_counter()
+        m = wf.vmc_step(ns, seed=111, step=1000 + it, couplings=couplings, sample_offset=offset)["moments"]
+        t1 = time.perf_counter()
+        mean_e = complex(m[0] / m[2], m[3] / m[2]) if wl["kind"] == "j1j2" else m[0] / m[2]
+        g = wf.vmc_gradient(mean_e, m[2], shapes)
+        t2 = time.perf_counter()
+        if it:                                # the first iteration packs the backward weight image
+            t_step.append(t1 - t0)
+            t_grad.append(t2 - t1)
+    bptt, gemm = wf.timing_get(3), wf.timing_get(4)
+    per = max(steps + 1, 1)
+    gnorm = float(np.sqrt(sum(float((v * v).sum()) for v in g.values())))
+    return {"steps": steps, "vmc_step_ms_median": float(np.median(t_step) * 1e3),
+            "gradient_ms_median": float(np.median(t_grad) * 1e3), "gradient_ms_mean": float(np.mean(t_grad) * 1e3),
+            "gradient_includes": "BPTT kernel(s) + weight-gradient GEMM + D2H of the gradient arrays + host unpacking",
+            "bptt_kernel_ms_per_iteration": bptt["total_ms"] / per, "bptt_launches_per_iteration": bptt["launches"] / per,
+            "tn_gemm_ms_per_iteration": gemm["total_ms"] / per, "tn_gemm_launches_per_iteration": gemm["launches"] / per,
+            "grad_l2_norm": gnorm, "finite": bool(np.isfinite(gnorm))}
 
 
 TRAFFIC_FILE = os.path.join("profiles", "pmc_traffic.json")
@@ -207,6 +300,9 @@ def main():
                     help="init: glorot-uniform as initialised; trained: kernels x 3 (sharper conditionals)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-engine", action="store_true", help="skip the extra f32-input-MFMA timing")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the last timed step's output")
+    ap.add_argument("--train", type=int, default=0, metavar="K",
+                    help="also time K training iterations' gradient (rnnwf_vmc_gradient) behind the timed region")
     ap.add_argument("--no-cfg5", action="store_true",
                     help="multi-GPU runs: skip the extra north-star config 5 leg (N=200, 100 units, 32768 samples per GPU)")
     ap.add_argument("--transport", default="rccl", choices=("rccl", "gloo"),
@@ -296,10 +392,15 @@ def main():
     wf.timing_reset()
     barrier(wf)
     t0 = time.perf_counter()
+    marks = [t0]
     for it in range(args.steps):
-        m = step(args.warmup + it)
+        m = step(args.warmup + it)            # ends with the step's one host synchronisation (the moments' D2H copy)
+        marks.append(time.perf_counter())
     barrier(wf)
     dt = time.perf_counter() - t0
+    dt_local = dt
+    step_ms = np.diff(marks) * 1e3
+    last_step = args.warmup + args.steps - 1
     flip = wf.timing_get(1)
     wf.timing_enable(1)
     wf.timing_reset()
@@ -316,6 +417,11 @@ def main():
         return float(t[0])
 
     dt = max_over_ranks(dt)
+    # every rank's own time per step beside the max that `value` is computed from: a straggler shows
+    per_rank_ms = [dt_local / args.steps * 1e3]
+    if dist is not None:
+        per_rank_ms = [None] * world
+        dist.all_gather_object(per_rank_ms, dt_local / args.steps * 1e3)
     # what each rank's communicator says about itself (ncclCommCount / ncclCommUserRank) and the GPU it sits on
     info = wf.comm_info()
     info["pid_rank"] = rank
@@ -355,7 +461,8 @@ def main():
         # the dominant kernel as rocprofv3 names it: 37..50 units run the ping-pong form of the bf16x3 engine
         # (RNNWF_ENGINE=bf16x3-serial pins the older 4-wave form for A/B runs)
         pp = engine == "bf16x3" and 37 <= wl["H"] <= 50 and os.environ.get("RNNWF_ENGINE") != "bf16x3-serial"
-        kernel = {"tfim1d": ("prnn_flip_pp_kernel" if pp else "prnn_flip_split_kernel") if engine == "bf16x3" else "prnn_flip_kernel",
+        kernel = {"tfim1d": "prnn_ml_flip_kernel" if wl.get("layers", 1) > 1 else
+                            ("prnn_flip_pp_kernel" if pp else "prnn_flip_split_kernel") if engine == "bf16x3" else "prnn_flip_kernel",
                   "j1j2": ("crnn_swap_pp_kernel" if pp else "crnn_swap_split_kernel") if engine == "bf16x3" else "crnn_swap_kernel",
                   "tfim2d": "mdrnn_flip_kernel", "tfim2d_gru": "prnn_flip_kernel<double>"}[wl["kind"]]
         traffic = load_traffic(args.workload)
@@ -365,11 +472,22 @@ def main():
                       if args.workload == "cfg2" else "samples*sites/sec (autoregressive sample+local_energy), " + args.workload,
             "value": value, "unit": "samples*sites/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": dtype, "data": "synthetic",
+            # the arithmetic the path computes in.  bf16x3: every f32 operand held EXACTLY as three bf16 parts, the six
+            # significant bf16 products accumulated in f32 (csrc/split_core.h) - f32-equivalent (both engines meet the same
+            # tolerance against the float64 oracle), not bitwise f32; the pure f32-input-MFMA run is `f32mfma_engine`
+            "dtype": dtype + (" (bf16x3 split, f32 accumulate)" if engine == "bf16x3" else ""),
+            "arithmetic": ("bf16x3: 3 exact bf16 parts per f32 operand, 6 bf16 MFMA products per f32 product, f32 accumulate; "
+                           "base pass / sampling on the f32-input MFMA" if engine == "bf16x3" else "%s-input MFMA, %s accumulate" % (dtype, dtype)),
+            "data": "synthetic",
+            # SURVEY.md 8(d) asks for the median of >= 20 steps: per-step wall times (each step ends with its own host
+            # synchronisation) of THIS rank; `ms_per_step` / `value` stay the barrier-bracketed total over K steps, max over ranks
+            "ms_per_step_median": float(np.median(step_ms)), "ms_per_step_min": float(step_ms.min()), "ms_per_step_max": float(step_ms.max()),
+            "value_at_median_step": world * ns * N / (float(np.median(step_ms)) * 1e-3),
+            "ms_per_step_per_rank": per_rank_ms,
             "config": {"workload": wl["desc"], "numsamples_per_gpu": ns, "global_numsamples": ns * world,
                        "sites": N, "num_units": wl["H"], "parallelism": "dp%d (sample shards, 1 %s all-reduce/step)" % (world, "RCCL" if args.transport == "rccl" else "gloo"),
                        "weights": "glorot-uniform RandomState(111), gate bias 1" + (", kernels x 3 (trained-like)" if args.weights == "trained" else ""),
-                       "mean_E": mean_e, "var_E": var_e,
+                       "mean_E": mean_e, "var_E": var_e, "mean_E_at_step": last_step,
                        "engine": engine},
             # the communicator's own rank count (ncclCommCount), per rank with its device: N x dp1 cannot pass for dp-N
             "rccl_nranks": min(i["nranks"] for i in infos) if args.transport == "rccl" and not transport_note["fallback"] else None,
@@ -405,8 +523,12 @@ def main():
         if cfg5 is not None:
             rec["cfg5_sharded"] = cfg5
         if engine == "bf16x3" and world == 1 and not args.no_alt_engine:
-            rec["f32mfma_engine"] = alt_engine_run(wl, couplings, args.warmup, max(args.steps // 2, 3))
-        if not args.no_cpu_baseline and world == 1 and wl["kind"] == "tfim1d":
+            rec["f32mfma_engine"] = alt_engine_run(wl, couplings, args.warmup, max(args.steps // 2, 3), last_step)
+        # the oracle as CHECKER of the timed path's own output (outside the timed region, like the cpu_baseline leg)
+        rec["parity"] = parity_leg(args.workload, wl, wf, prm, couplings, last_step, offset, m) if world == 1 and not args.no_parity else None
+        if args.train and world == 1:
+            rec["train"] = train_leg(wl, wf, prm, couplings, args.train, offset)
+        if not args.no_cpu_baseline and world == 1 and wl["kind"] == "tfim1d" and wl.get("layers", 1) == 1 and not wl.get("parity"):
             rec["cpu_baseline"] = cpu_baseline(wl, prm)
         else:
             rec["cpu_baseline"] = None

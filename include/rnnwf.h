@@ -210,10 +210,11 @@ int rnnwf_comm_destroy(rnnwf_handle* h);
 /* ---- measurement ------------------------------------------------------------------------------
  * HIP-event timing of the kernels on the handle's stream (bench.py's roofline leg).
  * kernel ids: 0 = base pass (sample / teacher-forced + checkpoints), 1 = flip pass (dominant),
- *             2 = local-energy assembly + moments.  total_ms / launches accumulate since the
+ *             2 = local-energy assembly + moments, 3 = back-propagation through time of rnnwf_vmc_gradient,
+ *             4 = its weight-gradient GEMM.  total_ms / launches accumulate since the
  *             last rnnwf_timing_reset.  work[0] = cell evaluations, work[1] = MFMA flops issued
  *             (padding included) by the flip pass since the last reset.
- * rnnwf_timing_enable: on = 0 off, 1 all three groups, 2 the dominant pass (id 1) only - two events per step instead of
+ * rnnwf_timing_enable: on = 0 off, 1 all groups, 2 the dominant pass (id 1) only - two events per step instead of
  *             ten, which is what a throughput measurement wants beside its roofline figure.       */
 int rnnwf_timing_enable(rnnwf_handle* h, int32_t on);
 int rnnwf_timing_reset(rnnwf_handle* h);

@@ -15,6 +15,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "c", "rnnwf_oracle.c")
 OUT = os.path.join(HERE, "_build", "librnnwf_oracle.so")
 STAMP = OUT + ".stamp"
+# AddressSanitizer + UndefinedBehaviorSanitizer build of the same source (tests/test_host.py runs the golden cases through
+# it in a child process with libasan preloaded; SURVEY.md 5: sanitizers on the CPU side only)
+OUT_SAN = os.path.join(HERE, "_build", "librnnwf_oracle_san.so")
 GRU = "multi_rnn_cell/cell_0/cudnn_compatible_gru_cell/"
 
 
@@ -45,13 +48,32 @@ def build(force=False):
     return OUT
 
 
+def build_sanitized():
+    """gcc -fsanitize=address,undefined -fno-sanitize-recover: any out-of-bounds access, misaligned load, signed
+    overflow or shift error in the C restatement aborts the process that loaded it."""
+    if os.path.exists(OUT_SAN) and os.path.getmtime(OUT_SAN) > os.path.getmtime(SRC):
+        return OUT_SAN
+    os.makedirs(os.path.dirname(OUT_SAN), exist_ok=True)
+    cmd = ["gcc", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           "-fopenmp", "-fPIC", "-std=c11", "-ffp-contract=off", "-shared", "-o", OUT_SAN, SRC, "-lm"]
+    subprocess.run(cmd, check=True, capture_output=True)
+    return OUT_SAN
+
+
+def sanitizer_runtime():
+    """Path of libasan.so for LD_PRELOAD (an ASan-instrumented .so cannot be dlopen'ed into a plain interpreter)."""
+    r = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True)
+    path = r.stdout.strip()
+    return path if r.returncode == 0 and os.path.isabs(path) and os.path.exists(path) else None
+
+
 _lib = None
 
 
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(build())
+        _lib = C.CDLL(build_sanitized() if os.environ.get("RNNWF_ORACLE_SANITIZED") == "1" else build())
         _lib.rnnwf_oracle_max_threads.restype = C.c_int
     return _lib
 

@@ -57,12 +57,18 @@ struct GLaunch {
         if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, lds, &bpc)) return rc;
         const int64_t need = (a.nsb + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
-        gru_bwd_kernel<T, NFULL, WAVES, NOUT><<<grid, WAVES * 64, lds, h->stream>>>(a);
+        {
+            TimedLaunch tl(h, 3);
+            gru_bwd_kernel<T, NFULL, WAVES, NOUT><<<grid, WAVES * 64, lds, h->stream>>>(a);
+        }
         RNNWF_HIP(h, hipGetLastError());
         int64_t rpb = (R + (int64_t)h->cu_count * 4 - 1) / ((int64_t)h->cu_count * 4);
         rpb = std::max<int64_t>(64, ((rpb + 3) / 4) * 4);
         const unsigned gblocks = (unsigned)((R + rpb - 1) / rpb);
-        tn_gemm_kernel<T, G::PCOLS / 16, G::QCOLS / 16><<<gblocks, 256, 0, h->stream>>>((const T*)a.P, (const T*)a.Q, R, rpb, (T*)dW);
+        {
+            TimedLaunch tl(h, 4);
+            tn_gemm_kernel<T, G::PCOLS / 16, G::QCOLS / 16><<<gblocks, 256, 0, h->stream>>>((const T*)a.P, (const T*)a.Q, R, rpb, (T*)dW);
+        }
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }
@@ -233,7 +239,10 @@ struct MLGrad {
         if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, lds, &bpc)) return rc;
         const int64_t need = (a.nsb + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
-        gru_upper_bwd_kernel<T, NFULL, WAVES, TOP, NOUT><<<grid, WAVES * 64, lds, h->stream>>>(a);
+        {
+            TimedLaunch tl(h, 3);
+            gru_upper_bwd_kernel<T, NFULL, WAVES, TOP, NOUT><<<grid, WAVES * 64, lds, h->stream>>>(a);
+        }
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }
@@ -242,8 +251,11 @@ struct MLGrad {
         int64_t rpb = (R + (int64_t)h->cu_count * 4 - 1) / ((int64_t)h->cu_count * 4);
         rpb = std::max<int64_t>(64, ((rpb + 3) / 4) * 4);
         const unsigned gblocks = (unsigned)((R + rpb - 1) / rpb);
-        if (upper) tn_gemm_kernel<T, GU::PCOLS / 16, GU::QCOLS / 16><<<gblocks, 256, 0, h->stream>>>(P, Q, R, rpb, dW);
-        else tn_gemm_kernel<T, G0::G::PCOLS / 16, G0::G::QCOLS / 16><<<gblocks, 256, 0, h->stream>>>(P, Q, R, rpb, dW);
+        {
+            TimedLaunch tl(h, 4);
+            if (upper) tn_gemm_kernel<T, GU::PCOLS / 16, GU::QCOLS / 16><<<gblocks, 256, 0, h->stream>>>(P, Q, R, rpb, dW);
+            else tn_gemm_kernel<T, G0::G::PCOLS / 16, G0::G::QCOLS / 16><<<gblocks, 256, 0, h->stream>>>(P, Q, R, rpb, dW);
+        }
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }

@@ -81,8 +81,8 @@ struct rnnwf_handle {
     rnnwf::DevBuf reduce_scratch;
 
     bool timing_on = false;
-    int timing_mask = 7;     // which kernel ids get HIP events (rnnwf_timing_enable: 1 = all, 2 = the dominant pass only)
-    rnnwf::KernelTimer timers[3];
+    int timing_mask = 31;    // which kernel ids get HIP events (rnnwf_timing_enable: 1 = all, 2 = the dominant pass only)
+    rnnwf::KernelTimer timers[5];   // 0 base pass, 1 flip / swap pass, 2 assembly, 3 gradient back-propagation, 4 weight-gradient GEMM
     double work[2] = {0.0, 0.0};
 
     rnnwf::Knobs knobs;

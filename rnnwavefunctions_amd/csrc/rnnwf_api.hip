@@ -511,7 +511,7 @@ extern "C" int rnnwf_load_batch(rnnwf_handle* h, const int32_t* samples, int64_t
 extern "C" int rnnwf_timing_enable(rnnwf_handle* h, int32_t on) {
     if (!h) return RNNWF_ERR_INVALID;
     h->timing_on = on != 0;
-    h->timing_mask = on == 2 ? 2 : 7;      // 2: events around the dominant (flip / swap) pass only - two per step instead of ten
+    h->timing_mask = on == 2 ? 2 : 31;      // 2: events around the dominant (flip / swap) pass only - two per step instead of ten
     return RNNWF_OK;
 }
 
@@ -540,7 +540,7 @@ extern "C" int rnnwf_timing_reset(rnnwf_handle* h) {
 }
 
 extern "C" int rnnwf_timing_get(rnnwf_handle* h, int32_t id, double* total_ms, int64_t* launches, double* work) {
-    if (!h || id < 0 || id > 2) return RNNWF_ERR_INVALID;
+    if (!h || id < 0 || id > 4) return RNNWF_ERR_INVALID;
     if (int rc = drain_timers(h)) return rc;
     if (total_ms) *total_ms = h->timers[id].total_ms;
     if (launches) *launches = h->timers[id].launches;

@@ -102,7 +102,10 @@ def test_j1j2_eloc_flags(periodic, marshall, J2v):
     assert np.allclose(e, e_ref, rtol=5e-5, atol=5e-5)
 
 
-@pytest.mark.parametrize("N,H,ns", [(16, 20, 60), (14, 50, 48), (12, 64, 40), (12, 100, 40), (10, 80, 33)])
+@pytest.mark.parametrize("N,H,ns", [(16, 20, 60), (14, 50, 48), (12, 64, 40), (12, 100, 40), (10, 80, 33),
+                                     # both sides of the bf16x3 engine's width-class boundaries (36|37, 50|51, 52|53, 68|69)
+                                     (12, 36, 33), (14, 37, 40), (10, 51, 33), (12, 52, 33), (12, 53, 40), (14, 60, 33),
+                                     (10, 68, 37), (12, 69, 33)])
 def test_both_swap_engines_agree_with_the_f64_oracle(N, H, ns, monkeypatch):
     """The J1-J2 swap pass on the bf16x3 engine (default; above 68 units with the w3 fragments read through L2) and on the
     f32-input MFMA (RNNWF_ENGINE=f32): both against the float64 oracle at the f32 tolerance, and each other."""
@@ -127,7 +130,7 @@ def test_both_swap_engines_agree_with_the_f64_oracle(N, H, ns, monkeypatch):
     assert np.allclose(got["f32"], got["bf16x3"], rtol=5e-5, atol=5e-5)
 
 
-@pytest.mark.parametrize("H", [20, 50, 64, 100])
+@pytest.mark.parametrize("H", [20, 36, 37, 50, 52, 53, 60, 64, 68, 69, 100])
 def test_copies_of_one_configuration_get_identical_values(H, monkeypatch):
     """The complex RNN's swap pass: 80 copies of one zero-magnetisation configuration -> bit-identical local energies on
     either engine, launch after launch (any difference is a scheduling hazard)."""
@@ -200,7 +203,8 @@ def test_vmc_step_j1j2():
 def test_config3_properties():
     """BASELINE config 3 (N=40, J2=0.5, num_units=50, numsamples=10000): zero magnetisation everywhere,
     finite local energies, connected-configuration count in the range the survey measured (~40 per sample),
-    and <E>/N against the oracle on a 32-sample subset."""
+    and E_loc / <E>/N against the oracle on 4 096 samples of the same sample matrix (~165 000 connected configurations
+    through the NumPy oracle, in chunks)."""
     N, H, ns = 40, 50, 10000
     prm = P.init_gru_params([H], seed=111, heads=HEADS)
     wf = make_wf(N, H, prm)
@@ -209,12 +213,13 @@ def test_config3_properties():
     s, e = out["samples"], out["eloc"]
     assert np.all(s.sum(axis=1) == N // 2)
     assert np.all(np.isfinite(e.real)) and np.all(np.isfinite(e.imag))
-    sub = np.arange(0, ns, ns // 32)[:32]
-    e_ref = E.j1j2_local_energies(np.ones(N), 0.5 * np.ones(N), np.zeros(N), s[sub],
-                                  lambda x: M.crnn_log_amplitude(prm, x))
+    sub = np.arange(0, ns, 2)[:4096]
+    e_ref = np.concatenate([E.j1j2_local_energies(np.ones(N), 0.5 * np.ones(N), np.zeros(N), s[sub[k:k + 512]],
+                                                  lambda x: M.crnn_log_amplitude(prm, x)) for k in range(0, 4096, 512)])
     per_site = np.abs(e[sub] - e_ref).max() / N
-    print("cfg3: max |E_loc diff| / N over 32 samples = %.2e" % per_site)
-    assert per_site < 1e-5
+    d_mean = abs(e[sub].astype(np.complex128).mean() - e_ref.astype(np.complex128).mean()) / N
+    print("cfg3: over 4096 samples max |E_loc diff| / N = %.2e, |<E> diff| / N = %.2e" % (per_site, d_mean))
+    assert per_site < 1e-5 and d_mean < 1e-5
     _, ncon = wf.j1j2_eloc(s, np.ones(N), 0.5 * np.ones(N), np.zeros(N))
     assert 30 * ns < ncon < 50 * ns
 

@@ -111,8 +111,8 @@ def test_vmc_step_2d_and_facade():
 
 def test_config4_at_full_size():
     """BASELINE config 4 exactly as stated (2DTFIM_2DRNN/run_2dTFIM.py:10: 12x12, num_units=50, numsamples=10000;
-    the 600 MB state buffer and the full persistent grid): energy per site of HIP vs the oracle on an 8-sample subset of
-    the same sample matrix, plus size-independent properties on the whole batch."""
+    the 600 MB state buffer and the full persistent grid): local energies and energy per site of HIP vs the float64 oracle on
+    512 samples of the same sample matrix (145 x 512 lattices of 144 sites), plus size-independent properties on the whole batch."""
     Nx = Ny = 12
     H, ns = 50, 10000
     prm = P.init_mdrnn_params(H, seed=111)
@@ -121,11 +121,13 @@ def test_config4_at_full_size():
     out = wf.vmc_step(ns, seed=111, step=0, couplings=np.append(Jz.ravel(), 3.0), want_samples=True, want_eloc=True)
     s, e = out["samples"], out["eloc"]
     assert np.all(np.isfinite(e))
-    sub = np.arange(0, ns, ns // 8)[:8]
-    e_ref = E.ising2d_local_energies(Jz, 3.0, Nx, Ny, s[sub], lambda x: M.mdrnn_log_probability(prm, x))
+    sub = np.arange(0, ns, ns // 512)[:512]
+    e_ref = np.concatenate([E.ising2d_local_energies(Jz, 3.0, Nx, Ny, s[sub[k:k + 64]], lambda x: M.mdrnn_log_probability(prm, x))
+                            for k in range(0, 512, 64)])
     per_site = np.abs(e[sub] - e_ref).max() / (Nx * Ny)
-    print("cfg4: max |E_loc diff| / N over 8 samples = %.2e" % per_site)
-    assert per_site < 1e-10
+    d_mean = abs(e[sub].mean() - e_ref.mean()) / (Nx * Ny)
+    print("cfg4: over 512 samples max |E_loc diff| / N = %.2e, |<E> diff| / N = %.2e" % (per_site, d_mean))
+    assert per_site < 1e-10 and d_mean < 1e-10
     assert s.shape == (ns, Nx, Ny) and set(np.unique(s)) <= {0, 1}
     # E_loc = diagonal - Bx * (sum of N positive ratios): strictly below the diagonal energy for every sample
     sz = 2.0 * s - 1.0

@@ -216,27 +216,45 @@ def test_vmc_step_is_sample_plus_eloc_plus_moments():
 
 
 def test_headline_config_energy_per_site_within_north_star():
-    """BASELINE config 2 (N=80, h=50, ns=10000): <E>/N of HIP vs the oracle on the same sample matrix
-    (oracle on a 64-sample subset: 81*64 chains), plus size-independent properties on the full batch."""
+    """BASELINE config 2 (N=80, h=50, ns=10000): the WHOLE batch against the oracle on the same sample matrix - the C
+    restatement of the reference formulation (81 x 10 000 chains scored from site 0 in <= 25 000-row chunks, oracle/c) -
+    north_star's acceptance statement (<E>/N within 1e-4 of the reference), held to 1e-5 here, per sample and for the mean;
+    plus the NumPy oracle on a subset (the two oracles are separate restatements) and size-independent properties."""
+    from oracle import cport
     from rnnwavefunctions_amd import _lib
     N, H, ns = 80, 50, 10000
     prm = P.init_gru_params([H], seed=111)
     wf = make_wf(_lib.MODEL_GRU1D, N, H, prm)
     Jz = np.ones(N)
     out = wf.vmc_step(ns, seed=111, step=0, couplings=np.append(Jz, 1.0), want_samples=True, want_eloc=True)
-    s, e = out["samples"], out["eloc"]
+    s, e, m = out["samples"], out["eloc"], out["moments"]
+    assert wf.engine_name() == "bf16x3"
     assert s.shape == (ns, N) and set(np.unique(s)) <= {0, 1}
     assert np.all(np.isfinite(e))
-    sub = np.arange(0, ns, ns // 64)[:64]
-    e_ref = E.ising_local_energies(Jz, 1.0, s[sub], lambda x: M.prnn_log_probability(prm, x))
-    per_site = np.abs(e[sub] - e_ref).max() / N
-    print("cfg2: max |E_loc diff| / N over 64 samples = %.2e ; mean diff / N = %.2e" %
-          (per_site, abs(e[sub].mean() - e_ref.mean()) / N))
+    e_ref = cport.ising_local_energies(prm, Jz, 1.0, s)
+    per_site = np.abs(e - e_ref).max() / N
+    d_mean = abs(e.mean() - e_ref.mean()) / N
+    print("cfg2, all %d samples: max |E_loc - oracle| / N = %.2e ; |<E> - <E>_oracle| / N = %.2e ; <E>/N = %.6f" %
+          (ns, per_site, d_mean, e.mean() / N))
     assert per_site < 1e-5
-    assert abs(e[sub].mean() - e_ref.mean()) / N < 1e-5          # north_star asks for 1e-4
+    assert d_mean < 1e-5                                           # north_star asks for 1e-4
+    assert abs(m[0] / m[2] - e_ref.mean()) / N < 1e-5              # the moments the step returns are those of this batch
+    sub = np.arange(0, ns, ns // 64)[:64]
+    e_np = E.ising_local_energies(Jz, 1.0, s[sub], lambda x: M.prnn_log_probability(prm, x))
+    assert np.abs(e[sub] - e_np).max() / N < 1e-5
     # off-diagonal part is a sum of N positive terms times -Bx: E_loc <= diagonal energy
     diag = -(np.where(s[:, :-1] == s[:, 1:], 1.0, -1.0)).sum(axis=1)
     assert np.all(e < diag)
+    # the same batch on the f32-input MFMA: the two engines agree per sample far inside the tolerance
+    import os
+    os.environ["RNNWF_ENGINE"] = "f32"
+    try:
+        wf32 = make_wf(_lib.MODEL_GRU1D, N, H, prm)
+    finally:
+        del os.environ["RNNWF_ENGINE"]
+    e32 = wf32.tfim_eloc(s, Jz, 1.0)
+    print("cfg2: max |E_loc(bf16x3) - E_loc(f32 MFMA)| / N = %.2e" % (np.abs(e - e32).max() / N))
+    assert np.abs(e32 - e_ref).max() / N < 1e-5 and np.abs(e - e32).max() / N < 1e-5
 
 
 def test_rccl_all_reduce_single_rank():
@@ -358,7 +376,10 @@ def test_edge_sizes(N, H, ns):
 
 @pytest.mark.parametrize("N,H,ns", [(20, 10, 100), (33, 20, 50), (40, 36, 64), (65, 50, 37), (30, 64, 33), (25, 44, 40),
                                      (25, 49, 40), (25, 52, 40), (25, 37, 33), (18, 17, 33), (18, 21, 33),
-                                     (20, 100, 40), (14, 70, 33), (12, 85, 70)])          # > 68 units: w3 fragments through L2
+                                     (20, 100, 40), (14, 70, 33), (12, 85, 70),           # > 68 units: w3 fragments through L2
+                                     # both sides of every width-class boundary of the bf16x3 engine (split.hip / split_stream.hip):
+                                     # flat <= 36 | aligned + special 37..50 | padded 51..52 | riders, LDS-resident 53..68 | streamed 69..100
+                                     (21, 51, 33), (22, 53, 40), (19, 60, 33), (23, 68, 37), (21, 69, 40), (17, 96, 33), (15, 99, 21)])
 def test_both_flip_engines_agree_with_the_f64_oracle(N, H, ns, monkeypatch):
     """The flip pass runs on the bf16x3 engine by default (three-way exact bf16 split of both operands, f32
     accumulate; csrc/split_core.h) and on the f32-input MFMA with RNNWF_ENGINE=f32.  Both must match the float64
@@ -474,7 +495,7 @@ def test_stacked_layers_limits_and_facade():
     assert np.allclose(lp, M.prnn_log_probability(prm, smp), rtol=0, atol=1e-4)
 
 
-@pytest.mark.parametrize("H", [10, 20, 36, 44, 50, 64, 85, 100])
+@pytest.mark.parametrize("H", [10, 20, 36, 37, 44, 50, 51, 52, 53, 60, 64, 68, 69, 85, 100])
 def test_copies_of_one_configuration_get_identical_values(H, monkeypatch):
     """96 copies of one spin configuration must give 96 bit-identical local energies on either engine, launch after
     launch: chains differ only in lane / wave / workgroup, so any difference is a scheduling hazard (round 2 found one this
@@ -629,11 +650,18 @@ def test_config5_shard_at_full_size():
     assert np.array_equal(np.concatenate([lo["samples"], hi["samples"]]), s)
     assert np.array_equal(np.concatenate([lo["eloc"], hi["eloc"]]), e)
     assert np.allclose(lo["moments"] + hi["moments"], m, rtol=1e-12)
-    sub = np.arange(0, ns, ns // 6)[:6]
-    e_ref = E.ising_local_energies(Jz, 1.0, s[sub], lambda x: M.prnn_log_probability(prm, x))
+    # 512 samples spread over the shard against the C oracle (201 x 512 chains of 200 sites from site 0: ~15 s of 16 cores),
+    # 6 of them also against the NumPy oracle
+    from oracle import cport
+    sub = np.arange(0, ns, ns // 512)[:512]
+    e_ref = cport.ising_local_energies(prm, Jz, 1.0, s[sub])
     per_site = np.abs(e[sub] - e_ref).max() / N
-    print("cfg5 shard: <E>/N = %.6f, max |E_loc - oracle|/N over 6 samples = %.2e" % (e.mean() / N, per_site))
-    assert per_site < 1e-4
+    d_mean = abs(e[sub].mean() - e_ref.mean()) / N
+    print("cfg5 shard: <E>/N = %.6f, over 512 samples: max |E_loc - oracle|/N = %.2e, |mean diff|/N = %.2e" %
+          (e.mean() / N, per_site, d_mean))
+    assert per_site < 2e-5 and d_mean < 1e-5
+    e_np = E.ising_local_energies(Jz, 1.0, s[sub[::86]], lambda x: M.prnn_log_probability(prm, x))
+    assert np.abs(e[sub[::86]] - e_np).max() / N < 2e-5
 
 
 def test_thousand_site_chain():

@@ -434,6 +434,47 @@ def test_reference_training_loop_of_1dtfim_runs_with_compat_as_tf():
     # a cost that is not the VMC cost is refused rather than mis-differentiated
     with pytest.raises(NotImplementedError):
         optimizer.compute_gradients(tf.reduce_mean(log_probs_))
+    # saver = tf.train.Saver() / saver.save / saver.restore (:166, :219, :172-183): the checkpoint holds the model AND the
+    # optimizer state of this graph's training op, and restore brings all of it back (Adam does not restart at t = 0)
+    import tempfile
+    from rnnwavefunctions_amd import tf_checkpoint as TC
+    with wf.graph.as_default():
+        saver = tf.train.Saver()
+    with tempfile.TemporaryDirectory() as d:
+        path = saver.save(sess, d + "/model.ckpt")
+        model, ostate = TC.split_saver_variables(TC.read_checkpoint(path))
+        assert len(model) == 8 and len(ostate["m"]) == 8 and ostate["global_step"] == numsteps + 1
+        adam = optimizer._adam
+        saved = ({k: v.copy() for k, v in wf.get_params().items()}, {k: v.copy() for k, v in adam.m.items()},
+                 {k: v.copy() for k, v in adam.v.items()}, adam.t)
+        for _ in range(2):                     # move on, then go back
+            samples = sess.run(samples_)
+            local_energies = Ising_local_energies(Jz, Bx, samples, queue_samples, log_probs_tensor, samples_placeholder, log_probs, sess)
+            sess.run(optstep, feed_dict={Eloc: local_energies, samp: samples, learningrate_placeholder: lr})
+        assert optimizer._adam.t == saved[3] + 2
+        saver.restore(sess, path)
+    assert optimizer._adam.t == saved[3] and int(sess.run(global_step)) == numsteps + 1
+    for k, v in wf.get_params().items():
+        assert np.array_equal(v, saved[0][k])
+        assert np.allclose(optimizer._adam.m[k], saved[1][k], rtol=1e-6, atol=1e-12)     # slots travel as float32
+        assert np.allclose(optimizer._adam.v[k], saved[2][k], rtol=1e-6, atol=1e-12)
+
+
+def test_comm_env_without_a_launcher_runs_as_a_single_process(monkeypatch):
+    """run_*(comm="env") with no launcher environment (or torchrun --nproc-per-node 1): no communicator exists, the run
+    is the plain single-process one."""
+    from rnnwavefunctions_amd.training import run_1DTFIM
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    kw = dict(numsteps=2, systemsize=8, num_units=6, numsamples=40, seed=5, verbose=False)
+    a, _ = run_1DTFIM(comm="env", **kw)
+    b, _ = run_1DTFIM(**kw)
+    assert a == b
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    c, _ = run_1DTFIM(comm="env", **kw)
+    assert c == b
 
 
 def test_reference_training_loop_of_j1j2_runs_with_compat_as_tf():

@@ -327,3 +327,51 @@ def test_rccl_shardcomm_never_returns_unreduced_arrays():
     assert np.array_equal(g["w"], 2 * np.ones((2, 2))) and np.array_equal(g["b"], 2 * np.arange(3.0))
     with pytest.raises(RuntimeError, match="no transport"):
         D.ShardComm(0, 2).allreduce(m)
+
+
+_SANITIZED_CASES = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from conftest import load_golden, golden_params
+from oracle import cport, models as M, estimators as E, philox
+from rnnwavefunctions_amd import params as P
+assert cport.lib()._name.endswith("librnnwf_oracle_san.so")
+g = load_golden("estimators_oracle_driven.npz")
+prm = golden_params(g, "g4a")
+# G4a: the reference's own Ising_local_energies driven by the oracle (N = 10, 2 400 samples -> two <= 25 000-row chunks)
+e, lp = cport.ising_local_energies(prm, g["g4a_Jz"], float(g["g4a_Bx"]), g["g4a_samples"], return_log_probs=True)
+assert np.allclose(lp, g["g4a_logp"], rtol=0, atol=3e-5) and np.allclose(e, g["g4a_eloc"], rtol=2e-5, atol=2e-5)
+e0 = cport.ising_local_energies(prm, g["g4a_Jz"], 0.0, g["g4a_samples"][:50])
+assert np.allclose(e0, g["g4a_eloc_bx0"], atol=1e-12)
+# ragged sizes around the 16-row register block, one thread and several, shortest chains, the widest cell
+rng = np.random.RandomState(0)
+for N, H, ns, nt in ((1, 3, 1, 1), (2, 5, 15, 1), (7, 20, 17, 3), (33, 50, 31, 0), (5, 100, 49, 2)):
+    q = P.randomize_biases(P.scale_kernels(P.init_gru_params([H], seed=N), 1.5), N + 1)
+    s = rng.randint(0, 2, (ns, N)).astype(np.int32)
+    assert np.allclose(cport.prnn_log_probability(q, s, nthreads=nt), M.prnn_log_probability(q, s), atol=2e-5)
+    ec = cport.ising_local_energies(q, np.ones(N), 0.7, s, nthreads=nt)
+    assert np.allclose(ec, E.ising_local_energies(np.ones(N), 0.7, s, lambda x: M.prnn_log_probability(q, x)), rtol=3e-5, atol=3e-5)
+    u = philox.uniforms(3, 1, 0, ns, N)
+    sc, lc = cport.prnn_sample(q, N, u, nthreads=nt)
+    sr, lr = M.prnn_sample(q, N, u)
+    assert (sc != sr).any(axis=1).sum() <= 1
+assert cport.prnn_log_probability(prm, np.zeros((0, 10), dtype=np.int32)).shape == (0,)
+print("sanitized oracle ok")
+"""
+
+
+def test_c_oracle_under_address_and_undefined_behaviour_sanitizers():
+    """sanitizers on the CPU side.  oracle/c/rnnwf_oracle.c built with -fsanitize=address,undefined
+    (-fno-sanitize-recover) runs the reference-generated golden case G4a, ragged block sizes and empty input in a child
+    process (libasan preloaded); any invalid access aborts it."""
+    import subprocess
+    import sys
+    rt = cport.sanitizer_runtime()
+    if rt is None:
+        pytest.skip("gcc has no libasan.so here")
+    cport.build_sanitized()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LD_PRELOAD=rt, RNNWF_ORACLE_SANITIZED="1", ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1", OMP_NUM_THREADS="4", PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, "-c", _SANITIZED_CASES, root], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "sanitized oracle ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
