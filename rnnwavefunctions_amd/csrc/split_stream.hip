@@ -19,6 +19,9 @@ struct RLaunch {
     using L = SplitLayout<NF32, RJ, 1, 3>;
     using LC = SplitLayout<NF32, RJ, 3, 3>;                  // complex RNN: three head rows
     static int flip(rnnwf_handle* h, const PrnnArgs& a, int kt16) {
+        if constexpr (RidersStepAsm<NF32, RJ, 1, L::STREAM>::kAvailable) {
+            if (h->knobs.engine != 4) return flip_asm(h, a, kt16);      // RNNWF_ENGINE=bf16x3-hipcc: the compiler-scheduled step, A/B only
+        }
         const void* fn = (const void*)prnn_flip_split_kernel<NF32, RJ, WAVES, 3>;
         if (L::HP > 4 * kt16) return h->fail(RNNWF_ERR_INVALID, "bf16x3 layout wider than the checkpoint rows (%d > %d)", L::HP, 4 * kt16);
         int bpc = 0;
@@ -28,6 +31,20 @@ struct RLaunch {
         const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
         TimedLaunch tl(h, 1);
         prnn_flip_split_kernel<NF32, RJ, WAVES, 3><<<grid, WAVES * 64, L::LDS_BYTES, h->stream>>>(a, h->wsplit.p, kt16);
+        RNNWF_HIP(h, hipGetLastError());
+        return 0;
+    }
+    // the same pass with the wave-step as one hand-scheduled asm block (split_riders_asm.h)
+    static int flip_asm(rnnwf_handle* h, const PrnnArgs& a, int kt16) {
+        const void* fn = (const void*)prnn_flip_riders_asm_kernel<NF32, RJ, WAVES>;
+        if (L::HP > 4 * kt16) return h->fail(RNNWF_ERR_INVALID, "bf16x3 layout wider than the checkpoint rows (%d > %d)", L::HP, 4 * kt16);
+        int bpc = 0;
+        if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, L::LDS_BYTES, &bpc)) return rc;
+        const int64_t ntiles = (int64_t)(a.N - 1) * ((a.ns + 31) / 32);
+        const int64_t need = (ntiles + WAVES - 1) / WAVES;
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
+        TimedLaunch tl(h, 1);
+        prnn_flip_riders_asm_kernel<NF32, RJ, WAVES><<<grid, WAVES * 64, L::LDS_BYTES, h->stream>>>(a, h->wsplit.p, kt16);
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }
