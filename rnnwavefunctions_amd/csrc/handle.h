@@ -29,6 +29,7 @@ struct KernelTimer {
 struct Knobs {
     int engine = 0;               // RNNWF_ENGINE: 0 default, 1 "f32" (f32-input MFMA everywhere), 2 "bf16x3" (pinned), 3 "bf16x3-serial" (pinned, 4-wave kernel without the ping-pong: A/B), 4 "bf16x3-hipcc" (pinned; 69..100 units: the compiler-scheduled riders step instead of the generated asm block: A/B)
     bool no_coop = false;         // RNNWF_NO_COOP=1: base pass always on the one-wave-per-block kernel
+    bool md_prefetch = false;     // RNNWF_MDRNN_PREFETCH=1: the MDRNN flip pass with the LDS-DMA prefetch of the vertical state (measured 1.7 % slower at config 4; A/B only)
     size_t state_budget = 0;      // RNNWF_STATE_BUDGET_MB << 20 (0: the family's default)
     int ablate = 0, ablate_base = 0;   // RNNWF_ABLATE / RNNWF_ABLATE_BASE: only in -DRNNWF_DIAGNOSTICS builds (tools/)
 };

@@ -38,7 +38,29 @@ struct MLaunch {
         *grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
         return 0;
     }
+    // prefetching variant (mdrnn_flip_pf_kernel): one 8-wave workgroup per CU, a staging slot per wave behind the spin words
+    static constexpr int PF_WAVES = 8;
+    static constexpr size_t PF_LDS = L::BYTES + (size_t)PF_WAVES * L::WORDS_BYTES + (size_t)PF_WAVES * ((L::KT + 1) / 2) * 1024;
+    static constexpr bool PF_FITS = PF_LDS <= 160 * 1024;
+    static int flip_pf(rnnwf_handle* h, MdArgs a) {
+        if constexpr (PF_FITS) {
+            const void* fn = (const void*)mdrnn_flip_pf_kernel<NFULL, PF_WAVES>;
+            int bpc = 0;
+            if (int rc = rnnwf::blocks_per_cu(h, fn, PF_WAVES * 64, PF_LDS, &bpc)) return rc;
+            const int64_t need = (a.ntiles + PF_WAVES - 1) / PF_WAVES;
+            const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
+            const size_t ring_bytes = (size_t)grid * PF_WAVES * a.Nx * ((L::KT + 1) / 2) * 64 * 16;
+            if (int rc = ensure(h, h->rowbuf, ring_bytes)) return rc;
+            a.ring = (double*)h->rowbuf.p;
+            a.ablate = h->knobs.ablate;
+            TimedLaunch tl(h, 1);
+            mdrnn_flip_pf_kernel<NFULL, PF_WAVES><<<grid, PF_WAVES * 64, PF_LDS, h->stream>>>(a);
+            RNNWF_HIP(h, hipGetLastError());
+        }
+        return 0;
+    }
     static int flip(rnnwf_handle* h, MdArgs a) {
+        if (PF_FITS && NFULL == 3 && h->knobs.md_prefetch) return flip_pf(h, a);      // A/B only: measured slower (profiles/r03_d_cfg4_prefetch.md)
         unsigned grid = 0;
         if (int rc = flip_grid(h, a.ntiles, &grid)) return rc;
         const size_t ring_bytes = (size_t)grid * WAVES * a.Nx * ((L::KT + 1) / 2) * 64 * 16;      // one slot per lattice column

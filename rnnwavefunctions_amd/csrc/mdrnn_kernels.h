@@ -96,8 +96,16 @@ struct MdCore {
     // Everything that needs only h_h (its half of the remainder-unit FMAs, the first 2 floor(KT/2) k-steps of the MFMA
     // chain) is issued before anything touches h_v: in the flip pass h_v is a 7 KB read from HBM that has then ~2 300
     // cycles to land.
+    struct NoFetch { __device__ __forceinline__ void operator()() const {} };
     static __device__ __forceinline__ void step(const char* lds, int sig_h, int sig_v, const double (&hh)[KT],
                                                 const double (&hv)[KT], double (&out)[KT], int lane, int rem, int ablate = 0) {
+        step_fetch(lds, sig_h, sig_v, hh, hv, out, lane, rem, ablate, NoFetch{});
+    }
+    // fetch_hv(): called once, after everything that needs only h_h has been issued and before the first use of hv - the
+    // prefetching flip kernel fills hv there (from its LDS staging slot) and starts the transfer of the next step's h_v
+    template <typename Fetch>
+    static __device__ __forceinline__ void step_fetch(const char* lds, int sig_h, int sig_v, const double (&hh)[KT],
+                                                      const double (&hv)[KT], double (&out)[KT], int lane, int rem, int ablate, Fetch&& fetch_hv) {
         const int q = lane >> 4;
         asm volatile("" ::: "memory");   // keep the weight fragments in LDS, not in registers (see gru_core.h)
         const double* tab = reinterpret_cast<const double*>(lds + L::OFF_TAB);
@@ -141,6 +149,7 @@ struct MdCore {
         constexpr int GH = KT / 2;                      // pairs made of h_h k-steps only
         if (!RNNWF_ABLATED(ablate, 16)) rem_part(0, KT);
         if (!RNNWF_ABLATED(ablate, 32)) mfma_part(0, GH);
+        fetch_hv();
         if (!RNNWF_ABLATED(ablate, 16)) rem_part(KT, 2 * KT);
         if (!RNNWF_ABLATED(ablate, 32)) mfma_part(GH, KT);
         // quarter q keeps unit j = q: lower half folds (s0, s1), upper half (s2, s3); then even rows keep the first
@@ -352,6 +361,133 @@ __global__ void __launch_bounds__(WAVES * 64, NFULL <= 3 ? 2 : 1) mdrnn_flip_ker
             lp += so ? lp1 : lp0;
             // the last row has no vertical successor: nothing reads its states
             if (p < N - Nx && !RNNWF_ABLATED(a.ablate, 1)) C::store_state(ring + (int64_t)nx * C::KP * 128, hn);
+            j = jn; ny = nyn;
+        }
+        if (valid && q == 0) a.lpq[(int64_t)a.row_of_pos[i] * a.ns + s] += lp;
+    }
+}
+
+// The flip pass with the vertical neighbour's state PREFETCHED one step ahead by LDS-DMA (global_load_lds_dwordx4: global
+// memory -> LDS without passing through registers; the kernel above has none to spare - 250 VGPRs at two waves per SIMD).
+// Per wave one 7 KB staging slot in LDS: the transfer of step p + 1's h_v (a base-pass state or one of the chain's own column
+// slots, written at least two steps earlier) starts in the middle of step p, right after step p's own h_v has been read out of
+// the slot, and has the rest of step p plus the h_h half of step p + 1 (~5 000 cycles) to land; the kernel above issues the
+// same 7 KB as register loads at the top of the step that needs them and waits ~1 000 cycles of their ~2 300 (profiles/
+// r02_cfg4_ablation.md: 4 - 5 ms of 23.5).  One workgroup of 8 waves per CU (one weight image instead of two).  Same
+// arithmetic, bit for bit.  MEASURED NEGATIVE (round 3, profiles/r03_d_cfg4_prefetch.md): 23.16 / 23.22 ms against 22.76 / 22.83 ms
+// of the kernel above on one box, alternating - the wait it removes is not where the time is: the pass runs at 0.93 of what
+// its f64 MFMA + f64 VALU instruction counts allow (they serialise on gfx950), and the slot's seven extra LDS reads and the
+// DMA issue cost more than the hidden latency gains.  Kept behind RNNWF_MDRNN_PREFETCH=1 for A/B runs only.
+template <int NFULL, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, 2) mdrnn_flip_pf_kernel(MdArgs a) {
+    using C = MdCore<NFULL>;
+    typedef typename C::V2 V2;
+    constexpr int KT = C::KT, KP = C::KP;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    C::stage(lds, a.wimg);
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t gw = (int64_t)blockIdx.x * WAVES + wave;
+    const int64_t nw = (int64_t)gridDim.x * WAVES;
+    const int N = a.N;
+    const int W = (N + 31) / 32;
+    const int Nx = a.Nx;
+    double* ring = a.ring + (int64_t)gw * Nx * KP * 128 + 2 * lane;
+    uint32_t* words = reinterpret_cast<uint32_t*>(lds + C::L::BYTES) + wave * 8 * 64 + lane;
+    char* slot = lds + C::L::BYTES + (size_t)WAVES * C::L::WORDS_BYTES + (size_t)wave * KP * 1024;      // [KP][64] double2, this wave's
+    typedef __attribute__((address_space(3))) void* LdsVoid;
+    typedef const __attribute__((address_space(1))) void* GlobVoid;
+    // global -> LDS: lane l's 16 bytes of piece g land at slot + g KB + 16 l (the layout load_state reads)
+    auto dma = [&](const double* base) {           // base includes + 2 * lane
+#pragma unroll
+        for (int g = 0; g < KP; ++g)
+            __builtin_amdgcn_global_load_lds((GlobVoid)(base + (size_t)g * 128), (LdsVoid)(slot + g * 1024), 16, 0, 0);
+    };
+    for (int64_t tile = gw; tile < a.ntiles; tile += nw) {
+        const int i = (int)(tile / a.nsb);
+        const int64_t sb = tile - (int64_t)i * a.nsb;
+        const int64_t s = sb * kChains + c;
+        const bool valid = s < a.ns;
+        const int64_t sc = valid ? s : a.ns - 1;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            uint32_t v = w < W ? a.bits[(int64_t)w * a.ns + sc] : 0u;
+            if (w == (i >> 5)) v ^= 1u << (i & 31);
+            words[w * 64] = v;
+        }
+        double hv[KT], hn[KT];
+        C::load_state(a.hs + (((int64_t)i * a.nsb + sb) * KP) * 128 + 2 * lane, hn);
+        int ny = (i + 1) / Nx, j = (i + 1) - ny * Nx;
+        double lp = 0.0;
+        auto bits_of = [&](int p, int jj, int nyy, int& sh, int& sv, int& so) {
+            const int pv = nyy > 0 ? p - 2 * jj - 1 : -1;
+            sh = jj == 0 ? -1 : (int)((words[((p - 1) >> 5) * 64] >> ((p - 1) & 31)) & 1);
+            sv = pv >= 0 ? (int)((words[(pv >> 5) * 64] >> (pv & 31)) & 1) : -1;
+            so = (int)((words[(p >> 5) * 64] >> (p & 31)) & 1);
+        };
+        // where position p's vertical neighbour comes from: 0 nothing (first row), 1 the state just computed (row turn),
+        // 2 memory - a base-pass state (pv <= i) or the chain's own column slot
+        auto source = [&](int p, int jj, int nyy, const double*& src) -> int {
+            const int pv = nyy > 0 ? p - 2 * jj - 1 : -1;
+            if (pv < 0) return 0;
+            if (pv == p - 1) return 1;
+            const int nx = (nyy & 1) ? Nx - 1 - jj : jj;
+            src = pv <= i ? a.hs + (((int64_t)pv * a.nsb + sb) * KP) * 128 + 2 * lane : ring + (int64_t)nx * KP * 128;
+            return 2;
+        };
+        int sig_h = -1, sig_v = -1, sig_o = 0;
+        if (i + 1 < N) bits_of(i + 1, j, ny, sig_h, sig_v, sig_o);
+        bool stores_behind = false;                    // ring stores issued after the transfer the coming step waits for
+        {
+            const double* src = nullptr;
+            if (i + 1 < N && source(i + 1, j, ny, src) == 2) dma(src);
+        }
+        for (int p = i + 1; p < N; ++p) {
+            const bool first = j == 0;
+            const int nx = (ny & 1) ? Nx - 1 - j : j;
+            const double* src_now = nullptr;
+            const int kind = source(p, j, ny, src_now);
+            if (kind == 0) {
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) hv[kt] = 0.0;
+            } else if (kind == 1) {
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) hv[kt] = hn[kt];
+            }
+            if (first) {
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) hn[kt] = 0.0;
+            }
+            const int sh = sig_h, sv = sig_v, so = sig_o;
+            int jn = j + 1, nyn = ny;
+            if (jn == Nx) { jn = 0; ++nyn; }
+            if (p + 1 < N) bits_of(p + 1, jn, nyn, sig_h, sig_v, sig_o);
+            const double* src_next = nullptr;
+            const int kind_next = p + 1 < N ? source(p + 1, jn, nyn, src_next) : 0;
+            C::step_fetch(lds, sh, sv, hn, hv, hn, lane, a.rem, a.ablate, [&]() {
+                if (kind == 2) {
+                    // this step's h_v: its transfer was issued in the middle of the previous step (or at the tile's start); the only
+                    // vector-memory operations behind it are that step's KP ring stores (counters: vmcnt 6 bits, lgkmcnt 4 bits)
+                    if (stores_behind) __builtin_amdgcn_s_waitcnt(0x0F70 | (KP & 15) | ((KP >> 4) << 14));
+                    else __builtin_amdgcn_s_waitcnt(0x0F70);
+                    asm volatile("" ::: "memory");
+                    const V2* st = reinterpret_cast<const V2*>(slot) + lane;
+#pragma unroll
+                    for (int g = 0; g < KP; ++g) {
+                        const V2 v = st[g * 64];
+                        hv[2 * g] = v[0];
+                        if (2 * g + 1 < KT) hv[2 * g + 1] = v[1];
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): the slot has been read before it is refilled
+                    asm volatile("" ::: "memory");
+                }
+                if (kind_next == 2) dma(src_next);
+            });
+            double lp0 = hn[0], lp1 = hn[1], p0;
+            if (!RNNWF_ABLATED(a.ablate, 4)) C::head(lds, hn, lane, lp0, lp1, p0);
+            lp += so ? lp1 : lp0;
+            stores_behind = p < N - Nx;
+            if (stores_behind) C::store_state(ring + (int64_t)nx * KP * 128, hn);
             j = jn; ny = nyn;
         }
         if (valid && q == 0) a.lpq[(int64_t)a.row_of_pos[i] * a.ns + s] += lp;
