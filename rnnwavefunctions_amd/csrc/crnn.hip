@@ -34,6 +34,7 @@ struct CLaunch {
         return 0;
     }
     static int base(rnnwf_handle* h, const CrnnArgs& a) {
+        if (NFULL <= 3 && base_bf_available(h)) return crnn_base_coop_bf(h, a);      // bf16 cooperative kernel, every batch size (prnn.hip)
         // fewer 16-chain blocks than SIMDs: the cooperative kernel (NFULL + 1 waves per block, bit-identical)
         if (NFULL <= 4 && a.nsb <= (int64_t)4 * h->cu_count && !h->knobs.no_coop) return base_coop(h, a);
         const void* fn = (const void*)crnn_base_kernel<NFULL, WAVES>;
@@ -249,6 +250,7 @@ int rnnwf::crnn_pack_image(rnnwf_handle* h, std::vector<char>& img) {
         RNNWF_HIP(h, hipStreamSynchronize(h->stream));
         RNNWF_HIP(h, hipMemcpy(h->wsplit.p, simg.data(), simg.size(), hipMemcpyHostToDevice));
     }
+    if (int rc = base_bf_pack(h)) return rc;
     CRNN_DISPATCH(h, { img = K::pack(h); return 0; });
     return h->fail(RNNWF_ERR_INVALID, "no cRNN kernel for NFULL=%d", h->NFULL);
 }

@@ -25,6 +25,7 @@ struct SwapItem {      // 16 bytes
 
 struct CrnnArgs {
     const void* wimg;
+    const void* wbf;           // bf16x3 A fragments of the cooperative base pass (BaseBfLayout), nullptr: none
     int32_t N;
     int64_t ns, nsb;
     uint32_t* bits;
@@ -133,8 +134,8 @@ __global__ void __launch_bounds__(WAVES * 64) crnn_base_kernel(CrnnArgs a) {
 
 // The same pass with NFULL + 1 waves per block of 16 chains (gru_kernels.h, coop_base_pass): used when there are fewer
 // blocks than SIMDs.  Bit-identical to crnn_base_kernel.
-template <int NFULL>
-__global__ void __launch_bounds__((NFULL + 1) * 64) crnn_base_coop_kernel(CrnnArgs a) {
+template <int NFULL, bool BF = false>
+__global__ void __launch_bounds__(BF ? (NFULL + 2) * 64 * BaseBfLayout<NFULL>::NB : (NFULL + 1) * 64) crnn_base_coop_kernel(CrnnArgs a) {
     using C = GruCore<float, NFULL, 3>;
     constexpr int KT = C::KT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -142,49 +143,53 @@ __global__ void __launch_bounds__((NFULL + 1) * 64) crnn_base_coop_kernel(CrnnAr
     const int N = a.N;
     int64_t s = 0, sc = 0;
     bool valid = false;
-    uint32_t word = 0;
+    uint32_t word = 0, word_in = 0;
     int num_up = 0;
     double re = 0.0, im = 0.0;
-    coop_base_pass<NFULL, 3>(
-        lds, a.wimg, N, a.nsb, a.hck, 0,
-        [&](int64_t sb) {
+    float u_next = 0.0f;
+    auto prefetch = [&](int n) {      // site n's uniform / word of given spins, fetched behind the publication of site n - 1's spin
+        if (a.sampling) u_next = philox_uniform(a.seed, a.step, (uint64_t)(a.sample_offset + sc), n);
+        else if ((n & 31) == 0) word_in = a.bits[(int64_t)(n >> 5) * a.ns + sc];
+    };
+    auto begin = [&](int64_t sb) {
             s = sb * kChains + c;
             valid = s < a.ns;
             sc = valid ? s : a.ns - 1;
             word = 0;
             num_up = 0;
             re = im = 0.0;
-        },
-        [&](int n, const float (&h)[KT]) -> int {
-            if (!a.sampling && (n & 31) == 0) word = a.bits[(int64_t)(n >> 5) * a.ns + sc];
+            prefetch(0);
+        };
+    auto site = [&](int n, const float (&h)[KT], auto&& publish) {
             float z[3];
             C::head(lds, h, lane, z);
             float la0, la1, w0, ph0, ph1;
             crnn_site(z, n, N, num_up, la0, la1, w0, ph0, ph1);
             int sig;
+            if (a.sampling) sig = (u_next < w0) ? 0 : 1;
+            else sig = (word_in >> (n & 31)) & 1;
+            publish(sig);                                               // the other waves wait for this
             if (a.sampling) {
-                const float u = philox_uniform(a.seed, a.step, (uint64_t)(a.sample_offset + sc), n);
-                sig = (u < w0) ? 0 : 1;
                 word |= (uint32_t)sig << (n & 31);
                 if (((n & 31) == 31 || n == N - 1) && valid && q == 0) a.bits[(int64_t)(n >> 5) * a.ns + s] = word;
                 if ((n & 31) == 31) word = 0;
-            } else {
-                sig = (word >> (n & 31)) & 1;
             }
             if (a.cb && valid && q == 0)
                 a.cb[(int64_t)n * a.ns + s] = make_double2(re + (double)(sig ? la0 : la1), im + (double)(sig ? ph0 : ph1));
             re += (double)(sig ? la1 : la0);
             im += (double)(sig ? ph1 : ph0);
             num_up += sig;
-            return sig;
-        },
-        [&](int64_t) {
+            if (n + 1 < N) prefetch(n + 1);
+        };
+    auto end = [&](int64_t) {
             if (valid && q == 0) {
                 if (a.tot) a.tot[s] = make_double2(re, im);
                 if (a.out_amp) a.out_amp[s] = make_float2((float)re, (float)im);
                 if (a.out_logp) a.out_logp[s] = 2.0 * re;
             }
-        });
+        };
+    if constexpr (BF) coop_base_pass_bf<NFULL, 3>(lds, a.wimg, a.wbf, N, a.nsb, a.hck, begin, site, end);
+    else coop_base_pass<NFULL, 3>(lds, a.wimg, N, a.nsb, a.hck, 0, begin, site, end);
 }
 
 // ---- connected configurations -----------------------------------------------------------------------

@@ -29,6 +29,8 @@ struct KernelTimer {
 struct Knobs {
     int engine = 0;               // RNNWF_ENGINE: 0 default, 1 "f32" (f32-input MFMA everywhere), 2 "bf16x3" (pinned), 3 "bf16x3-serial" (pinned, 4-wave kernel without the ping-pong: A/B), 4 "bf16x3-hipcc" (pinned; 69..100 units: the compiler-scheduled riders step instead of the generated asm block: A/B)
     bool no_coop = false;         // RNNWF_NO_COOP=1: base pass always on the one-wave-per-block kernel
+    bool base_f32 = false;        // RNNWF_BASE=f32: the base pass keeps the f32-input MFMA (no bf16 cooperative kernel): A/B, and the
+                                  // bit-identity test of the two f32 kernels
     bool md_prefetch = false;     // RNNWF_MDRNN_PREFETCH=1: the MDRNN flip pass with the LDS-DMA prefetch of the vertical state (measured 1.7 % slower at config 4; A/B only)
     size_t state_budget = 0;      // RNNWF_STATE_BUDGET_MB << 20 (0: the family's default)
     int ablate = 0, ablate_base = 0;   // RNNWF_ABLATE / RNNWF_ABLATE_BASE: only in -DRNNWF_DIAGNOSTICS builds (tools/)
@@ -69,6 +71,8 @@ struct rnnwf_handle {
     rnnwf::DevBuf gradDX[2];      // stacked layers: dL/dx of one layer's pass = dL/dh input of the pass below
     // bf16x3 engine (split_core.h): second weight image; engine_split = use it for the flip pass
     rnnwf::DevBuf wsplit;
+    rnnwf::DevBuf wbasebf;        // bf16x3 A fragments of the cooperative base pass (layout.h: BaseBfLayout); valid iff base_bf
+    bool base_bf = false;
     bool engine_split = false;
     bool engine_forced = false;   // RNNWF_ENGINE=bf16x3: no small-batch fallback to the f32-input MFMA
     int64_t call_ns = 0;          // samples of the whole API call (a call may run several passes: one engine for all)

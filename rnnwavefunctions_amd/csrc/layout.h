@@ -58,6 +58,26 @@ struct GruLayout {
     static constexpr size_t BYTES = ((OFF_BD + 32 + 15) / 16) * 16;
 };
 
+// bf16x3 operand image of the COOPERATIVE base pass (gru_kernels.h: coop_base_pass_bf; f32 models, NFULL <= 3): the same tiles,
+// rows and unit assignment as GruLayout, but the matrix products run on v_mfma_f32_16x16x32_bf16 with both operands held
+// exactly as three bf16 parts (split_core.h explains the arithmetic): A fragments [NT][3 parts][NKS][64 lanes] x 16 B, lane
+// (row = lane & 15, g = lane >> 4) holding the row's weights for the K entries 32 t + 8 g .. + 7 of k-step t.  K axis of one
+// part: the units in groups of 16, group m = wave m's units, entry 4 q + r of the group = unit 16 m + 4 r + q - the four units a
+// lane (c, q) of that wave produces are then four consecutive entries (one 8-byte store per part into the block's operand
+// buffer); the remainder group holds its units 16 NFULL + q at entries 4 q.  The bias / input / head tables stay GruLayout's.
+template <int NFULL_>
+struct BaseBfLayout {
+    static constexpr int NFULL = NFULL_;
+    static constexpr int NW = NFULL + 1;                    // waves per block of 16 chains = unit groups
+    static constexpr int KU = ((16 * NW + 31) / 32) * 32;   // K entries per part (padded to whole k-steps)
+    static constexpr int NKS = KU / 32;                     // k-steps per part
+    static constexpr int NO = KU / 8;                       // 16-byte octets per part and chain in the operand buffer
+    static constexpr int NT = 3 * NFULL + 1;
+    static constexpr size_t BYTES = (size_t)NT * 3 * NKS * 64 * 16;
+    static constexpr size_t PB_BYTES = (size_t)3 * NO * 16 * 16;   // operand buffer of one block: [part][octet][chain] x 16 B
+    static constexpr int NB = 3;                            // blocks of 16 chains per workgroup (share one image in LDS)
+};
+
 // Stacked GRU layers above the first (tf.nn.rnn_cell.MultiRNNCell, 1DTFIM/RNNwavefunction.py:32):
 // the input x is the new state of the layer below - already a B fragment - so one step is two blocks of
 // products into one set of accumulators,

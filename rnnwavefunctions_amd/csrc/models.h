@@ -65,6 +65,12 @@ int crnn_split_stream_pack(rnnwf_handle* h, std::vector<char>& simg);
 int crnn_split_swap(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles);
 double crnn_split_flops_per_step(rnnwf_handle* h);
 int crnn_split_pack(rnnwf_handle* h, std::vector<char>& simg);
+// cooperative base pass on the bf16 matrix core (gru_kernels.h: coop_base_pass_bf; f32 models, one layer, num_units <= 52):
+// base_bf_available: this handle has the image (h->wbasebf); *_base_coop_bf: the launches; base_bf_pack: at commit
+bool base_bf_available(const rnnwf_handle* h);
+int base_bf_pack(rnnwf_handle* h);
+int prnn_base_coop_bf(rnnwf_handle* h, const PrnnArgs& a);
+int crnn_base_coop_bf(rnnwf_handle* h, const CrnnArgs& a);
 
 // teacher-forced base pass with checkpoints on caller-supplied samples (rnnwf_load_batch)
 int prnn_load_batch(rnnwf_handle* h, const int32_t* samples, int64_t ns);

@@ -29,6 +29,48 @@ inline void split3(double w, uint16_t (&p)[3]) {
     }
 }
 
+// bf16x3 A fragments of the cooperative base pass (layout.h: BaseBfLayout): the rows of pack_gru_image (same scaled f32
+// weights), each split exactly into three bf16 parts.
+template <int NFULL>
+std::vector<char> pack_base_bf_image(const rnnwf_handle* h) {
+    using B = BaseBfLayout<NFULL>;
+    const int H = h->H;
+    std::vector<char> img(B::BYTES, 0);
+    const std::string pre = kGruPre;
+    const auto& Wg = pv(h, pre + "gates/kernel");
+    const auto& Wch = pv(h, pre + "candidate/hidden_projection/kernel");
+    const double sg = PackScale<float>::gate, sc = PackScale<float>::cand;
+    auto wt = [&](int gate, int unit, int k) -> double {
+        if (k >= H) return 0.0;
+        if (gate == 0) return sg * Wg[(size_t)(2 + k) * 2 * H + unit];
+        if (gate == 1) return sg * Wg[(size_t)(2 + k) * 2 * H + H + unit];
+        return sc * Wch[(size_t)k * H + unit];
+    };
+    uint16_t* A = reinterpret_cast<uint16_t*>(img.data());
+    for (int tile = 0; tile < B::NT; ++tile)
+        for (int row = 0; row < 16; ++row) {
+            const int q = row >> 2, r = row & 3;                // C/D row 4 q + r of the f32 16x16 output
+            int gate, unit;
+            if (tile < 3 * NFULL) { gate = tile / NFULL; unit = 16 * (tile % NFULL) + 4 * r + q; }
+            else { if (r == 3) continue; gate = r; unit = 16 * NFULL + q; }
+            if (unit >= H) continue;
+            for (int t = 0; t < B::NKS; ++t)
+                for (int g = 0; g < 4; ++g)
+                    for (int e = 0; e < 8; ++e) {
+                        const int kappa = 32 * t + 8 * g + e, grp = kappa / 16, loc = kappa % 16, kq = loc / 4, kr = loc % 4;
+                        int ku = -1;
+                        if (grp < NFULL) ku = 16 * grp + 4 * kr + kq;
+                        else if (grp == NFULL && kr == 0) ku = 16 * NFULL + kq;
+                        if (ku < 0 || ku >= H) continue;
+                        uint16_t p[3];
+                        split3((double)(float)wt(gate, unit, ku), p);
+                        const int lane = (g << 4) | row;
+                        for (int a = 0; a < 3; ++a) A[((((size_t)tile * 3 + a) * B::NKS + t) * 64 + lane) * 8 + e] = p[a];
+                    }
+        }
+    return img;
+}
+
 template <int NF32, int RJ, int NOUT = 1, int MODE = 0>
 std::vector<char> pack_split_image(const rnnwf_handle* h) {
     using L = SplitLayout<NF32, RJ, NOUT, MODE>;

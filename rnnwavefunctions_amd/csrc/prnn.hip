@@ -35,6 +35,9 @@ struct Launch {
         return 0;
     }
     static int base(rnnwf_handle* h, const PrnnArgs& a) {
+        // f32 models of 37..52 units: the cooperative kernel on the bf16 matrix core, for every batch size (a batch and its
+        // shards always take the same kernel); RNNWF_BASE=f32 / RNNWF_NO_COOP=1 keep the f32-input-MFMA kernels
+        if (std::is_same<T, float>::value && NFULL <= 3 && base_bf_available(h)) return prnn_base_coop_bf(h, a);
         if (std::is_same<T, float>::value && NFULL <= 4 && a.nsb <= (int64_t)4 * h->cu_count && !h->knobs.no_coop)
             return base_coop(h, a);
         const void* fn = (const void*)prnn_base_kernel<T, NFULL, WAVES>;
@@ -282,6 +285,7 @@ int rnnwf::prnn_pack_image(rnnwf_handle* h, std::vector<char>& img) {
         RNNWF_HIP(h, hipStreamSynchronize(h->stream));
         RNNWF_HIP(h, hipMemcpy(h->wsplit.p, simg.data(), simg.size(), hipMemcpyHostToDevice));
     }
+    if (int rc = base_bf_pack(h)) return rc;
     PRNN_DISPATCH(h, { img = K::pack(h); return 0; });
     return h->fail(RNNWF_ERR_INVALID, "no pRNN kernel for NFULL=%d f64=%d", h->NFULL, (int)h->f64);
 }

@@ -5,6 +5,7 @@
 // serialise anyway, so half the VALU instructions is a straight gain: config 5 0.79 -> 0.86 of the f32 pipe).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "crnn_split_kernels.h"
 #include "models.h"
@@ -144,6 +145,104 @@ struct CSLaunch {
 bool riders(const rnnwf_handle* h) { return h->NFULL == 6 || (h->NFULL == 4 && h->knobs.engine != 3); }
 
 }  // namespace
+
+// ---- cooperative base pass on the bf16 matrix core (gru_kernels.h: coop_base_pass_bf) ---------------------------------
+namespace {
+template <int NFULL>
+struct BfBase {
+    using B = BaseBfLayout<NFULL>;
+    template <int NOUT> static size_t lds_bytes() {
+        return GruLayout<float, NFULL, NOUT>::BYTES + B::BYTES + (size_t)B::NB * (B::PB_BYTES + (size_t)2 * (4 * NFULL + 1) * 64 * 4 + 2 * 64 * 4);
+    }
+    template <typename Args, typename Kern>
+    static int launch(rnnwf_handle* h, const Args& a, Kern kern, size_t lds) {
+        const void* fn = (const void*)kern;
+        const int threads = B::NB * (B::NW + 1) * 64;              // per block: NW product / gate waves + the sampler
+        int bpc = 0;
+        if (int rc = rnnwf::blocks_per_cu(h, fn, threads, lds, &bpc)) return rc;
+        // every CU gets work before any workgroup gets a second block: grid = min(blocks, CUs x resident workgroups)
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(a.nsb, (int64_t)bpc * h->cu_count));
+#ifdef RNNWF_DIAGNOSTICS
+        if constexpr (std::is_same<Args, PrnnArgs>::value) {
+            if (getenv("RNNWF_STAMPS_BASE")) {    // in-kernel cycle stamps, median over the waves of each role -> stderr (tools/stamps_base.py)
+                Args b = a;
+                const size_t nwv = (size_t)grid * B::NB * (B::NW + 1);
+                RNNWF_HIP(h, hipMalloc((void**)&b.stamps, nwv * 64));
+                RNNWF_HIP(h, hipMemsetAsync(b.stamps, 0, nwv * 64, h->stream));
+                kern<<<grid, threads, lds, h->stream>>>(b);
+                RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+                std::vector<unsigned long long> st(nwv * 8);
+                RNNWF_HIP(h, hipMemcpy(st.data(), b.stamps, nwv * 64, hipMemcpyDeviceToHost));
+                RNNWF_HIP(h, hipFree(b.stamps));
+                const char* names[7] = {"products", "wait_barrier_B", "gates_writes", "wait_barrier_A", "site", "total_cycles", "realtime_100MHz"};
+                for (int role = 0; role < 3; ++role) {
+                    fprintf(stderr, "RNNWF_STAMPS_BASE grid=%u %s waves:", grid, role == 2 ? "sampler" : role ? "remainder" : "gate");
+                    for (int k = 0; k < 7; ++k) {
+                        std::vector<unsigned long long> v;
+                        for (size_t w = 0; w < nwv; ++w) {
+                            const int mm = (int)st[w * 8 + 7], r_ = mm < NFULL ? 0 : mm == NFULL ? 1 : 2;
+                            if (st[w * 8 + 5] && r_ == role) v.push_back(st[w * 8 + k]);
+                        }
+                        if (v.empty()) continue;
+                        std::sort(v.begin(), v.end());
+                        fprintf(stderr, " %s med %llu max %llu;", names[k], v[v.size() / 2], v.back());
+                    }
+                    fprintf(stderr, "\n");
+                }
+                return 0;
+            }
+        }
+#endif
+        TimedLaunch tl(h, 0);
+        kern<<<grid, threads, lds, h->stream>>>(a);
+        RNNWF_HIP(h, hipGetLastError());
+        return 0;
+    }
+};
+}  // namespace
+
+bool rnnwf::base_bf_available(const rnnwf_handle* h) { return h->base_bf; }
+
+int rnnwf::base_bf_pack(rnnwf_handle* h) {
+    h->base_bf = false;
+    // measured (profiles/r03_g_base_pass.md): at 37..52 units the pass gains 14 - 16 % (configs 2, 3); at 20 units and 500 samples
+    // (config 1) the f32 cooperative kernel is 9 % faster - its image is three times smaller to stage - so narrower models keep it
+    if (h->f64 || h->NL != 1 || h->NFULL != 3 || h->knobs.base_f32 || h->knobs.no_coop || h->knobs.engine == 1) return 0;
+    std::vector<char> img;
+    switch (h->NFULL) {
+        case 1: img = pack_base_bf_image<1>(h); break;
+        case 2: img = pack_base_bf_image<2>(h); break;
+        case 3: img = pack_base_bf_image<3>(h); break;
+        default: return 0;
+    }
+    if (int rc = ensure(h, h->wbasebf, img.size())) return rc;
+    RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+    RNNWF_HIP(h, hipMemcpy(h->wbasebf.p, img.data(), img.size(), hipMemcpyHostToDevice));
+    h->base_bf = true;
+    return 0;
+}
+
+int rnnwf::prnn_base_coop_bf(rnnwf_handle* h, const PrnnArgs& a0) {
+    PrnnArgs a = a0;
+    a.wbf = h->wbasebf.p;
+    switch (h->NFULL) {
+        case 1: return BfBase<1>::launch(h, a, prnn_base_coop_kernel<1, true>, BfBase<1>::lds_bytes<1>());
+        case 2: return BfBase<2>::launch(h, a, prnn_base_coop_kernel<2, true>, BfBase<2>::lds_bytes<1>());
+        case 3: return BfBase<3>::launch(h, a, prnn_base_coop_kernel<3, true>, BfBase<3>::lds_bytes<1>());
+    }
+    return h->fail(RNNWF_ERR_INVALID, "no bf16 cooperative base kernel for NFULL=%d", h->NFULL);
+}
+
+int rnnwf::crnn_base_coop_bf(rnnwf_handle* h, const CrnnArgs& a0) {
+    CrnnArgs a = a0;
+    a.wbf = h->wbasebf.p;
+    switch (h->NFULL) {
+        case 1: return BfBase<1>::launch(h, a, crnn_base_coop_kernel<1, true>, BfBase<1>::lds_bytes<3>());
+        case 2: return BfBase<2>::launch(h, a, crnn_base_coop_kernel<2, true>, BfBase<2>::lds_bytes<3>());
+        case 3: return BfBase<3>::launch(h, a, crnn_base_coop_kernel<3, true>, BfBase<3>::lds_bytes<3>());
+    }
+    return h->fail(RNNWF_ERR_INVALID, "no bf16 cooperative base kernel for NFULL=%d", h->NFULL);
+}
 
 int rnnwf::prnn_split_flip(rnnwf_handle* h, const PrnnArgs& a) {
     const int kt16 = 4 * h->NFULL + 1;

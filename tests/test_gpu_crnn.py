@@ -226,8 +226,10 @@ def test_config3_properties():
 
 @pytest.mark.parametrize("N,H,ns", [(10, 11, 50), (40, 50, 333), (34, 20, 70), (16, 64, 33)])
 def test_cooperative_base_pass_is_bit_identical(N, H, ns, monkeypatch):
-    """crnn_base_coop_kernel (small batches) vs crnn_base_kernel: samples, log-amplitudes and J1-J2 local energies."""
+    """The two f32-input-MFMA base kernels, crnn_base_coop_kernel vs crnn_base_kernel: samples, log-amplitudes and J1-J2 local
+    energies bit for bit (RNNWF_BASE=f32: up to 52 units the default is the bf16 cooperative kernel, next test)."""
     prm = trained_like(H, seed=N)
+    monkeypatch.setenv("RNNWF_BASE", "f32")
     wf = make_wf(N, H, prm)
     J1, J2, Bz = np.ones(N), 0.5 * np.ones(N), np.zeros(N)
     s1 = wf.sample(ns, seed=4, step=1)
@@ -236,12 +238,44 @@ def test_cooperative_base_pass_is_bit_identical(N, H, ns, monkeypatch):
     monkeypatch.setenv("RNNWF_NO_COOP", "1")                 # read once, at rnnwf_create
     wf = make_wf(N, H, prm)
     monkeypatch.delenv("RNNWF_NO_COOP")
+    monkeypatch.delenv("RNNWF_BASE")
     s2 = wf.sample(ns, seed=4, step=1)
     a2 = wf.log_amp(s1)
     e2, n2 = wf.j1j2_eloc(s1, J1, J2, Bz)
     assert np.array_equal(s1, s2) and np.array_equal(a1, a2)
     assert n1 == n2 and np.array_equal(e1, e2)
     assert np.all(s1.sum(axis=1) == N // 2)
+
+
+@pytest.mark.parametrize("N,H,ns", [(10, 11, 50), (40, 50, 333), (34, 20, 700), (16, 36, 33), (22, 52, 5000), (40, 50, 30000)])
+def test_bf16_cooperative_base_pass_against_the_f32_kernels_and_the_oracle(N, H, ns, monkeypatch):
+    """The complex RNN's base pass on the bf16 matrix core (gru_kernels.h: coop_base_pass_bf, the default up to 52 units, every
+    batch size): U(1) on every sample, log-amplitudes against the float64 oracle at the f32 tolerance and against the
+    f32-input-MFMA kernels, the same draws except near-ties, shard invariance, the same J1-J2 local energies."""
+    prm = trained_like(H, seed=N + 3)
+    prm64 = {k: v.astype(np.float64) for k, v in prm.items()}
+    wf = make_wf(N, H, prm)
+    s1 = wf.sample(ns, seed=4, step=1)
+    assert np.all(s1.sum(axis=1) == N // 2)
+    cut = (ns // 3) | 1
+    assert np.array_equal(np.concatenate([wf.sample(cut, seed=4, step=1), wf.sample(ns - cut, seed=4, step=1, sample_offset=cut)]), s1)
+    sub = np.arange(0, ns, max(1, ns // 300))[:300]
+    a1 = wf.log_amp(s1[sub])
+    ref = M.crnn_log_amplitude(prm64, s1[sub], dtype=np.float64)
+    assert np.abs(a1 - ref).max() <= 2e-6 * N + 2e-6
+    monkeypatch.setenv("RNNWF_BASE", "f32")
+    wf32 = make_wf(N, H, prm)
+    monkeypatch.delenv("RNNWF_BASE")
+    s2 = wf32.sample(ns, seed=4, step=1)
+    bad = (s1 != s2).any(axis=1).sum()
+    print("cRNN N=%d H=%d ns=%d: %d rows drawn differently by the bf16 and the f32 base pass" % (N, H, ns, bad))
+    assert bad <= max(2, ns // 2000)
+    a2 = wf32.log_amp(s1[sub])
+    assert np.abs(a1 - a2).max() <= 2e-6 * N + 2e-6
+    J1, J2, Bz = np.ones(N), 0.5 * np.ones(N), np.zeros(N)
+    e1, n1 = wf.j1j2_eloc(s1[sub], J1, J2, Bz)
+    e2, n2 = wf32.j1j2_eloc(s1[sub], J1, J2, Bz)
+    assert n1 == n2 and np.allclose(e1, e2, rtol=5e-5, atol=5e-5)
 
 
 # ---- stacked layers: the reference's DEFAULT constructor is units=[10, 10] (J1J2/ComplexRNNwavefunction.py:16,40) ----

@@ -406,11 +406,16 @@ def test_both_flip_engines_agree_with_the_f64_oracle(N, H, ns, monkeypatch):
         assert err_lp <= 2e-6 * N + 2e-6
         assert err_e <= 2e-5
     assert np.allclose(got["f32"][0], got["bf16x3"][0], rtol=2e-5)
-    # without RNNWF_ENGINE a batch this small (fewer 32-chain tiles than two waves per SIMD) takes the 16-chain f32 kernel
+    # without RNNWF_ENGINE a batch this small (fewer 32-chain tiles than two waves per SIMD) takes the 16-chain f32 flip kernel
+    # (its base pass is then the default one - bf16 cooperative up to 52 units - where RNNWF_ENGINE=f32 pins the f32 base pass too)
     monkeypatch.delenv("RNNWF_ENGINE")
     wf = make_wf(_lib.MODEL_GRU1D, N, H, prm)
     e = wf.tfim_eloc(s, Jz, 1.1)
-    assert wf.engine_name() == "f32mfma" and np.array_equal(e, got["f32"][0])
+    assert wf.engine_name() == "f32mfma" and np.allclose(e, got["f32"][0], rtol=2e-5)
+    monkeypatch.setenv("RNNWF_BASE", "f32")
+    wf = make_wf(_lib.MODEL_GRU1D, N, H, prm)
+    monkeypatch.delenv("RNNWF_BASE")
+    assert np.array_equal(wf.tfim_eloc(s, Jz, 1.1), got["f32"][0])
 
 
 # ---- stacked layers (units = [h] * num_layers, 1DTFIM/TrainingRNN_1DTFIM.py:98; MultiRNNCell, RNNwavefunction.py:32) ----
@@ -610,22 +615,66 @@ def test_log_prob_beyond_one_device_chunk():
 
 @pytest.mark.parametrize("N,H,ns", [(20, 10, 100), (33, 36, 333), (80, 50, 1000), (12, 64, 50), (7, 20, 16)])
 def test_cooperative_base_pass_is_bit_identical(N, H, ns, monkeypatch):
-    """Small batches run the base pass with NFULL+1 waves per 16-chain block (prnn_base_coop_kernel); a batch and its
-    shards may therefore take different kernels, so the two must agree in every bit, draws included."""
+    """The two f32-input-MFMA base kernels - one wave per 16-chain block (prnn_base_kernel) and NFULL+1 waves per block
+    (prnn_base_coop_kernel) - agree in every bit, draws included.  Up to 52 units the default base pass is a third kernel
+    (the cooperative pass on the bf16 matrix core, next test); RNNWF_BASE=f32 selects the f32 pair here."""
     from rnnwavefunctions_amd import _lib
     prm = trained_like(H, seed=N)
+    monkeypatch.setenv("RNNWF_BASE", "f32")                  # read once, at rnnwf_create
     wf = make_wf(_lib.MODEL_GRU1D, N, H, prm)
     s1, lg1 = wf.sample(ns, seed=9, step=1, return_log=True)
     lp1 = wf.log_prob(s1)
     e1 = wf.tfim_eloc(s1, np.ones(N), 1.0)
-    monkeypatch.setenv("RNNWF_NO_COOP", "1")                 # read once, at rnnwf_create
+    monkeypatch.setenv("RNNWF_NO_COOP", "1")
     wf = make_wf(_lib.MODEL_GRU1D, N, H, prm)
     monkeypatch.delenv("RNNWF_NO_COOP")
+    monkeypatch.delenv("RNNWF_BASE")
     s2, lg2 = wf.sample(ns, seed=9, step=1, return_log=True)
     lp2 = wf.log_prob(s1)
     e2 = wf.tfim_eloc(s1, np.ones(N), 1.0)
     assert np.array_equal(s1, s2) and np.array_equal(lg1, lg2)
     assert np.array_equal(lp1, lp2) and np.array_equal(e1, e2)
+
+
+@pytest.mark.parametrize("N,H,ns", [(20, 10, 100), (33, 20, 777), (33, 36, 333), (80, 50, 1000), (40, 44, 5000), (21, 52, 130), (7, 21, 16),
+                                     (64, 50, 40000)])
+def test_bf16_cooperative_base_pass_against_the_f32_kernels_and_the_oracle(N, H, ns, monkeypatch):
+    """Up to 52 units the base pass (sample / log_probability / the checkpoints the flip pass starts from) runs NFULL+1 waves per
+    16-chain block on the bf16 matrix core with bf16x3 operands (gru_kernels.h: coop_base_pass_bf), three blocks per workgroup,
+    for EVERY batch size.  Against the f32-input-MFMA kernels (RNNWF_BASE=f32): log-probabilities within the f32 tolerance, the
+    same draws except near-ties; against the float64 oracle: the same tolerance as every f32 path; shards reproduce the batch
+    bit for bit (ragged last workgroup, several rounds at 40 000 samples)."""
+    from rnnwavefunctions_amd import _lib
+    prm = trained_like(H, seed=N + 1)
+    prm64 = {k: v.astype(np.float64) for k, v in prm.items()}
+    wf = make_wf(_lib.MODEL_GRU1D, N, H, prm)
+    s1, lg1 = wf.sample(ns, seed=9, step=1, return_log=True)
+    sub = np.arange(0, ns, max(1, ns // 400))[:400]
+    ref64 = M.prnn_log_probability(prm64, s1[sub], dtype=np.float64)
+    assert np.abs(lg1[sub] - ref64).max() <= 2e-6 * N + 2e-6
+    lp1 = wf.log_prob(s1)
+    assert np.array_equal(lp1, lg1)                          # teacher-forced on its own draws: the same kernel, the same numbers
+    cut = (ns // 3) | 1
+    a = wf.sample(cut, seed=9, step=1)
+    b = wf.sample(ns - cut, seed=9, step=1, sample_offset=cut)
+    assert np.array_equal(np.concatenate([a, b]), s1)        # shard invariance
+    e1 = wf.tfim_eloc(s1[sub], np.ones(N), 1.0)
+    monkeypatch.setenv("RNNWF_BASE", "f32")
+    wf32 = make_wf(_lib.MODEL_GRU1D, N, H, prm)
+    monkeypatch.delenv("RNNWF_BASE")
+    s2, lg2 = wf32.sample(ns, seed=9, step=1, return_log=True)
+    bad = np.where((s1 != s2).any(axis=1))[0]
+    print("N=%d H=%d ns=%d: %d rows drawn differently by the bf16 and the f32 base pass" % (N, H, ns, len(bad)))
+    assert len(bad) <= max(2, ns // 2000)
+    u = philox.uniforms(9, 1, 0, ns, N)
+    for r in bad[:8]:                                        # a differing row must be a near-tie
+        n0 = np.argmax(s1[r] != s2[r])
+        p0 = M.prnn_site_probs(prm, s2[r:r + 1])[0, n0, 0]
+        assert abs(u[r, n0] - p0) < 1e-5
+    good = np.setdiff1d(np.arange(ns), bad)
+    assert np.abs(lg1[good] - lg2[good]).max() <= 2e-6 * N + 2e-6
+    e2 = wf32.tfim_eloc(s1[sub], np.ones(N), 1.0)
+    assert np.allclose(e1, e2, rtol=2e-5)
 
 
 def test_config5_shard_at_full_size():

@@ -469,12 +469,13 @@ def test_comm_env_without_a_launcher_runs_as_a_single_process(monkeypatch):
     kw = dict(numsteps=2, systemsize=8, num_units=6, numsamples=40, seed=5, verbose=False)
     a, _ = run_1DTFIM(comm="env", **kw)
     b, _ = run_1DTFIM(**kw)
-    assert a == b
+    # (the weight-gradient GEMM combines its partial sums with float atomics: two runs agree to rounding, not bit for bit)
+    assert a[0] == b[0] and np.allclose(a, b, rtol=1e-7, atol=0)
     monkeypatch.setenv("WORLD_SIZE", "1")
     monkeypatch.setenv("RANK", "0")
     monkeypatch.setenv("LOCAL_RANK", "0")
     c, _ = run_1DTFIM(comm="env", **kw)
-    assert c == b
+    assert c[0] == b[0] and np.allclose(c, b, rtol=1e-7, atol=0)
 
 
 def test_reference_training_loop_of_j1j2_runs_with_compat_as_tf():
