@@ -188,7 +188,9 @@ int j1j2_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
     a.seed = seed; a.step = step; a.sample_offset = offset;
     if (int rc = launch_base(h, a)) return rc;
 
-    RNNWF_HIP(h, hipMemsetAsync(cnt, 0, (size_t)N * 4, h->stream));
+    // the item counters are zeroed by the previous step's assembly kernel (j1j2_eloc_kernel); a memset only when that did not happen
+    if (!h->j1j2_cnt_clean) RNNWF_HIP(h, hipMemsetAsync(cnt, 0, (size_t)N * 4, h->stream));
+    h->j1j2_cnt_clean = false;
     RNNWF_HIP(h, hipMemsetAsync(h->lpq.p, 0, (size_t)ns * 2 * N * sizeof(double2), h->stream));   // contrib: inactive bonds contribute 0
     J1J2Args e{};
     e.bits = (const uint32_t*)h->bits.p;
@@ -202,10 +204,11 @@ int j1j2_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
         dim3 grid((unsigned)((ns + 255) / 256), (unsigned)(2 * N));
         j1j2_enumerate_kernel<<<grid, 256, 0, h->stream>>>(e);
         RNNWF_HIP(h, hipGetLastError());
-        j1j2_tile_scan_kernel<<<1, 64, 0, h->stream>>>(cnt, N, tile_start, total_items, h->engine_split ? 32 : kChains);
+        // the three totals land in pinned[64..88) - written by the kernel itself - and are read at the caller's next stream sync
+        // (collect_totals)
+        j1j2_tile_scan_kernel<<<1, 64, 0, h->stream>>>(cnt, N, tile_start, total_items, (int64_t*)((char*)h->pinned_dev + 64),
+                                                       h->engine_split ? 32 : kChains);
         RNNWF_HIP(h, hipGetLastError());
-        // lands in pinned[64..88) at the caller's next stream sync (see collect_totals)
-        RNNWF_HIP(h, hipMemcpyAsync((char*)h->pinned + 64, total_items, 24, hipMemcpyDeviceToHost, h->stream));
     }
     a.sampling = 0;
     a.tile_start = tile_start;
@@ -222,8 +225,9 @@ int j1j2_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
     {
         TimedLaunch tl(h, 2);
         j1j2_eloc_kernel<<<(unsigned)((ns + 255) / 256), 256, 0, h->stream>>>((const double2*)h->lpq.p, diag, ns, N,
-                                                                            (float2*)h->eloc.p);
+                                                                            (float2*)h->eloc.p, N <= 256 ? cnt : nullptr);
         RNNWF_HIP(h, hipGetLastError());
+        h->j1j2_cnt_clean = N <= 256;
     }
     return 0;
 }

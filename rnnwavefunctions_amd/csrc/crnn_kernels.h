@@ -42,7 +42,7 @@ struct CrnnArgs {
     const int32_t* cnt;        // [N] items per lo
     const SwapItem* items;     // [N][cap]
     int64_t cap;
-    double2* contrib;          // [ns][2N]
+    double2* contrib;          // [2N][ns]  (bond slot major: the assembly kernel reads it coalesced)
 };
 
 // One site of the complex RNN (ComplexRNNwavefunction.py:83-93,143-157) from the head outputs
@@ -265,7 +265,34 @@ static __global__ void __launch_bounds__(256) j1j2_enumerate_kernel(J1J2Args a) 
             a.items[(int64_t)lo * a.cap + k] = it;
         }
     }
-    if (slot == 0 && in_range) {     // diagonal element, once per sample (TrainingRNN_J1J2.py:32,46-57)
+    __shared__ double cpl[3][256];   // slot-0 blocks: J1, J2, Bz
+    if (slot == 0 && N <= 256) {
+        for (int i = threadIdx.x; i < N; i += blockDim.x) { cpl[0][i] = a.J1[i]; cpl[1][i] = a.J2[i]; cpl[2][i] = a.Bz[i]; }
+        __syncthreads();
+    }
+    if (slot == 0 && in_range && N <= 256) {     // diagonal element, once per sample (TrainingRNN_J1J2.py:32,46-57)
+        // These 40 blocks were the kernel's long pole: 3 N iterations, each waiting for a scalar load of its coupling and two
+        // global loads of spins.  Now: the sample's packed words in registers (N <= 256) and the couplings in LDS (staged by the
+        // whole block below); the same three sums in the same order.
+        constexpr int MAXW = 8;
+        uint32_t wd[MAXW];
+        const int W = (N + 31) / 32;
+#pragma unroll
+        for (int w = 0; w < MAXW; ++w) wd[w] = w < W ? a.bits[(int64_t)w * a.ns + s] : 0u;
+        auto sp = [&](int i) -> int {
+            uint32_t v = 0;
+#pragma unroll
+            for (int w = 0; w < MAXW; ++w) if (w == (i >> 5)) v = wd[w];
+            return (int)((v >> (i & 31)) & 1);
+        };
+        double d = 0.0;
+        for (int i = 0; i < N; ++i) d += ((double)sp(i) - 0.5) * cpl[2][i];
+        const int lim1 = a.periodic ? N : N - 1, lim2 = a.periodic ? N : N - 2;
+        for (int i = 0; i < lim1; ++i) d += (sp(i) != sp((i + 1) % N) ? -0.25 : 0.25) * cpl[0][i];
+        for (int i = 0; i < lim2; ++i)
+            if (cpl[1][i] != 0.0) d += (sp(i) != sp((i + 2) % N) ? -0.25 : 0.25) * cpl[1][i];
+        a.diag[s] = d;
+    } else if (slot == 0 && in_range) {      // chains longer than 256 sites: straight from global memory
         double d = 0.0;
         for (int i = 0; i < N; ++i) d += ((double)spin_of(a.bits, a.ns, s, i) - 0.5) * a.Bz[i];
         const int lim1 = a.periodic ? N : N - 1, lim2 = a.periodic ? N : N - 2;
@@ -281,20 +308,43 @@ static __global__ void __launch_bounds__(256) j1j2_enumerate_kernel(J1J2Args a) 
 // tile_start[lo] = sum_{l < lo} ceil(cnt[l] / 16); tile_start[N] = total;
 // totals[0] = sum cnt (off-diagonal configurations), totals[1] = sum cnt[lo] (N-1-lo) (cell evaluations),
 // totals[2] = sum tiles[lo] (N-1-lo) (wave-steps actually issued)
-static __global__ void j1j2_tile_scan_kernel(const int32_t* cnt, int N, int32_t* tile_start, int64_t* totals, int tile_items) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int32_t acc = 0;
+// One wave: lane l takes the sites l, l + 64, ... (one load each instead of N dependent ones), wave-level prefix sums.
+// totals_host: the same three numbers straight into pinned host memory (read after the caller's stream sync; no copy launch).
+static __global__ void __launch_bounds__(64) j1j2_tile_scan_kernel(const int32_t* cnt, int N, int32_t* tile_start, int64_t* totals,
+                                                                   int64_t* totals_host, int tile_items) {
+    const int lane = threadIdx.x;
+    int32_t carry = 0;
     int64_t items = 0, evals = 0, wsteps = 0;
-    for (int lo = 0; lo < N; ++lo) {
-        tile_start[lo] = acc;
-        const int t = (cnt[lo] + tile_items - 1) / tile_items;
-        acc += t;
-        items += cnt[lo];
-        evals += (int64_t)cnt[lo] * (N - 1 - lo);
-        wsteps += (int64_t)t * (N - 1 - lo);
+    for (int base = 0; base < N; base += 64) {
+        const int lo = base + lane;
+        const int c = lo < N ? cnt[lo] : 0;
+        const int t = (c + tile_items - 1) / tile_items;
+        int incl = t;                                        // inclusive prefix sum of the tile counts over the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        if (lo < N) tile_start[lo] = carry + incl - t;
+        carry += __shfl(incl, 63);
+        if (lo < N) {
+            items += c;
+            evals += (int64_t)c * (N - 1 - lo);
+            wsteps += (int64_t)t * (N - 1 - lo);
+        }
     }
-    tile_start[N] = acc;
-    totals[0] = items; totals[1] = evals; totals[2] = wsteps;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        items += __shfl_xor(items, d);
+        evals += __shfl_xor(evals, d);
+        wsteps += __shfl_xor(wsteps, d);
+    }
+    if (lane == 0) {
+        tile_start[N] = carry;
+        totals[0] = items; totals[1] = evals; totals[2] = wsteps;
+        if (totals_host) { totals_host[0] = items; totals_host[1] = evals; totals_host[2] = wsteps; }
+    }
+
 }
 
 template <int NFULL, int WAVES>
@@ -354,19 +404,30 @@ __global__ void __launch_bounds__(WAVES * 64) crnn_swap_kernel(CrnnArgs a) {
             const double2 t = a.tot[s];
             const double dre = b.x + re - t.x, dim = b.y + im - t.y;
             const double mag = exp(dre) * (double)it.coef;
-            a.contrib[s * (2 * N) + it.slot] = make_double2(mag * cos(dim), mag * sin(dim));
+            a.contrib[(int64_t)it.slot * a.ns + s] = make_double2(mag * cos(dim), mag * sin(dim));
         }
     }
 }
 
 // E_loc[s] = diag + sum over bond slots (J1 bonds by site, then J2 bonds by site: the reference's row order)
+// contrib is [2N][ns]: consecutive samples read consecutive 16-byte values; the sum runs in the reference's bond order.
+// cnt_to_clear: the per-site item counters of this step, zeroed here for the next one (saves a memset launch per step).
 static __global__ void j1j2_eloc_kernel(const double2* __restrict__ contrib, const double* __restrict__ diag, int64_t ns,
-                                 int N, float2* __restrict__ eloc) {
+                                 int N, float2* __restrict__ eloc, int32_t* cnt_to_clear) {
+    if (cnt_to_clear && blockIdx.x == 0 && (int)threadIdx.x < N) cnt_to_clear[threadIdx.x] = 0;
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= ns) return;
     double re = diag[s], im = 0.0;
-    for (int k = 0; k < 2 * N; ++k) {
-        const double2 v = contrib[s * (2 * N) + k];
+    int k = 0;
+    for (; k + 8 <= 2 * N; k += 8) {                     // eight loads in flight, added in bond order
+        double2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = contrib[(int64_t)(k + u) * ns + s];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { re += v[u].x; im += v[u].y; }
+    }
+    for (; k < 2 * N; ++k) {
+        const double2 v = contrib[(int64_t)k * ns + s];
         re += v.x;
         im += v.y;
     }

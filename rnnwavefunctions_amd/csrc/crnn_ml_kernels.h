@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(WAVES * 64) crnn_ml_swap_kernel(CrnnArgs a) {
             const double2 t = a.tot[s];
             const double dre = b.x + re - t.x, dim = b.y + im - t.y;
             const double mag = exp(dre) * (double)it.coef;
-            a.contrib[s * (2 * N) + it.slot] = make_double2(mag * cos(dim), mag * sin(dim));
+            a.contrib[(int64_t)it.slot * a.ns + s] = make_double2(mag * cos(dim), mag * sin(dim));
         }
     }
 }

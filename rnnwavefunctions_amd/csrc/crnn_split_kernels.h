@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(WAVES * 64, (3 * NF32 + (3 * RJ + 15) / 16) <=
             const double2 t = a.tot[s];
             const double dre = b.x + re - t.x, dim = b.y + im - t.y;
             const double mag = exp(dre) * (double)it.coef;
-            a.contrib[s * (2 * N) + it.slot] = make_double2(mag * cos(dim), mag * sin(dim));
+            a.contrib[(int64_t)it.slot * a.ns + s] = make_double2(mag * cos(dim), mag * sin(dim));
         }
     }
 }
@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(512) crnn_swap_pp_kernel(CrnnArgs a, const voi
                     const double2 t = a.tot[s];
                     const double dre = b.x + re - t.x, dim = b.y + im - t.y;
                     const double mag = exp(dre) * (double)it.coef;
-                    a.contrib[(int64_t)s * (2 * N) + it.slot] = make_double2(mag * cos(dim), mag * sin(dim));
+                    a.contrib[(int64_t)it.slot * a.ns + s] = make_double2(mag * cos(dim), mag * sin(dim));
                 }
                 next_tile();
                 if (active) begin_tile();

@@ -81,6 +81,8 @@ struct rnnwf_handle {
     int64_t last_ns = 0;          // batch of the last rnnwf_vmc_step still resident (bits, hck, eloc)
     bool last_has_ckpt = false;
     void* pinned = nullptr;  // small pinned staging (moments)
+    void* pinned_dev = nullptr;   // the same memory as the device addresses it: kernels write the step's 32 + 24 result bytes there directly
+    bool j1j2_cnt_clean = false;  // the J1-J2 item counters are zero (left so by the last assembly kernel)
     void* staging = nullptr; // pinned staging of the host-side all-reduces (comm.hip), grown on demand
     size_t staging_cap = 0;
     rnnwf::DevBuf reduce_scratch;

@@ -83,7 +83,7 @@ tfim_eloc_kernel(const uint32_t* __restrict__ bits, const double* __restrict__ l
 // re/im may be f64 (TFIM, im == nullptr) or interleaved f32 pairs (J1J2).
 template <typename TE>
 __global__ void __launch_bounds__(1024) moments_kernel(const TE* __restrict__ e, int64_t ns, int stride,
-                                                       int has_im, double* __restrict__ moments) {
+                                                       int has_im, double* __restrict__ moments, double* host_copy) {
     __shared__ double sh[3][1024];
     double s1 = 0.0, s2 = 0.0, si = 0.0;
     for (int64_t s = threadIdx.x; s < ns; s += blockDim.x) {
@@ -104,6 +104,7 @@ __global__ void __launch_bounds__(1024) moments_kernel(const TE* __restrict__ e,
     }
     if (threadIdx.x == 0) {
         moments[0] = sh[0][0]; moments[1] = sh[1][0]; moments[2] = (double)ns; moments[3] = sh[2][0];
+        if (host_copy) { host_copy[0] = sh[0][0]; host_copy[1] = sh[1][0]; host_copy[2] = (double)ns; host_copy[3] = sh[2][0]; }
     }
 }
 
