@@ -461,8 +461,10 @@ def main():
         # the dominant kernel as rocprofv3 names it: 37..50 units run the ping-pong form of the bf16x3 engine
         # (RNNWF_ENGINE=bf16x3-serial pins the older 4-wave form for A/B runs)
         pp = engine == "bf16x3" and 37 <= wl["H"] <= 50 and os.environ.get("RNNWF_ENGINE") != "bf16x3-serial"
+        riders_asm = engine == "bf16x3" and wl["H"] > 68 and os.environ.get("RNNWF_ENGINE") != "bf16x3-hipcc"
         kernel = {"tfim1d": "prnn_ml_flip_kernel" if wl.get("layers", 1) > 1 else
-                            ("prnn_flip_pp_kernel" if pp else "prnn_flip_split_kernel") if engine == "bf16x3" else "prnn_flip_kernel",
+                            ("prnn_flip_pp_kernel" if pp else "prnn_flip_riders_asm_kernel" if riders_asm else "prnn_flip_split_kernel")
+                            if engine == "bf16x3" else "prnn_flip_kernel",
                   "j1j2": ("crnn_swap_pp_kernel" if pp else "crnn_swap_split_kernel") if engine == "bf16x3" else "crnn_swap_kernel",
                   "tfim2d": "mdrnn_flip_kernel", "tfim2d_gru": "prnn_flip_kernel<double>"}[wl["kind"]]
         traffic = load_traffic(args.workload)

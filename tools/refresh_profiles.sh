@@ -13,24 +13,32 @@ for w in cfg1 cfg2 cfg3 cfg4 cfg5; do
   timeout -k 10 300 python bench.py --workload $w --steps $steps --warmup 3 $extra > $out/${tag}_bench_$w.json 2> $out/${tag}_bench_$w.err || { echo "bench $w failed"; exit 1; }
   echo "bench $w done"
 done
+# SURVEY 8 rows f4 / f1 "at speed": the parity-symmetric model, stacked layers, and the gradient leg (--train) of every config
+for w in cfg2_parity cfg2_l2 cfg2_l3; do
+  timeout -k 10 300 python bench.py --workload $w --steps 10 --warmup 2 --train 5 > $out/${tag}_bench_$w.json 2> $out/${tag}_bench_$w.err || { echo "bench $w failed"; exit 1; }
+done
+for w in cfg2 cfg3 cfg4 cfg5; do
+  timeout -k 10 300 python bench.py --workload $w --steps 5 --warmup 2 --train 10 --no-cpu-baseline --no-alt-engine --no-parity > $out/${tag}_train_$w.json 2> $out/${tag}_train_$w.err || { echo "train $w failed"; exit 1; }
+done
 for w in cfg2 cfg3; do
   RNNWF_ENGINE=f32 timeout -k 10 200 python bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline --no-alt-engine > $out/${tag}_bench_${w}_engine_f32.json 2>/dev/null || exit 1
 done
 cd /tmp && export TMPDIR=/tmp
-for w in cfg1 cfg2 cfg3 cfg4 cfg5; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof_$w -- python3 $R/bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline --no-alt-engine > $out/${tag}_prof_$w.log 2>&1 || { echo "rocprof $w failed"; exit 1; }
+for w in cfg1 cfg2 cfg3 cfg4 cfg5 cfg2_parity cfg2_l2 cfg2_l3; do
+  steps=10; [ $w = cfg5 ] && steps=4
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof_$w -- python3 $R/bench.py --workload $w --steps $steps --warmup 2 --train 3 --no-cpu-baseline --no-alt-engine --no-parity > $out/${tag}_prof_$w.log 2>&1 || { echo "rocprof $w failed"; exit 1; }
   cp $out/${tag}_prof_$w/*/*kernel_stats.csv $out/${tag}_kernel_stats_$w.csv
   echo "stats $w done"
 done
 for w in cfg2 cfg4 cfg5; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/${tag}_pmc_${w}_$c -- python3 $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-alt-engine > $out/${tag}_pmc_${w}_$c.log 2>&1 || { echo "pmc $w $c failed"; exit 1; }
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/${tag}_pmc_${w}_$c -- python3 $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-alt-engine --no-parity > $out/${tag}_pmc_${w}_$c.log 2>&1 || { echo "pmc $w $c failed"; exit 1; }
   done
 done
 # SQ counters of the dominant kernels at config 2 (one pass per counter set; no trace domains besides --kernel-trace)
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" "SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES"; do
   t=$(echo $set | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/${tag}_sq_cfg2/$t -- python3 $R/bench.py --workload cfg2 --steps 2 --warmup 1 --no-cpu-baseline --no-alt-engine > $out/${tag}_sq_cfg2_$t.log 2>&1 || echo "sq set failed: $set"
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/${tag}_sq_cfg2/$t -- python3 $R/bench.py --workload cfg2 --steps 2 --warmup 1 --no-cpu-baseline --no-alt-engine --no-parity > $out/${tag}_sq_cfg2_$t.log 2>&1 || echo "sq set failed: $set"
 done
 python3 - <<PY
 import csv, glob, collections
