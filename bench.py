@@ -462,8 +462,9 @@ def main():
         # (RNNWF_ENGINE=bf16x3-serial pins the older 4-wave form for A/B runs)
         pp = engine == "bf16x3" and 37 <= wl["H"] <= 50 and os.environ.get("RNNWF_ENGINE") != "bf16x3-serial"
         riders_asm = engine == "bf16x3" and wl["H"] > 68 and os.environ.get("RNNWF_ENGINE") != "bf16x3-hipcc"
+        riders_name = "prnn_flip_riders_asm_kernel" if os.environ.get("RNNWF_ENGINE") == "bf16x3-asm32" else "prnn_flip_riders16_asm_kernel"
         kernel = {"tfim1d": "prnn_ml_flip_kernel" if wl.get("layers", 1) > 1 else
-                            ("prnn_flip_pp_kernel" if pp else "prnn_flip_riders_asm_kernel" if riders_asm else "prnn_flip_split_kernel")
+                            ("prnn_flip_pp_kernel" if pp else riders_name if riders_asm else "prnn_flip_split_kernel")
                             if engine == "bf16x3" else "prnn_flip_kernel",
                   "j1j2": ("crnn_swap_pp_kernel" if pp else "crnn_swap_split_kernel") if engine == "bf16x3" else "crnn_swap_kernel",
                   "tfim2d": "mdrnn_flip_kernel", "tfim2d_gru": "prnn_flip_kernel<double>"}[wl["kind"]]

@@ -27,7 +27,7 @@ struct KernelTimer {
 
 // Environment switches, read ONCE in rnnwf_create (never on the per-step path).
 struct Knobs {
-    int engine = 0;               // RNNWF_ENGINE: 0 default, 1 "f32" (f32-input MFMA everywhere), 2 "bf16x3" (pinned), 3 "bf16x3-serial" (pinned, 4-wave kernel without the ping-pong: A/B), 4 "bf16x3-hipcc" (pinned; 69..100 units: the compiler-scheduled riders step instead of the generated asm block: A/B)
+    int engine = 0;               // RNNWF_ENGINE: 0 default, 1 "f32" (f32-input MFMA everywhere), 2 "bf16x3" (pinned), 3 "bf16x3-serial" (pinned, 4-wave kernel without the ping-pong: A/B), 4 "bf16x3-hipcc" (pinned; 69..100 units: the compiler-scheduled riders step instead of the generated asm block: A/B), 5 "bf16x3-asm32" (pinned; 69..100 units: the 32x32x16 asm step instead of the 16x16x32 one: A/B)
     bool no_coop = false;         // RNNWF_NO_COOP=1: base pass always on the one-wave-per-block kernel
     bool base_f32 = false;        // RNNWF_BASE=f32: the base pass keeps the f32-input MFMA (no bf16 cooperative kernel): A/B, and the
                                   // bit-identity test of the two f32 kernels
@@ -71,6 +71,7 @@ struct rnnwf_handle {
     rnnwf::DevBuf gradDX[2];      // stacked layers: dL/dx of one layer's pass = dL/dh input of the pass below
     // bf16x3 engine (split_core.h): second weight image; engine_split = use it for the flip pass
     rnnwf::DevBuf wsplit;
+    rnnwf::DevBuf wsplit16;       // image of the 16x16x32 form of the flip pass at 69..100 units (split16_core.h)
     rnnwf::DevBuf wbasebf;        // bf16x3 A fragments of the cooperative base pass (layout.h: BaseBfLayout); valid iff base_bf
     bool base_bf = false;
     bool engine_split = false;

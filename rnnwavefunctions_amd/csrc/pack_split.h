@@ -5,6 +5,7 @@
 
 #include "pack.h"
 #include "split_core.h"
+#include "split16_core.h"
 
 namespace rnnwf {
 
@@ -27,6 +28,88 @@ inline void split3(double w, uint16_t (&p)[3]) {
         p[i] = bf16_rne(r);
         r -= bf16_to_float(p[i]);
     }
+}
+
+// Image of the 16x16x32 form of the flip pass at 69..100 units (split16_core.h: S16Layout).
+template <int NOUT>
+std::vector<char> pack_split16_image(const rnnwf_handle* h) {
+    using L = S16Layout<NOUT>;
+    static_assert(NOUT == 1, "the 16x16x32 form carries one head row (positive RNN)");
+    const int H = h->H;
+    std::vector<char> img(L::BYTES, 0);
+    const std::string pre = kGruPre;
+    const auto& Wg = pv(h, pre + "gates/kernel");
+    const auto& bg = pv(h, pre + "gates/bias");
+    const auto& Wci = pv(h, pre + "candidate/input_projection/kernel");
+    const auto& bci = pv(h, pre + "candidate/input_projection/bias");
+    const auto& Wch = pv(h, pre + "candidate/hidden_projection/kernel");
+    const auto& bch = pv(h, pre + "candidate/hidden_projection/bias");
+    const auto& Wd = pv(h, "wf_dense/kernel");
+    const auto& bd = pv(h, "wf_dense/bias");
+    const double sg = PackScale<float>::gate, sc = PackScale<float>::cand;
+    // row (tile t, row i = 4 g + r) -> (gate, unit): gate 0 r, 1 u, 2 candidate, 3 head; unit -1: unused row
+    auto decode = [&](int t, int g, int r, int& gate, int& unit) {
+        if (t < L::NTF) {
+            const int b = t / 6, tau = t % 2;
+            gate = (t % 6) / 2;
+            unit = 4 * (8 * b + 4 * tau + r) + g;
+        } else if (r < 3) {
+            gate = r;
+            unit = 4 * L::NJA + g;
+        } else {
+            gate = 3;
+            unit = 0;
+        }
+        if (gate < 3 && unit >= H) unit = -1;
+    };
+    auto weight = [&](int gate, int uo, int ui) -> double {
+        if (ui >= H) return 0.0;
+        return gate == 0 ? sg * Wg[(size_t)(2 + ui) * 2 * H + uo]
+             : gate == 1 ? sg * Wg[(size_t)(2 + ui) * 2 * H + H + uo]
+             : gate == 2 ? sc * Wch[(size_t)ui * H + uo]
+                         : Wd[(size_t)ui * 2 + 1] - Wd[(size_t)ui * 2];
+    };
+    uint16_t* A = reinterpret_cast<uint16_t*>(img.data() + L::OFF_A);
+    uint16_t* ASP = reinterpret_cast<uint16_t*>(img.data() + L::OFF_ASP);
+    float* CI = reinterpret_cast<float*>(img.data() + L::OFF_CI);
+    for (int t = 0; t < L::NT; ++t)
+        for (int i = 0; i < 16; ++i) {
+            const int go = i >> 2, r = i & 3;
+            int gate, uo;
+            decode(t, go, r, gate, uo);
+            if (uo < 0) continue;
+            for (int sgm = 0; sgm < 2; ++sgm) {                  // accumulator start value: bias + one-hot input row
+                const double v = gate == 0 ? sg * (bg[uo] + Wg[(size_t)sgm * 2 * H + uo])
+                               : gate == 1 ? sg * (bg[H + uo] + Wg[(size_t)sgm * 2 * H + H + uo])
+                               : gate == 2 ? sc * bch[uo] : bd[1] - bd[0];
+                CI[(((size_t)sgm * L::NT + t) * 4 + go) * 4 + r] = (float)v;
+            }
+            for (int g = 0; g < 4; ++g) {                        // K side: lane group g supplies its units 4 j + g
+                const int lane = (g << 4) | i;
+                for (int o = 0; o < L::NOCT; ++o)
+                    for (int e = 0; e < 8; ++e) {
+                        uint16_t p[3];
+                        split3(weight(gate, uo, 4 * (8 * o + e) + g), p);
+                        for (int a = 0; a < 3; ++a) A[((((size_t)t * 3 + a) * L::NOCT + o) * 64 + lane) * 8 + e] = p[a];
+                    }
+                uint16_t p[3];
+                split3(weight(gate, uo, 4 * L::NJA + g), p);
+                const int part[6] = {0, 0, 0, 1, 1, 2};          // against the B entries {h1, h2, h3, h1, h2, h1}
+                for (int e = 0; e < 6; ++e) ASP[((size_t)t * 64 + lane) * 8 + e] = p[part[e]];
+            }
+        }
+    float* XC = reinterpret_cast<float*>(img.data() + L::OFF_XC);
+    float* WD = reinterpret_cast<float*>(img.data() + L::OFF_WD);
+    float* BD = reinterpret_cast<float*>(img.data() + L::OFF_BD);
+    for (int g = 0; g < 4; ++g)
+        for (int j = 0; j < L::NJ; ++j) {
+            const int u = 4 * j + g;
+            if (u >= H) continue;
+            for (int sgm = 0; sgm < 2; ++sgm) XC[((size_t)sgm * 4 + g) * L::XCP + j] = (float)(sc * (bci[u] + Wci[(size_t)sgm * H + u]));
+            WD[(size_t)g * L::XCP + j] = (float)(Wd[(size_t)u * 2 + 1] - Wd[(size_t)u * 2]);
+        }
+    BD[0] = (float)(bd[1] - bd[0]);
+    return img;
 }
 
 // bf16x3 A fragments of the cooperative base pass (layout.h: BaseBfLayout): the rows of pack_gru_image (same scaled f32

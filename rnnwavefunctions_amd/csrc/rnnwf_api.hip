@@ -73,7 +73,7 @@ size_t rnnwf::state_budget_bytes(const rnnwf_handle* h, size_t dflt) {
 // The environment is consulted here and nowhere else: once per handle, at creation.
 static void read_knobs(Knobs& k) {
     if (const char* e = getenv("RNNWF_MDRNN_PREFETCH")) k.md_prefetch = !strcmp(e, "1");
-    if (const char* e = getenv("RNNWF_ENGINE")) k.engine = !strcmp(e, "f32") ? 1 : !strcmp(e, "bf16x3") ? 2 : !strcmp(e, "bf16x3-serial") ? 3 : !strcmp(e, "bf16x3-hipcc") ? 4 : 0;
+    if (const char* e = getenv("RNNWF_ENGINE")) k.engine = !strcmp(e, "f32") ? 1 : !strcmp(e, "bf16x3") ? 2 : !strcmp(e, "bf16x3-serial") ? 3 : !strcmp(e, "bf16x3-hipcc") ? 4 : !strcmp(e, "bf16x3-asm32") ? 5 : 0;
     if (const char* e = getenv("RNNWF_NO_COOP")) k.no_coop = atoi(e) != 0;
     if (const char* e = getenv("RNNWF_BASE")) k.base_f32 = !strcmp(e, "f32");
     if (const char* e = getenv("RNNWF_STATE_BUDGET_MB")) {
@@ -202,7 +202,7 @@ extern "C" int rnnwf_destroy(rnnwf_handle* h) {
     rnnwf_comm_destroy(h);
     DevBuf* bufs[] = {&h->wimg, &h->samples_i32, &h->bits, &h->bits2, &h->hck, &h->lpq, &h->lpq2, &h->out_lp,
                       &h->out_lp2, &h->eloc, &h->moments, &h->coupl, &h->maps, &h->camp, &h->tiles,
-                      &h->tile_count, &h->cbase, &h->cout, &h->rowbuf, &h->wbwd, &h->gradP, &h->gradQ, &h->gradW, &h->wsplit, &h->wbasebf, &h->gradDX[0], &h->gradDX[1], &h->reduce_scratch};
+                      &h->tile_count, &h->cbase, &h->cout, &h->rowbuf, &h->wbwd, &h->gradP, &h->gradQ, &h->gradW, &h->wsplit, &h->wsplit16, &h->wbasebf, &h->gradDX[0], &h->gradDX[1], &h->reduce_scratch};
     for (DevBuf* b : bufs) free_buf(*b);
     for (auto& t : h->timers) {
         for (auto& ev : t.pending) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }

@@ -20,7 +20,9 @@ struct RLaunch {
     using LC = SplitLayout<NF32, RJ, 3, 3>;                  // complex RNN: three head rows
     static int flip(rnnwf_handle* h, const PrnnArgs& a, int kt16) {
         if constexpr (RidersStepAsm<NF32, RJ, 1, L::STREAM>::kAvailable) {
-            if (h->knobs.engine != 4) return flip_asm(h, a, kt16);      // RNNWF_ENGINE=bf16x3-hipcc: the compiler-scheduled step, A/B only
+            // default: the 16x16x32 form; RNNWF_ENGINE=bf16x3-asm32: the 32x32x16 asm step; bf16x3-hipcc: the compiler-scheduled step (A/B)
+            if (h->knobs.engine != 4 && h->knobs.engine != 5 && h->wsplit16.p) return flip_asm16(h, a, kt16);
+            if (h->knobs.engine != 4) return flip_asm(h, a, kt16);
         }
         const void* fn = (const void*)prnn_flip_split_kernel<NF32, RJ, WAVES, 3>;
         if (L::HP > 4 * kt16) return h->fail(RNNWF_ERR_INVALID, "bf16x3 layout wider than the checkpoint rows (%d > %d)", L::HP, 4 * kt16);
@@ -48,6 +50,21 @@ struct RLaunch {
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }
+    // the 16x16x32 form (split16_core.h), 69..100 units
+    static int flip_asm16(rnnwf_handle* h, const PrnnArgs& a, int kt16) {
+        using L16 = S16Layout<1>;
+        const void* fn = (const void*)prnn_flip_riders16_asm_kernel<WAVES>;
+        if (kt16 != L16::NJ) return h->fail(RNNWF_ERR_INVALID, "the 16x16x32 form expects %d checkpoint k-steps, got %d", L16::NJ, kt16);
+        int bpc = 0;
+        if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, L16::LDS_BYTES, &bpc)) return rc;
+        const int64_t ntiles = (int64_t)(a.N - 1) * ((a.ns + 31) / 32);
+        const int64_t need = (ntiles + WAVES - 1) / WAVES;
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
+        TimedLaunch tl(h, 1);
+        prnn_flip_riders16_asm_kernel<WAVES><<<grid, WAVES * 64, L16::LDS_BYTES, h->stream>>>(a, h->wsplit16.p, kt16);
+        RNNWF_HIP(h, hipGetLastError());
+        return 0;
+    }
     static int swap(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles, int kt16) {
         const void* fn = (const void*)crnn_swap_split_kernel<NF32, RJ, WAVES, 3>;
         if (LC::HP > 4 * kt16) return h->fail(RNNWF_ERR_INVALID, "bf16x3 layout wider than the checkpoint rows (%d > %d)", LC::HP, 4 * kt16);
@@ -71,11 +88,22 @@ int rnnwf::prnn_split_flip_stream(rnnwf_handle* h, const PrnnArgs& a, int kt16) 
     return h->NFULL == 6 ? R100::flip(h, a, kt16) : R68::flip(h, a, kt16);
 }
 double rnnwf::prnn_split_stream_flops_per_step(rnnwf_handle* h) {
+    // the 16x16x32 form: 19 tiles x 19 k-steps x 2 chain sets of 16 x 16 x 32 x 2 flop per 32-chain wave-step
+    if (h->NFULL == 6 && h->wsplit16.p && h->knobs.engine != 4 && h->knobs.engine != 5)
+        return (double)S16Layout<1>::NT * S16Layout<1>::KS * 2 * 16384.0;
     return h->NFULL == 6 ? (double)R100::L::NT * R100::L::KS * 32768.0 : (double)R68::L::NT * R68::L::KS * 32768.0;
 }
 int rnnwf::prnn_split_stream_pack(rnnwf_handle* h, std::vector<char>& simg) {
-    if (h->NFULL == 6) simg = pack_split_image<3, 2, 1, 3>(h);
-    else simg = pack_split_image<2, 2, 1, 3>(h);
+    if (h->NFULL == 6) {
+        simg = pack_split_image<3, 2, 1, 3>(h);
+        // the 16x16x32 form's image (split16_core.h) beside it: the default flip pass at these widths
+        const std::vector<char> img16 = pack_split16_image<1>(h);
+        if (int rc = ensure(h, h->wsplit16, img16.size())) return rc;
+        RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+        RNNWF_HIP(h, hipMemcpy(h->wsplit16.p, img16.data(), img16.size(), hipMemcpyHostToDevice));
+    } else {
+        simg = pack_split_image<2, 2, 1, 3>(h);
+    }
     return 0;
 }
 
