@@ -1,3 +1,5 @@
+# usage (GPU box, repo root): bash tools/refresh_cfg5.sh  -> full GPU suite, config-5 bench lines of the three step variants (default 16x16x32 asm,
+# RNNWF_ENGINE=bf16x3-asm32, bf16x3-hipcc), FETCH_SIZE / WRITE_SIZE passes and rocprofv3 stats of the default kernel, all under gpurun_out/r03_n_*
 timeout -k 10 700 python -m pytest tests -m gpu -q -x > gpurun_out/r03_n_tests.log 2>&1; echo "tests rc=$?"; tail -5 gpurun_out/r03_n_tests.log
 for e in default bf16x3-asm32 bf16x3-hipcc; do if [ $e = default ]; then unset RNNWF_ENGINE; else export RNNWF_ENGINE=$e; fi; timeout -k 10 200 python bench.py --workload cfg5 --steps 5 --warmup 2 --no-cpu-baseline --no-alt-engine > gpurun_out/r03_n_cfg5_$e.json 2> gpurun_out/r03_n_cfg5_$e.err; python -c "
 import json
