@@ -3,6 +3,7 @@
 #include <algorithm>
 
 #include "grad_kernels.h"
+#include "tn_gemm.h"
 #include "ml_grad_kernels.h"
 #include "models.h"
 #include "pack.h"
@@ -57,20 +58,17 @@ struct GLaunch {
         if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, lds, &bpc)) return rc;
         const int64_t need = (a.nsb + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
+        constexpr int HN = NOUT * G::HEAD_ROW;
+        T* part = nullptr;
+        if (int rc = head_part_alloc<T>(h, (size_t)grid * WAVES, HN, &part)) return rc;
+        a.head_part = part;
         {
             TimedLaunch tl(h, 3);
             gru_bwd_kernel<T, NFULL, WAVES, NOUT><<<grid, WAVES * 64, lds, h->stream>>>(a);
+            head_reduce_launch<T>(h, (size_t)grid * WAVES, HN, (T*)a.head_grad);
         }
         RNNWF_HIP(h, hipGetLastError());
-        int64_t rpb = (R + (int64_t)h->cu_count * 4 - 1) / ((int64_t)h->cu_count * 4);
-        rpb = std::max<int64_t>(64, ((rpb + 3) / 4) * 4);
-        const unsigned gblocks = (unsigned)((R + rpb - 1) / rpb);
-        {
-            TimedLaunch tl(h, 4);
-            tn_gemm_kernel<T, G::PCOLS / 16, G::QCOLS / 16><<<gblocks, 256, 0, h->stream>>>((const T*)a.P, (const T*)a.Q, R, rpb, (T*)dW);
-        }
-        RNNWF_HIP(h, hipGetLastError());
-        return 0;
+        return tn_gemm_launch<T, G::PCOLS / 16, G::QCOLS / 16>(h, (const T*)a.P, (const T*)a.Q, R, (T*)dW);
     }
 
     // dW image [PCOLS][QCOLS] + head gradients -> TF-named gradient arrays
@@ -231,7 +229,7 @@ struct MLGrad {
     }
 
     template <bool TOP>
-    static int upper_pass(rnnwf_handle* h, const UpperGradArgs& a) {
+    static int upper_pass(rnnwf_handle* h, UpperGradArgs a) {
         const void* fn = (const void*)gru_upper_bwd_kernel<T, NFULL, WAVES, TOP, NOUT>;
         const size_t lds = U::BYTES + GU::BWD_BYTES + (TOP ? GU::HEAD_BYTES : 0);
         if (lds > 160 * 1024) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: stacked-layer images (%zu B) exceed the 160 KB LDS", lds);
@@ -239,25 +237,24 @@ struct MLGrad {
         if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, lds, &bpc)) return rc;
         const int64_t need = (a.nsb + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
+        constexpr int HN = NOUT * GU::HEAD_ROW;
+        if (TOP) {
+            T* part = nullptr;
+            if (int rc = head_part_alloc<T>(h, (size_t)grid * WAVES, HN, &part)) return rc;
+            a.head_part = part;
+        }
         {
             TimedLaunch tl(h, 3);
             gru_upper_bwd_kernel<T, NFULL, WAVES, TOP, NOUT><<<grid, WAVES * 64, lds, h->stream>>>(a);
+            if (TOP) head_reduce_launch<T>(h, (size_t)grid * WAVES, HN, (T*)a.head_grad);
         }
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }
 
     static int gemm(rnnwf_handle* h, const T* P, const T* Q, int64_t R, T* dW, bool upper) {
-        int64_t rpb = (R + (int64_t)h->cu_count * 4 - 1) / ((int64_t)h->cu_count * 4);
-        rpb = std::max<int64_t>(64, ((rpb + 3) / 4) * 4);
-        const unsigned gblocks = (unsigned)((R + rpb - 1) / rpb);
-        {
-            TimedLaunch tl(h, 4);
-            if (upper) tn_gemm_kernel<T, GU::PCOLS / 16, GU::QCOLS / 16><<<gblocks, 256, 0, h->stream>>>(P, Q, R, rpb, dW);
-            else tn_gemm_kernel<T, G0::G::PCOLS / 16, G0::G::QCOLS / 16><<<gblocks, 256, 0, h->stream>>>(P, Q, R, rpb, dW);
-        }
-        RNNWF_HIP(h, hipGetLastError());
-        return 0;
+        if (upper) return tn_gemm_launch<T, GU::PCOLS / 16, GU::QCOLS / 16>(h, P, Q, R, dW);
+        return tn_gemm_launch<T, G0::G::PCOLS / 16, G0::G::QCOLS / 16>(h, P, Q, R, dW);
     }
 
     static int run(rnnwf_handle* h, double mean_energy, double mean_energy_im, double norm) {

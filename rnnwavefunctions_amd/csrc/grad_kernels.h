@@ -8,10 +8,11 @@
 //                     the pre-activation gradients (VALU) and propagates dL/dh through the transposed weights
 //                     on the f32 MFMA (same lane layout trick as the forward: the C/D fragment is the next B
 //                     operand).  It writes, per (site, chain), the row  P = [d a_r | d a_u | d q | d y]  and the
-//                     row  Q = [h_in | x one-hot | 1]; head gradients are reduced in registers.
-//   tn_gemm_kernel  : dW = P^T Q over all R = N*ns rows (tall-skinny TN GEMM on the f32 MFMA; operands are read
-//                     straight from the row-major arrays, which already have the A/B fragment shape), partial
-//                     sums combined with float atomics.
+//                     row  Q = [h_in | x one-hot | 1]; head gradients are summed in registers, one row per wave,
+//                     and head_reduce_kernel adds the rows.
+//   tn_gemm_kernel  : dW = P^T Q over all R = N*ns rows (tall-skinny TN GEMM on the f32 / f64 MFMA; operands are read
+//                     straight from the row-major arrays, which already have the A/B fragment shape); every block
+//                     stores its partial fragments, tn_reduce_kernel adds them in a fixed order.
 #pragma once
 #include "gru_core.h"
 
@@ -49,12 +50,49 @@ struct GradArgs {
     double mean_e, mean_im, inv_norm;   // w_s = (E_s - mean) * inv_norm  (real and imaginary part separately)
     void* P;                   // [N*ns][PCOLS] T
     void* Q;                   // [N*ns][QCOLS] T
-    void* head_grad;           // [NOUT][HEAD_ROW] T, zeroed before the launch
+    void* head_grad;           // [NOUT][HEAD_ROW] T, zeroed before the launch (written by head_reduce_kernel)
+    void* head_part;           // [waves of the grid][NOUT][HEAD_ROW] T: every wave's head-row sums
     // stacked layers: this kernel is then the LAST pass (layer 0); dL/dh of every site arrives from
     // the layer above instead of from the head, and hck holds hck_nl layers per (site, block)
     const void* dh_in;         // [N][nsb][KT][64] T or nullptr
     int32_t hck_nl;            // layers per checkpoint entry (0 or 1: single layer)
 };
+
+// Head-row sums of one wave over its chains, stored (not added) to row = part[global wave][NOUT][HEAD_ROW]: slot 4 k + q is a unit
+// slot, 4 KT the bias, the rest zero.  head_reduce_kernel adds the waves' rows in a fixed order: no atomics, the gradient is
+// bit-reproducible.
+template <typename T, int NOUT, int KT>
+__device__ __forceinline__ void store_head_part(T* row, int head_row, const T (&hg)[NOUT][KT], const T (&gb)[NOUT], int c, int q) {
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            T v = hg[o][k];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            if (c == 0) row[o * head_row + 4 * k + q] = v;
+        }
+        T v = gb[o];
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+        if (c == 0) row[o * head_row + 4 * KT + q] = q == 0 ? v : T(0);
+    }
+}
+
+// out[j] += sum over the nparts rows of part[.][j], j < n; 64 entries per workgroup of 16 waves (wave w adds the rows w, w + 16, ...).
+template <typename T>
+__global__ void __launch_bounds__(1024) head_reduce_kernel(const T* __restrict__ part, int nparts, int n, T* __restrict__ out) {
+    __shared__ T sums[16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    T v = T(0);
+    if (j < n)
+        for (int p = w; p < nparts; p += 16) v += part[(size_t)p * n + j];
+    sums[w][lane] = v;
+    __syncthreads();
+    if (w != 0 || j >= n) return;
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v += sums[k][lane];
+    out[j] += v;
+}
 
 // NOUT = 1: positive RNN, L = sum_s w_s log P(s).
 // NOUT = 3: complex RNN, L = sum_s [w_re Re log psi(s) + w_im Im log psi(s)]  (J1J2/TrainingRNN_J1J2.py:197:
@@ -94,6 +132,13 @@ __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
     const int N = a.N;
     const T* wd = reinterpret_cast<const T*>(lds + C::L::OFF_WD) + q * C::L::WD_Q;
     const int hck_nl = a.hck_nl > 1 ? a.hck_nl : 1;
+    T hg[NOUT][KT], gb[NOUT];                             // head-row sums over all chains of this wave
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        gb[o] = T(0);
+#pragma unroll
+        for (int k = 0; k < KT; ++k) hg[o][k] = T(0);
+    }
     for (int64_t sb = gw; sb < a.nsb; sb += nw) {
         const int64_t s = sb * kChains + c;
         const bool valid = s < a.ns;
@@ -109,16 +154,9 @@ __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
             }
         }
         auto spin = [&](int n) { return (int)((a.bits[(int64_t)(n >> 5) * a.ns + sc] >> (n & 31)) & 1); };
-        T dh[KT], hg[NOUT][KT];
-        T gb[NOUT];
+        T dh[KT];
 #pragma unroll
         for (int k = 0; k < KT; ++k) dh[k] = T(0);
-#pragma unroll
-        for (int o = 0; o < NOUT; ++o) {
-            gb[o] = T(0);
-#pragma unroll
-            for (int k = 0; k < KT; ++k) hg[o][k] = T(0);
-        }
         int num_up = 0;                                   // complex RNN: up spins among sites < n (for the U(1) mask)
         if constexpr (NOUT == 3)
             for (int m = 0; m < N; ++m) num_up += spin(m);
@@ -239,66 +277,193 @@ __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
                 for (int r = 0; r < 4; ++r) dh[4 * m + r] += accb[m][r];
             dh[KT - 1] += accb[NFULL][0];
         }
-        // head gradients: reduce over the 16 chains of each lane quarter, one atomic per (row, unit slot)
+    }
+    store_head_part<T, NOUT, KT>(reinterpret_cast<T*>(a.head_part) + (size_t)gw * NOUT * G::HEAD_ROW, G::HEAD_ROW, hg, gb, c, q);
+}
+
+// Partial sums of  P[row][:]^T Q[row][:]  over one contiguous chunk of rows per block (4 waves).
+// A 16x16x4 step takes four rows (k = lane quarter lk); which sixteen columns make up an output tile is free, so the columns of
+// a row are taken in CHUNKS of VW tiles (16 bytes per lane): lane li loads the VW consecutive columns  off + VW li .. + VW - 1
+// of its row with one 16-byte load and element j feeds tile j of the chunk (tile row i <-> column off + VW i + j).  The last
+// chunk of a row may be narrower (P: 2 tiles at f32; Q: 1 - 3), loaded with 8- and 4-byte pieces.  Wave w owns the P chunks
+// w, w + WAVES, ... and every Q chunk; the next eight rows are fetched while the current eight are multiplied.
+template <typename T, int NTILES, int CW = 16 / (int)sizeof(T)>
+struct RowChunks {
+    static constexpr int VW = CW;                          // tiles per chunk = elements per lane and load
+    static constexpr int NC = (NTILES + VW - 1) / VW;
+    static constexpr int WL = NTILES - VW * (NC - 1);      // tiles of the last chunk, 1 .. VW
+    static constexpr int COLS = 16 * NTILES;
+    static constexpr int width(int c) { return c < NC - 1 ? VW : WL; }
+    static constexpr int col(int c, int i, int j) { return 16 * VW * c + width(c) * i + j; }
+    // elements of a chunk of W tiles starting at p for lane li:  v[j] = p[W li + j]
+    template <int W>
+    static __device__ __forceinline__ void load(const T* __restrict__ p, int li, T (&v)[VW]) {
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) {
+        for (int j = W; j < VW; ++j) v[j] = T(0);
+        if constexpr (W == 4 || W == 2) {
+            typedef T VT __attribute__((ext_vector_type(W)));
+            const VT x = *reinterpret_cast<const VT*>(p + W * li);
 #pragma unroll
-            for (int k = 0; k < KT; ++k) {
-                T v = hg[o][k];
-                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-                if (c == 0) atomicAdd(&reinterpret_cast<T*>(a.head_grad)[o * G::HEAD_ROW + 4 * k + q], v);
-            }
-            T v = gb[o];
-            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-            if (c == 0 && q == 0) atomicAdd(&reinterpret_cast<T*>(a.head_grad)[o * G::HEAD_ROW + 4 * KT], v);
+            for (int j = 0; j < W; ++j) v[j] = x[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < W; ++j) v[j] = p[W * li + j];
         }
+    }
+};
+
+// Waves per block and P-chunk width of the product: 8 waves where four would hold more than 160 accumulator registers each;
+// the widest chunk (fewest loads) among those that give the busiest wave the fewest tiles (the large shapes are MFMA-bound).
+constexpr int tn_max_tiles(int nt, int cw, int waves) {
+    const int nc = (nt + cw - 1) / cw;
+    int worst = 0;
+    for (int w = 0; w < waves; ++w) {
+        int tiles = 0;
+        for (int c = w; c < nc; c += waves) tiles += c < nc - 1 ? cw : nt - cw * (nc - 1);
+        worst = tiles > worst ? tiles : worst;
+    }
+    return worst;
+}
+template <typename T, int PT, int QT>
+struct TnGemmShape {
+    static constexpr int VWMAX = 16 / (int)sizeof(T);
+    static constexpr int WAVES = ((PT + 3) / 4) * QT * (int)sizeof(T) > 160 ? 8 : 4;
+    static constexpr int pick() {
+        int best = VWMAX;
+        for (int cw = VWMAX / 2; cw >= 1; cw /= 2)
+            if (tn_max_tiles(PT, cw, WAVES) < tn_max_tiles(PT, best, WAVES)) best = cw;
+        return best;
+    }
+    static constexpr int CW = pick();
+    using CP = RowChunks<T, PT, CW>;
+    using CQ = RowChunks<T, QT>;
+};
+
+// LAST: what this wave's chunk slot ILAST = (NC - 1) / WAVES holds: 0 nothing, 1 the row's narrow last chunk, 2 a full chunk.
+template <typename T, int PT, int QT, int WAVES, int LAST>
+__device__ __forceinline__ void tn_gemm_body(const T* __restrict__ P, const T* __restrict__ Q, int64_t r0, int64_t r1,
+                                             T* __restrict__ part, int wave, int li, int lk) {
+    using V4 = typename Frag<T>::V4;
+    using CP = typename TnGemmShape<T, PT, QT>::CP;
+    using CQ = typename TnGemmShape<T, PT, QT>::CQ;
+    constexpr int VW = CP::VW, VQ = CQ::VW;
+    constexpr int ILAST = (CP::NC - 1) / WAVES;
+    constexpr int MC = ILAST + (LAST != 0 ? 1 : 0);        // P chunks of this wave
+    constexpr int NS = MC * VW * QT * (int)sizeof(T) > 160 ? 1 : 2;    // 4-row steps per iteration (one when the accumulators are many)
+    if constexpr (MC > 0) {
+        auto pw = [](int i) { return i == ILAST && LAST == 1 ? CP::WL : VW; };
+        V4 acc[MC][VW][QT];
+#pragma unroll
+        for (int i = 0; i < MC; ++i)
+#pragma unroll
+            for (int jp = 0; jp < VW; ++jp)
+#pragma unroll
+                for (int t = 0; t < QT; ++t) acc[i][jp][t] = V4{T(0), T(0), T(0), T(0)};
+        T pa[NS][MC][VW], qb[NS][CQ::NC][VQ];
+        // rows past r1 are read from row r0 instead (always in bounds) and zeroed when they are multiplied
+        auto fetch = [&](int64_t r, T (&pv)[NS][MC][VW], T (&qv)[NS][CQ::NC][VQ], bool (&okv)[NS]) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int64_t row = r + 4 * s + lk;
+                const bool ok = row < r1;
+                okv[s] = ok;
+                const int64_t rc = ok ? row : r0;
+                const T* prow = P + rc * CP::COLS + 16 * VW * wave;
+#pragma unroll
+                for (int i = 0; i < MC; ++i) {
+                    if (i == ILAST && LAST == 1) CP::template load<CP::WL>(prow + 16 * VW * WAVES * i, li, pv[s][i]);
+                    else CP::template load<VW>(prow + 16 * VW * WAVES * i, li, pv[s][i]);
+                }
+                const T* qrow = Q + rc * CQ::COLS;
+#pragma unroll
+                for (int c = 0; c < CQ::NC; ++c) {
+                    if (c == CQ::NC - 1) CQ::template load<CQ::WL>(qrow + 16 * VQ * c, li, qv[s][c]);
+                    else CQ::template load<VQ>(qrow + 16 * VQ * c, li, qv[s][c]);
+                }
+            }
+        };
+        auto multiply = [&](const T (&pv)[NS][MC][VW], const T (&qv)[NS][CQ::NC][VQ], const bool (&okv)[NS]) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int i = 0; i < MC; ++i)
+#pragma unroll
+                    for (int jp = 0; jp < VW; ++jp) {
+                        if (jp >= pw(i)) continue;
+                        const T a = okv[s] ? pv[s][i][jp] : T(0);
+#pragma unroll
+                        for (int t = 0; t < QT; ++t)
+                            acc[i][jp][t] = Frag<T>::mfma(a, qv[s][t / VQ][t % VQ], acc[i][jp][t]);
+                    }
+        };
+        // two register sets: the loads of one are in flight while the other is multiplied (a set past r1 is all zeros)
+        T pb[NS][MC][VW], qc[NS][CQ::NC][VQ];
+        bool oka[NS], okb[NS];
+        fetch(r0, pa, qb, oka);
+        for (int64_t r = r0; r < r1; r += 8 * NS) {
+            fetch(r + 4 * NS, pb, qc, okb);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(pa, qb, oka);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(r + 8 * NS, pa, qb, oka);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(pb, qc, okb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // this block's partial sums, one 16-byte fragment per (tile, lane): part[block][P tile][Q tile][64]
+        V4* out = reinterpret_cast<V4*>(part) + (size_t)blockIdx.x * PT * QT * 64 + (threadIdx.x & 63);
+#pragma unroll
+        for (int i = 0; i < MC; ++i)
+#pragma unroll
+            for (int jp = 0; jp < VW; ++jp) {
+                if (jp >= pw(i)) continue;
+                const int ptile = VW * (wave + WAVES * i) + jp;
+#pragma unroll
+                for (int t = 0; t < QT; ++t) out[(size_t)(ptile * QT + t) * 64] = acc[i][jp][t];
+            }
     }
 }
 
-// dW[PCOLS][QCOLS] += sum over rows of P[row][:]^T Q[row][:]; one block = 4 waves = one contiguous chunk of rows.
-// Wave w owns the 16-row output tiles mt = w, w+4, ... and all QCOLS/16 column tiles.
 template <typename T, int PT, int QT>
-__global__ void __launch_bounds__(256) tn_gemm_kernel(const T* __restrict__ P, const T* __restrict__ Q, int64_t R,
-                                                      int64_t rows_per_block, T* __restrict__ dW) {
-    using V4 = typename Frag<T>::V4;
-    constexpr int MW = (PT + 3) / 4;                       // output row tiles per wave
+__global__ void __launch_bounds__((TnGemmShape<T, PT, QT>::WAVES * 64)) tn_gemm_kernel(const T* __restrict__ P, const T* __restrict__ Q, int64_t R,
+                                                                                    int64_t rows_per_block, T* __restrict__ part) {
+    using CP = typename TnGemmShape<T, PT, QT>::CP;
+    constexpr int WAVES = TnGemmShape<T, PT, QT>::WAVES;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int li = lane & 15, lk = lane >> 4;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;      // the host launches ceil(R / rows_per_block) blocks: r0 < R
     const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
-    V4 acc[MW][QT];
+    constexpr int WLAST = (CP::NC - 1) % WAVES;            // the wave that owns the row's last chunk
+    if (wave < WLAST) tn_gemm_body<T, PT, QT, WAVES, 2>(P, Q, r0, r1, part, wave, li, lk);
+    else if (wave == WLAST) tn_gemm_body<T, PT, QT, WAVES, CP::WL == CP::VW ? 2 : 1>(P, Q, r0, r1, part, wave, li, lk);
+    else tn_gemm_body<T, PT, QT, WAVES, 0>(P, Q, r0, r1, part, wave, li, lk);
+}
+
+// dW[P column][Q column] += sum over the blocks' partial fragments, in a fixed order (no atomics: the weight gradients are
+// bit-reproducible).  One workgroup of 16 waves per output tile: wave w adds the blocks w, w + 16, ..., wave 0 the sixteen sums.
+template <typename T, int PT, int QT>
+__global__ void __launch_bounds__(1024) tn_reduce_kernel(const T* __restrict__ part, int nblocks, T* __restrict__ dW) {
+    using V4 = typename Frag<T>::V4;
+    using CP = typename TnGemmShape<T, PT, QT>::CP;
+    using CQ = typename TnGemmShape<T, PT, QT>::CQ;
+    constexpr int VW = CP::VW, VQ = CQ::VW;
+    __shared__ V4 sums[16][64];
+    const int tile = blockIdx.x, ptile = tile / QT, t = tile % QT;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const V4* src = reinterpret_cast<const V4*>(part) + (size_t)tile * 64 + lane;
+    V4 v = V4{T(0), T(0), T(0), T(0)};
+    for (int b = w; b < nblocks; b += 16) v += src[(size_t)b * PT * QT * 64];
+    sums[w][lane] = v;
+    __syncthreads();
+    if (w != 0) return;
 #pragma unroll
-    for (int i = 0; i < MW; ++i)
+    for (int k = 1; k < 16; ++k) v += sums[k][lane];
+    const int li = lane & 15, lk = lane >> 4;
+    const int c = ptile / VW, jp = ptile % VW, cq = t / VQ;
 #pragma unroll
-        for (int j = 0; j < QT; ++j) acc[i][j] = V4{T(0), T(0), T(0), T(0)};
-    for (int64_t r = r0; r < r1; r += 4) {
-        const int64_t row = r + lk;
-        const bool ok = row < r1;
-        T af[MW], bf[QT];
-#pragma unroll
-        for (int i = 0; i < MW; ++i) {
-            const int mt = wave + 4 * i;
-            af[i] = (ok && mt < PT) ? P[row * (PT * 16) + mt * 16 + li] : T(0);
-        }
-#pragma unroll
-        for (int j = 0; j < QT; ++j) bf[j] = ok ? Q[row * (QT * 16) + j * 16 + li] : T(0);
-#pragma unroll
-        for (int i = 0; i < MW; ++i)
-#pragma unroll
-            for (int j = 0; j < QT; ++j) acc[i][j] = Frag<T>::mfma(af[i], bf[j], acc[i][j]);
-    }
-#pragma unroll
-    for (int i = 0; i < MW; ++i) {
-        const int mt = wave + 4 * i;
-        if (mt >= PT) continue;
-#pragma unroll
-        for (int j = 0; j < QT; ++j)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                // C/D fragment row of (lane quarter lk, register rr): f32 4 lk + rr, f64 lk + 4 rr
-                const int row = sizeof(T) == 4 ? 4 * lk + rr : lk + 4 * rr;
-                atomicAdd(&dW[(size_t)(mt * 16 + row) * (QT * 16) + j * 16 + li], acc[i][j][rr]);
-            }
+    for (int rr = 0; rr < 4; ++rr) {
+        const int fr = sizeof(T) == 4 ? 4 * lk + rr : lk + 4 * rr;      // C/D fragment row of (lane quarter lk, register rr)
+        dW[(size_t)CP::col(c, fr, jp) * CQ::COLS + CQ::col(cq, li, t % VQ)] += v[rr];
     }
 }
 

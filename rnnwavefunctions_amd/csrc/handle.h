@@ -67,6 +67,7 @@ struct rnnwf_handle {
     rnnwf::DevBuf rowbuf;
     // gradient (grad.hip)
     rnnwf::DevBuf wbwd, gradP, gradQ, gradW;
+    rnnwf::DevBuf gradPart, gradHeadPart;    // per-block partial sums of the weight-gradient GEMM; per-wave head-row sums
     std::vector<double> coupl_host;   // what h->coupl holds (couplings rarely change between steps: skip the upload)
     rnnwf::DevBuf gradDX[2];      // stacked layers: dL/dx of one layer's pass = dL/dh input of the pass below
     // bf16x3 engine (split_core.h): second weight image; engine_split = use it for the flip pass

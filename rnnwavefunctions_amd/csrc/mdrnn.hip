@@ -4,6 +4,7 @@
 
 #include "grad_kernels.h"
 #include "mdrnn_grad_kernels.h"
+#include "tn_gemm.h"
 #include "mdrnn_kernels.h"
 #include "models.h"
 #include "pack.h"
@@ -415,20 +416,14 @@ struct MGrad {
         const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
         if (int rc = ensure(h, h->rowbuf, (size_t)grid * WAVES * 2 * a.Nx * G::KT * 64 * 8)) return rc;
         a.ring = (double*)h->rowbuf.p;
+        if (int rc = head_part_alloc<double>(h, (size_t)grid * WAVES, 2 * G::HEAD_ROW, &a.head_part)) return rc;
         {
             TimedLaunch tl(h, 3);
             mdrnn_bwd_kernel<NFULL, WAVES><<<grid, WAVES * 64, G::BYTES, h->stream>>>(a);
+            head_reduce_launch<double>(h, (size_t)grid * WAVES, 2 * G::HEAD_ROW, a.head_grad);
         }
         RNNWF_HIP(h, hipGetLastError());
-        int64_t rpb = (R + (int64_t)h->cu_count * 4 - 1) / ((int64_t)h->cu_count * 4);
-        rpb = std::max<int64_t>(64, ((rpb + 3) / 4) * 4);
-        const unsigned gblocks = (unsigned)((R + rpb - 1) / rpb);
-        {
-            TimedLaunch tl(h, 4);
-            tn_gemm_kernel<double, G::PCOLS / 16, G::QCOLS / 16><<<gblocks, 256, 0, h->stream>>>(a.P, a.Q, R, rpb, dW);
-        }
-        RNNWF_HIP(h, hipGetLastError());
-        return 0;
+        return tn_gemm_launch<double, G::PCOLS / 16, G::QCOLS / 16>(h, a.P, a.Q, R, dW);
     }
 
     static void unpack(rnnwf_handle* h, const double* dW, const double* hg) {

@@ -10,6 +10,7 @@
 // positions in HBM, written and read by the same lane.  Weight gradients are  P^T Q  (tn_gemm_kernel) with
 //   P [N*ns][16 NT]  = dpre,   Q [N*ns][32 NT] = [h_h, onehot(x_h), 1 | h_v, onehot(x_v), 0].
 #pragma once
+#include "grad_kernels.h"
 #include "mdrnn_kernels.h"
 
 namespace rnnwf {
@@ -39,7 +40,8 @@ struct MdGradArgs {
     double mean_e, inv_norm;
     double* P;
     double* Q;
-    double* head_grad;             // [2][HEAD_ROW], zeroed before the launch
+    double* head_grad;             // [2][HEAD_ROW], zeroed before the launch (written by head_reduce_kernel)
+    double* head_part;             // [waves of the grid][2][HEAD_ROW]: every wave's head-row sums
     const int32_t* vert_pos;
     const int32_t* row_first;
 };
@@ -176,18 +178,7 @@ __global__ void __launch_bounds__(WAVES * 64) mdrnn_bwd_kernel(MdGradArgs a) {
             carry[KT - 1] = first ? (turn ? acc[NT + NFULL][0] : 0.0) : acc[NFULL][0];
         }
     }
-#pragma unroll
-    for (int o = 0; o < 2; ++o) {
-#pragma unroll
-        for (int k = 0; k < KT; ++k) {
-            double v = hg[o][k];
-            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-            if (c == 0) atomicAdd(&a.head_grad[o * G::HEAD_ROW + 4 * k + q], v);
-        }
-        double v = gb[o];
-        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-        if (c == 0 && q == 0) atomicAdd(&a.head_grad[o * G::HEAD_ROW + 4 * KT], v);
-    }
+    store_head_part<double, 2, KT>(a.head_part + (size_t)gw * 2 * G::HEAD_ROW, G::HEAD_ROW, hg, gb, c, q);
 }
 
 }  // namespace rnnwf

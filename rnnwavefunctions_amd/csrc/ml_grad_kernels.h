@@ -45,7 +45,8 @@ struct UpperGradArgs {
     void* dx_out;              // [N][nsb][KT][64] T
     void* P;
     void* Q;
-    void* head_grad;           // [NOUT][HEAD_ROW] T (top layer)
+    void* head_grad;           // [NOUT][HEAD_ROW] T (top layer; written by head_reduce_kernel)
+    void* head_part;           // [waves of the grid][NOUT][HEAD_ROW] T (top layer)
 };
 
 // NOUT (top layer only): 1 = positive RNN head, 3 = complex RNN heads (the site terms of gru_bwd_kernel).
@@ -58,7 +59,6 @@ __global__ void __launch_bounds__(WAVES * 64) gru_upper_bwd_kernel(UpperGradArgs
     constexpr int KT = CU::KT, NT = G::NT, VW = G::VW;
     const T* hck = reinterpret_cast<const T*>(a.hck);
     const T* dh_in = reinterpret_cast<const T*>(a.dh_in);
-    T* head_grad = reinterpret_cast<T*>(a.head_grad);
     extern __shared__ __attribute__((aligned(16))) char lds[];
     {
         auto copy = [&](char* dst_, const void* src_, size_t bytes) {
@@ -240,20 +240,7 @@ __global__ void __launch_bounds__(WAVES * 64) gru_upper_bwd_kernel(UpperGradArgs
             dxo[(KT - 1) * 64] = accX[NFULL][0];
         }
     }
-    if (TOP) {
-#pragma unroll
-        for (int o = 0; o < NOUT; ++o) {
-#pragma unroll
-            for (int k = 0; k < KT; ++k) {
-                T v = hg[o][k];
-                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-                if (c == 0) atomicAdd(&head_grad[o * G::HEAD_ROW + 4 * k + q], v);
-            }
-            T v = gb[o];
-            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-            if (c == 0 && q == 0) atomicAdd(&head_grad[o * G::HEAD_ROW + 4 * KT], v);
-        }
-    }
+    if (TOP) store_head_part<T, NOUT, KT>(reinterpret_cast<T*>(a.head_part) + (size_t)gw * NOUT * G::HEAD_ROW, G::HEAD_ROW, hg, gb, c, q);
 }
 
 }  // namespace rnnwf

@@ -469,13 +469,48 @@ def test_comm_env_without_a_launcher_runs_as_a_single_process(monkeypatch):
     kw = dict(numsteps=2, systemsize=8, num_units=6, numsamples=40, seed=5, verbose=False)
     a, _ = run_1DTFIM(comm="env", **kw)
     b, _ = run_1DTFIM(**kw)
-    # (the weight-gradient GEMM combines its partial sums with float atomics: two runs agree to rounding, not bit for bit)
-    assert a[0] == b[0] and np.allclose(a, b, rtol=1e-7, atol=0)
+    # (every reduction of the gradient has a fixed order - tn_reduce_kernel, head_reduce_kernel: two runs agree bit for bit)
+    assert np.array_equal(a, b)
     monkeypatch.setenv("WORLD_SIZE", "1")
     monkeypatch.setenv("RANK", "0")
     monkeypatch.setenv("LOCAL_RANK", "0")
     c, _ = run_1DTFIM(comm="env", **kw)
-    assert c[0] == b[0] and np.allclose(c, b, rtol=1e-7, atol=0)
+    assert np.array_equal(c, b)
+
+
+@pytest.mark.parametrize("model,shape,units,ns", [("gru", (40, 1), (50,), 5000), ("gru", (12, 1), (20, 20), 3000), ("gru", (10, 1), (100,), 1500),
+                                                  ("crnn", (20, 1), (50,), 4000), ("mdrnn", (4, 4), (20,), 3000), ("gru64", (4, 4), (20,), 3000)])
+def test_gradient_is_bit_reproducible(model, shape, units, ns):
+    """Every reduction of the gradient has a fixed order (tn_reduce_kernel over the blocks of the weight-gradient GEMM,
+    head_reduce_kernel over the waves of the backward pass; no float atomics): the same batch gives the same bits, on the
+    same handle and on a fresh one.  The batches are large enough for hundreds of GEMM blocks and backward waves."""
+    from rnnwavefunctions_amd import _lib
+    from rnnwavefunctions_amd.training import cost_gradient
+    N = shape[0] * shape[1]
+    if model == "mdrnn":
+        prm = P.scale_kernels(P.init_mdrnn_params(units[0], seed=7), 1.5)
+        mid, couplings = _lib.MODEL_MDRNN2D, np.append(np.ones(N), 2.0)
+    elif model == "crnn":
+        prm = P.scale_kernels(P.init_gru_params(list(units), seed=7, heads=("wf_dense_ampl", "wf_dense_phase")), 1.5)
+        mid, couplings = _lib.MODEL_CRNN_U1, np.concatenate([np.ones(N), 0.5 * np.ones(N), np.zeros(N), [0.0, 0.0]])
+    else:
+        prm = P.scale_kernels(P.init_gru_params(list(units), seed=7, dtype=np.float64 if model == "gru64" else np.float32), 1.5)
+        mid, couplings = (_lib.MODEL_GRU1D_F64 if model == "gru64" else _lib.MODEL_GRU1D), np.append(np.ones(N), 1.0)
+
+    def gradients(twice):
+        wf = _lib.NativeWavefunction(mid, shape[0], shape[1], units)
+        wf.set_params(prm, scope=SCOPE)
+        out = wf.vmc_step(ns, seed=5, step=0, couplings=couplings, want_eloc=True)
+        mean = out["eloc"].mean()
+        return [cost_gradient(wf, prm, SCOPE, mean, ns) for _ in range(2 if twice else 1)]
+
+    a, b = gradients(True)
+    (c,) = gradients(False)
+    assert set(a) == set(prm)
+    for name in a:
+        assert np.all(np.isfinite(a[name])) and np.abs(a[name]).max() > 0, name
+        assert np.array_equal(a[name], b[name]), name
+        assert np.array_equal(a[name], c[name]), name
 
 
 def test_reference_training_loop_of_j1j2_runs_with_compat_as_tf():
