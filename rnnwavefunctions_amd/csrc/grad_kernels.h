@@ -153,25 +153,40 @@ __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
                 w_im = (T)(((double)e.y - a.mean_im) * a.inv_norm);
             }
         }
-        auto spin = [&](int n) { return (int)((a.bits[(int64_t)(n >> 5) * a.ns + sc] >> (n & 31)) & 1); };
+        auto word = [&](int wi) { return a.bits[(int64_t)wi * a.ns + sc]; };
+        // nothing a site needs is fetched in that site: the spin words of sites n and n - 1 sit in registers (the word below is
+        // fetched 32 sites ahead) and the input state of site n - 1 is fetched while site n is worked on
+        uint32_t wcur = word((N - 1) >> 5), wlow = N > 32 ? word(((N - 1) >> 5) - 1) : 0u;
+        auto fetch_state = [&](int n, T (&dst)[KT]) {           // h_in of site n = state after site n - 1 (zero at n = 0)
+            if (n > 0) {
+                const T* src = reinterpret_cast<const T*>(a.hck) + (((int64_t)(n - 1) * a.nsb + sb) * hck_nl * KT) * 64 + lane;
+#pragma unroll
+                for (int k = 0; k < KT; ++k) dst[k] = src[k * 64];
+            } else {
+#pragma unroll
+                for (int k = 0; k < KT; ++k) dst[k] = T(0);
+            }
+        };
+        T hpf[KT];
+        fetch_state(N - 1, hpf);
         T dh[KT];
 #pragma unroll
         for (int k = 0; k < KT; ++k) dh[k] = T(0);
         int num_up = 0;                                   // complex RNN: up spins among sites < n (for the U(1) mask)
         if constexpr (NOUT == 3)
-            for (int m = 0; m < N; ++m) num_up += spin(m);
+            for (int wi = 0; wi < (N + 31) / 32; ++wi)
+                num_up += __popc(word(wi) & (32 * wi + 32 <= N ? 0xffffffffu : (1u << (N & 31)) - 1u));
         for (int n = N - 1; n >= 0; --n) {
             T h[KT], hn[KT], rg[KT], ug[KT], cc[KT], qv[KT];
-            if (n > 0) {
-                const T* src = reinterpret_cast<const T*>(a.hck) + (((int64_t)(n - 1) * a.nsb + sb) * hck_nl * KT) * 64 + lane;
 #pragma unroll
-                for (int k = 0; k < KT; ++k) h[k] = src[k * 64];
-            } else {
-#pragma unroll
-                for (int k = 0; k < KT; ++k) h[k] = T(0);
+            for (int k = 0; k < KT; ++k) h[k] = hpf[k];
+            if (n > 0) fetch_state(n - 1, hpf);
+            const int sig = (int)((wcur >> (n & 31)) & 1);
+            const int sig_in = n == 0 ? -1 : (n & 31) ? (int)((wcur >> ((n - 1) & 31)) & 1) : (int)(wlow >> 31);
+            if ((n & 31) == 0 && n > 0) {
+                wcur = wlow;
+                wlow = n >= 64 ? word((n >> 5) - 2) : 0u;
             }
-            const int sig_in = n > 0 ? spin(n - 1) : -1;
-            const int sig = spin(n);
             C::step_keep(lds, sig_in, h, hn, rg, ug, cc, qv, lane);
             T z[NOUT];
             C::head(lds, hn, lane, z);
