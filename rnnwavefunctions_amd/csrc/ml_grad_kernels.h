@@ -107,21 +107,30 @@ __global__ void __launch_bounds__(WAVES * 64) gru_upper_bwd_kernel(UpperGradArgs
         T dh[KT];
 #pragma unroll
         for (int k = 0; k < KT; ++k) dh[k] = T(0);
-        for (int n = N - 1; n >= 0; --n) {
-            T x[KT], h[KT], hn[KT], rg[KT], ug[KT], cc[KT], qv[KT];
+        // the inputs of site n - 1 (state of the layer below at that site, this layer's state before it) are fetched while
+        // site n is worked on
+        auto fetch_inputs = [&](int n, T (&xd)[KT], T (&hd)[KT]) {
             {
                 const T* src = hck + ((((int64_t)n * a.nsb + sb) * a.hck_nl + a.layer - 1) * KT) * 64 + lane;
 #pragma unroll
-                for (int k = 0; k < KT; ++k) x[k] = src[k * 64];
+                for (int k = 0; k < KT; ++k) xd[k] = src[k * 64];
             }
             if (n > 0) {
                 const T* src = hck + ((((int64_t)(n - 1) * a.nsb + sb) * a.hck_nl + a.layer) * KT) * 64 + lane;
 #pragma unroll
-                for (int k = 0; k < KT; ++k) h[k] = src[k * 64];
+                for (int k = 0; k < KT; ++k) hd[k] = src[k * 64];
             } else {
 #pragma unroll
-                for (int k = 0; k < KT; ++k) h[k] = T(0);
+                for (int k = 0; k < KT; ++k) hd[k] = T(0);
             }
+        };
+        T xpf[KT], hpf[KT];
+        fetch_inputs(N - 1, xpf, hpf);
+        for (int n = N - 1; n >= 0; --n) {
+            T x[KT], h[KT], hn[KT], rg[KT], ug[KT], cc[KT], qv[KT];
+#pragma unroll
+            for (int k = 0; k < KT; ++k) { x[k] = xpf[k]; h[k] = hpf[k]; }
+            if (n > 0) fetch_inputs(n - 1, xpf, hpf);
             CU::step_keep(lds, x, h, hn, rg, ug, cc, qv, lane);
             T g[NOUT];
 #pragma unroll

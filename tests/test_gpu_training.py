@@ -16,7 +16,8 @@ def oracle_cost(prm64, samples, eloc):
     return np.mean(lp * eloc) - np.mean(eloc) * np.mean(lp)          # TrainingRNN_1DTFIM.py:156
 
 
-@pytest.mark.parametrize("N,H,ns", [(6, 6, 64), (9, 20, 48), (7, 50, 32), (6, 64, 32), (6, 100, 24), (5, 80, 40)])   # > 68 units: backward operand through L2
+@pytest.mark.parametrize("N,H,ns", [(6, 6, 64), (9, 20, 48), (7, 50, 32), (6, 64, 32), (6, 100, 24), (5, 80, 40),   # > 68 units: backward operand through L2
+                                    (1, 10, 5), (2, 6, 3), (35, 20, 7), (67, 10, 9)])   # fewer rows than one GEMM step; spin words beyond the first
 def test_gradient_matches_finite_differences_of_the_oracle(N, H, ns):
     from rnnwavefunctions_amd import _lib
     from rnnwavefunctions_amd.training import cost_gradient
