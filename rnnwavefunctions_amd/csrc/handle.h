@@ -27,7 +27,7 @@ struct KernelTimer {
 
 // Environment switches, read ONCE in rnnwf_create (never on the per-step path).
 struct Knobs {
-    int engine = 0;               // RNNWF_ENGINE: 0 default, 1 "f32" (f32-input MFMA everywhere), 2 "bf16x3" (pinned), 3 "bf16x3-serial" (pinned, 4-wave kernel without the ping-pong: A/B), 4 "bf16x3-hipcc" (pinned; 69..100 units: the compiler-scheduled riders step instead of the generated asm block: A/B), 5 "bf16x3-asm32" (pinned; 69..100 units: the 32x32x16 asm step instead of the 16x16x32 one: A/B)
+    int engine = 0;               // RNNWF_ENGINE: 0 default, 1 "f32" (f32-input MFMA everywhere), 2 "bf16x3" (pinned), 3 "bf16x3-serial" (pinned, 4-wave kernel without the ping-pong: A/B), 4 "bf16x3-hipcc" (pinned; 69..100 units: the compiler-scheduled riders step instead of the generated asm block: A/B), 5 "bf16x3-asm32" (pinned; 69..100 units: the 32x32x16 asm step instead of the 16x16x32 one: A/B), 7 "bf16x3-n16" (pinned; 37..52 units, positive RNN: the 16x16x32 riders form instead of the 32x32x16 ping-pong kernel: A/B, 10 % slower)
     bool no_coop = false;         // RNNWF_NO_COOP=1: base pass always on the one-wave-per-block kernel
     bool base_f32 = false;        // RNNWF_BASE=f32: the base pass keeps the f32-input MFMA (no bf16 cooperative kernel): A/B, and the
                                   // bit-identity test of the two f32 kernels

@@ -59,6 +59,10 @@ int prnn_split_pack(rnnwf_handle* h, std::vector<char>& simg);
 int prnn_split_flip_stream(rnnwf_handle* h, const PrnnArgs& a, int kt16);
 double prnn_split_stream_flops_per_step(rnnwf_handle* h);
 int prnn_split_stream_pack(rnnwf_handle* h, std::vector<char>& simg);
+// the 16x16x32 form at 37..52 units (split_stream.hip; image in h->wsplit16)
+int prnn_split_flip_16n(rnnwf_handle* h, const PrnnArgs& a, int kt16);
+double prnn_split_16n_flops_per_step();
+int prnn_split_16n_pack(rnnwf_handle* h);
 int crnn_split_swap_stream(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles, int kt16);
 double crnn_split_stream_flops_per_step(rnnwf_handle* h);
 int crnn_split_stream_pack(rnnwf_handle* h, std::vector<char>& simg);

@@ -30,6 +30,87 @@ inline void split3(double w, uint16_t (&p)[3]) {
     }
 }
 
+// Image of the 16x16x32 form of the flip pass at 37..52 units (split16_core.h: S16nLayout).
+template <int NOUT>
+std::vector<char> pack_split16n_image(const rnnwf_handle* h) {
+    using L = S16nLayout<NOUT>;
+    static_assert(NOUT == 1, "the 16x16x32 form carries one head row (positive RNN)");
+    const int H = h->H;
+    std::vector<char> img(L::BYTES, 0);
+    const std::string pre = kGruPre;
+    const auto& Wg = pv(h, pre + "gates/kernel");
+    const auto& bg = pv(h, pre + "gates/bias");
+    const auto& Wci = pv(h, pre + "candidate/input_projection/kernel");
+    const auto& bci = pv(h, pre + "candidate/input_projection/bias");
+    const auto& Wch = pv(h, pre + "candidate/hidden_projection/kernel");
+    const auto& bch = pv(h, pre + "candidate/hidden_projection/bias");
+    const auto& Wd = pv(h, "wf_dense/kernel");
+    const auto& bd = pv(h, "wf_dense/bias");
+    const double sg = PackScale<float>::gate, sc = PackScale<float>::cand;
+    // row (tile t, row i = 4 g + r) -> (gate, unit): gate 0 r, 1 u, 2 candidate, 3 head; unit -1: unused row
+    auto decode = [&](int t, int g, int r, int& gate, int& unit) {
+        if (t < 6) { gate = t / 2; unit = 4 * (4 * (t % 2) + r) + g; }
+        else if (t < 9) { gate = t - 6; unit = 4 * (8 + r) + g; }
+        else if (r < 3) { gate = r; unit = 4 * 12 + g; }
+        else { gate = 3; unit = 0; }
+        if (gate < 3 && unit >= H) unit = -1;
+    };
+    auto weight = [&](int gate, int uo, int ui) -> double {
+        if (ui >= H) return 0.0;
+        return gate == 0 ? sg * Wg[(size_t)(2 + ui) * 2 * H + uo]
+             : gate == 1 ? sg * Wg[(size_t)(2 + ui) * 2 * H + H + uo]
+             : gate == 2 ? sc * Wch[(size_t)ui * H + uo]
+                         : Wd[(size_t)ui * 2 + 1] - Wd[(size_t)ui * 2];
+    };
+    uint16_t* A = reinterpret_cast<uint16_t*>(img.data() + L::OFF_A);
+    float* CI = reinterpret_cast<float*>(img.data() + L::OFF_CI);
+    for (int t = 0; t < L::NT; ++t)
+        for (int i = 0; i < 16; ++i) {
+            const int go = i >> 2, r = i & 3;
+            int gate, uo;
+            decode(t, go, r, gate, uo);
+            if (uo < 0) continue;
+            for (int sgm = 0; sgm < 2; ++sgm) {                  // accumulator start value: bias + one-hot input row
+                const double v = gate == 0 ? sg * (bg[uo] + Wg[(size_t)sgm * 2 * H + uo])
+                               : gate == 1 ? sg * (bg[H + uo] + Wg[(size_t)sgm * 2 * H + H + uo])
+                               : gate == 2 ? sc * bch[uo] : bd[1] - bd[0];
+                CI[(((size_t)sgm * L::NT + t) * 4 + go) * 4 + r] = (float)v;
+            }
+            for (int g = 0; g < 4; ++g) {                        // K side: lane group g supplies its units 4 j + g
+                const int lane = (g << 4) | i;
+                auto frag = [&](int f) { return A + (((size_t)t * L::NFR + f) * 64 + lane) * 8; };
+                for (int e = 0; e < 8; ++e) {                    // octet j = 0..7: fragment a = weight part a
+                    uint16_t p[3];
+                    split3(weight(gate, uo, 4 * e + g), p);
+                    for (int a = 0; a < 3; ++a) frag(a)[e] = p[a];
+                }
+                for (int e = 0; e < 4; ++e) {                    // j = 8..11: two products per k-step (entries e | 4 + e)
+                    uint16_t p[3];
+                    split3(weight(gate, uo, 4 * (8 + e) + g), p);
+                    frag(3)[e] = p[0]; frag(3)[4 + e] = p[0];    // (w1 | w1) x (h2 | h1)
+                    frag(4)[e] = p[1]; frag(4)[4 + e] = p[0];    // (w2 | w1) x (h1 | h3)
+                    frag(5)[e] = p[1]; frag(5)[4 + e] = p[2];    // (w2 | w3) x (h2 | h1)
+                }
+                uint16_t p[3];
+                split3(weight(gate, uo, 4 * 12 + g), p);
+                const int part[6] = {0, 0, 0, 1, 1, 2};          // against the B entries {h1, h2, h3, h1, h2, h1}
+                for (int e = 0; e < 6; ++e) frag(6)[e] = p[part[e]];
+            }
+        }
+    float* XC = reinterpret_cast<float*>(img.data() + L::OFF_XC);
+    float* WD = reinterpret_cast<float*>(img.data() + L::OFF_WD);
+    float* BD = reinterpret_cast<float*>(img.data() + L::OFF_BD);
+    for (int g = 0; g < 4; ++g)
+        for (int j = 0; j < L::NJ; ++j) {
+            const int u = 4 * j + g;
+            if (u >= H) continue;
+            for (int sgm = 0; sgm < 2; ++sgm) XC[((size_t)sgm * 4 + g) * L::XCP + j] = (float)(sc * (bci[u] + Wci[(size_t)sgm * H + u]));
+            WD[(size_t)g * L::XCP + j] = (float)(Wd[(size_t)u * 2 + 1] - Wd[(size_t)u * 2]);
+        }
+    BD[0] = (float)(bd[1] - bd[0]);
+    return img;
+}
+
 // Image of the 16x16x32 form of the flip pass at 69..100 units (split16_core.h: S16Layout).
 template <int NOUT>
 std::vector<char> pack_split16_image(const rnnwf_handle* h) {

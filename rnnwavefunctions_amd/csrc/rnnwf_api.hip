@@ -73,7 +73,7 @@ size_t rnnwf::state_budget_bytes(const rnnwf_handle* h, size_t dflt) {
 // The environment is consulted here and nowhere else: once per handle, at creation.
 static void read_knobs(Knobs& k) {
     if (const char* e = getenv("RNNWF_MDRNN_PREFETCH")) k.md_prefetch = !strcmp(e, "1");
-    if (const char* e = getenv("RNNWF_ENGINE")) k.engine = !strcmp(e, "f32") ? 1 : !strcmp(e, "bf16x3") ? 2 : !strcmp(e, "bf16x3-serial") ? 3 : !strcmp(e, "bf16x3-hipcc") ? 4 : !strcmp(e, "bf16x3-asm32") ? 5 : 0;
+    if (const char* e = getenv("RNNWF_ENGINE")) k.engine = !strcmp(e, "f32") ? 1 : !strcmp(e, "bf16x3") ? 2 : !strcmp(e, "bf16x3-serial") ? 3 : !strcmp(e, "bf16x3-hipcc") ? 4 : !strcmp(e, "bf16x3-asm32") ? 5 : !strcmp(e, "bf16x3-n16") ? 7 : 0;
     if (const char* e = getenv("RNNWF_NO_COOP")) k.no_coop = atoi(e) != 0;
     if (const char* e = getenv("RNNWF_BASE")) k.base_f32 = !strcmp(e, "f32");
     if (const char* e = getenv("RNNWF_STATE_BUDGET_MB")) {

@@ -143,6 +143,11 @@ struct CSLaunch {
 // widths served by the riders form (split_stream.hip): 53..100 units (53..68: RNNWF_ENGINE=bf16x3-serial selects the padded
 // serial kernel of round 1 instead, for A/B runs: 5.55 against 4.56 ms at N=80, 64 units, 10 000 samples)
 bool riders(const rnnwf_handle* h) { return h->NFULL == 6 || (h->NFULL == 4 && h->knobs.engine != 3); }
+// 37..52 units, positive RNN: RNNWF_ENGINE=bf16x3-n16 runs the flip pass in the 16x16x32 riders form (split_stream.hip:
+// prnn_flip_riders16n_asm_kernel) instead of the 32x32x16 ping-pong kernel - built and measured in round 3, 10 % slower
+bool riders16n(const rnnwf_handle* h) {
+    return h->NFULL == 3 && h->model != RNNWF_MODEL_CRNN_U1 && h->knobs.engine == 7;
+}
 
 }  // namespace
 
@@ -247,12 +252,14 @@ int rnnwf::crnn_base_coop_bf(rnnwf_handle* h, const CrnnArgs& a0) {
 int rnnwf::prnn_split_flip(rnnwf_handle* h, const PrnnArgs& a) {
     const int kt16 = 4 * h->NFULL + 1;
     if (riders(h)) return prnn_split_flip_stream(h, a, kt16);
+    if (riders16n(h)) return prnn_split_flip_16n(h, a, kt16);
     if (h->knobs.engine == 3) { SPLIT_DISPATCH(h, return K::flip(h, a, kt16)); }      // RNNWF_ENGINE=bf16x3-serial: A/B only
     else { SPLIT_DISPATCH(h, return K::flip_pp(h, a, kt16)); }
     return h->fail(RNNWF_ERR_INVALID, "no bf16x3 kernel for NFULL=%d", h->NFULL);
 }
 double rnnwf::prnn_split_flops_per_step(rnnwf_handle* h) {
     if (riders(h)) return prnn_split_stream_flops_per_step(h);
+    if (riders16n(h)) return prnn_split_16n_flops_per_step();
     SPLIT_DISPATCH(h, return K::mfma_flops_per_step());
     return 0;
 }
@@ -260,6 +267,9 @@ double rnnwf::prnn_split_flops_per_step(rnnwf_handle* h) {
 
 int rnnwf::prnn_split_pack(rnnwf_handle* h, std::vector<char>& simg) {
     if (riders(h)) return prnn_split_stream_pack(h, simg);
+    if (riders16n(h)) {
+        if (int rc = prnn_split_16n_pack(h)) return rc;
+    }
     SPLIT_DISPATCH(h, { simg = K::pack(h); return 0; });
     return h->fail(RNNWF_ERR_INVALID, "no bf16x3 layout for NFULL=%d", h->NFULL);
 }

@@ -45,4 +45,25 @@ struct S16Layout {
     static constexpr int tile_of(int b, int gate, int tau) { return 6 * b + 2 * gate + tau; }
 };
 
+// The same form at 37..52 units (13 units per lane group; tools/gen_riders16n_asm.py, split_riders16n_asm.h).  Tiles: t = 2 gate + tau
+// (tau = 0, 1): row 4 g + r <-> gate of unit 4 (4 tau + r) + g (j = 0..7); t = 6 + gate: unit 4 (8 + r) + g (j = 8..11); tile 9: row
+// 4 g + r, r < 3: gate r of unit 48 + g (j = 12), r = 3: the head row.  K-steps of a tile (10): the six products over the "octet"
+// j = 0..7 (fragments 0..2 = weight parts w1..w3 of the octet), three k-steps that carry TWO products each over j = 8..11 (K entries
+// 0..3 | 4..7 of a lane group: fragment 3 = (w1 | w1) against the state quad (h2 | h1), fragment 4 = (w2 | w1) against (h1 | h3),
+// fragment 5 = (w2 | w3) against (h2 | h1)), and the special k-step of j = 12 (fragment 6: {w1, w1, w1, w2, w2, w3} against
+// {h1, h2, h3, h1, h2, h1}).  10 tiles x 10 k-steps x 2 sets = 200 MFMAs per wave-step; 70 fragments of 1 KB + tables, all in LDS.
+template <int NOUT_ = 1>
+struct S16nLayout {
+    static constexpr int NOUT = NOUT_;
+    static constexpr int NJ = 13, NT = 10, NFR = 7, KS = 10, HP = 52;
+    static constexpr int XCP = 16;                          // padded row of the candidate-input table (64-byte rows)
+    static constexpr size_t OFF_A = 0;                                              // [NT][NFR][64] x 16 B
+    static constexpr size_t OFF_CI = (size_t)NT * NFR * 1024;                       // [2 sigma][NT][4 g][4 r] f32
+    static constexpr size_t OFF_XC = OFF_CI + (size_t)2 * NT * 4 * 16;              // [2 sigma][4 g][XCP] f32 (scaled)
+    static constexpr size_t OFF_WD = OFF_XC + (size_t)2 * 4 * XCP * 4;              // [4 g][XCP] f32 head weights (logit difference)
+    static constexpr size_t OFF_BD = OFF_WD + (size_t)4 * XCP * 4;                  // [4] f32
+    static constexpr size_t BYTES = OFF_BD + 16;
+    static_assert(BYTES <= 160 * 1024, "the image must fit LDS");
+};
+
 }  // namespace rnnwf

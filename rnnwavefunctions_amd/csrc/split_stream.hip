@@ -84,6 +84,30 @@ static_assert(R100::L::STREAM && R100::L::HP == 100 && R100::LC::STREAM, "layout
 static_assert(!R68::L::STREAM && R68::L::HP == 68 && !R68::LC::STREAM, "layout mode 3 at 68 units is LDS-resident");
 }  // namespace
 
+// ---- the 16x16x32 form at 37..52 units (split16_core.h: S16nLayout): the default flip pass of the positive RNN at these widths ----
+int rnnwf::prnn_split_flip_16n(rnnwf_handle* h, const PrnnArgs& a, int kt16) {
+    using L16 = S16nLayout<1>;
+    const void* fn = (const void*)prnn_flip_riders16n_asm_kernel<WAVES>;
+    if (kt16 != L16::NJ) return h->fail(RNNWF_ERR_INVALID, "the 16x16x32 form expects %d checkpoint k-steps, got %d", L16::NJ, kt16);
+    int bpc = 0;
+    if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, L16::BYTES, &bpc)) return rc;
+    const int64_t ntiles = (int64_t)(a.N - 1) * ((a.ns + 31) / 32);
+    const int64_t need = (ntiles + WAVES - 1) / WAVES;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)h->cu_count));       // one wave per SIMD
+    TimedLaunch tl(h, 1);
+    prnn_flip_riders16n_asm_kernel<WAVES><<<grid, WAVES * 64, L16::BYTES, h->stream>>>(a, h->wsplit16.p, kt16);
+    RNNWF_HIP(h, hipGetLastError());
+    return 0;
+}
+double rnnwf::prnn_split_16n_flops_per_step() { return (double)S16nLayout<1>::NT * S16nLayout<1>::KS * 2 * 16384.0; }
+int rnnwf::prnn_split_16n_pack(rnnwf_handle* h) {
+    const std::vector<char> img16 = pack_split16n_image<1>(h);
+    if (int rc = ensure(h, h->wsplit16, img16.size())) return rc;
+    RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+    RNNWF_HIP(h, hipMemcpy(h->wsplit16.p, img16.data(), img16.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
 int rnnwf::prnn_split_flip_stream(rnnwf_handle* h, const PrnnArgs& a, int kt16) {
     return h->NFULL == 6 ? R100::flip(h, a, kt16) : R68::flip(h, a, kt16);
 }
