@@ -530,10 +530,7 @@ def main():
         # the oracle as CHECKER of the timed path's own output (outside the timed region, like the cpu_baseline leg)
         rec["parity"] = parity_leg(args.workload, wl, wf, prm, couplings, last_step, offset, m) if world == 1 and not args.no_parity else None
         if args.train and world == 1:
-            # (rnnwf_vmc_gradient covers every model but the parity-symmetrised one, which the reference never trains:
-            #  1DTFIM/TrainingRNN_1DTFIM.py imports RNNwavefunction, not RNNwavefunction_paritysym)
-            rec["train"] = train_leg(wl, wf, prm, couplings, args.train, offset) if not wl.get("parity") else \
-                {"skipped": "rnnwf_vmc_gradient is not implemented for the parity-symmetrised model"}
+            rec["train"] = train_leg(wl, wf, prm, couplings, args.train, offset)
         if not args.no_cpu_baseline and world == 1 and wl["kind"] == "tfim1d" and wl.get("layers", 1) == 1 and not wl.get("parity"):
             rec["cpu_baseline"] = cpu_baseline(wl, prm)
         else:

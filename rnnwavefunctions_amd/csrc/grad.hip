@@ -398,8 +398,9 @@ extern "C" int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double me
     if (!h) return RNNWF_ERR_INVALID;
     if (!h->committed) return h->fail(RNNWF_ERR_STATE, "parameters not committed");
     if (h->model == RNNWF_MODEL_MDRNN2D) return mdrnn_vmc_gradient(h, mean_energy, norm);
-    if (h->model != RNNWF_MODEL_GRU1D && h->model != RNNWF_MODEL_CRNN_U1 && h->model != RNNWF_MODEL_GRU1D_F64)
-        return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: not implemented for the parity-symmetrised GRU RNN");
+    const bool parity = h->model == RNNWF_MODEL_GRU1D_PARITY;
+    if (parity && h->NL != 1)
+        return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: not implemented for the parity-symmetrised GRU RNN with stacked layers");
     if (h->NL != 1) {
         if (h->model != RNNWF_MODEL_GRU1D && h->model != RNNWF_MODEL_CRNN_U1 && h->model != RNNWF_MODEL_GRU1D_F64)
             return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: not implemented for the parity-symmetrised GRU RNN");
@@ -449,6 +450,24 @@ extern "C" int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double me
     a.P = h->gradP.p;
     a.Q = h->gradQ.p;
     a.head_grad = (char*)h->gradW.p + (size_t)pcols * qcols * es;
+    if (parity) {
+        // log P_sym = log(0.5 (P_F + P_R)) (1DTFIM/RNNwavefunction_paritysym.py:145): the gradient is the sum of the two directions'
+        // gradients, each sample weighted by the direction's share of P_sym.  The step left the checkpoints of ONE direction: both
+        // are redone here, teacher-forced, with the shares from the same two passes.
+        if (int rc = ensure(h, h->out_lp, (size_t)ns * 8)) return rc;
+        if (int rc = ensure(h, h->out_lp2, (size_t)ns * 8)) return rc;
+        double* lpF = (double*)h->out_lp.p;
+        double* lpR = (double*)h->out_lp2.p;
+        if (int rc = prnn_teacher_base(h, ns, false, lpF)) return rc;
+        if (int rc = prnn_teacher_base(h, ns, true, lpR)) return rc;              // the reversed chains' states are resident now
+        if (int rc = run_parity_share(h, lpF, lpR, ns)) return rc;
+        a.bits = (const uint32_t*)h->bits2.p;
+        a.wfac = lpR;
+        GRAD_DISPATCH(h, { if (int rc = K::run(h, a, R, h->gradW.p)) return rc; break; });
+        if (int rc = prnn_teacher_base(h, ns, false, nullptr)) return rc;
+        a.bits = (const uint32_t*)h->bits.p;
+        a.wfac = lpF;
+    }
     GRAD_DISPATCH(h, { if (int rc = K::run(h, a, R, h->gradW.p)) return rc; break; });
     std::vector<char> host(dw_floats * es);
     RNNWF_HIP(h, hipMemcpyAsync(host.data(), h->gradW.p, dw_floats * es, hipMemcpyDeviceToHost, h->stream));

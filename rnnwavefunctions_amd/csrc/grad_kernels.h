@@ -48,6 +48,7 @@ struct GradArgs {
     const double* eloc;        // [ns] f64 (positive RNN) ...
     const float2* eloc_c;      // ... or [ns] complex64 (complex RNN)
     double mean_e, mean_im, inv_norm;   // w_s = (E_s - mean) * inv_norm  (real and imaginary part separately)
+    const double* wfac;        // [ns] extra factor of w_s or nullptr (parity-symmetric model: the direction's share of P_sym)
     void* P;                   // [N*ns][PCOLS] T
     void* Q;                   // [N*ns][QCOLS] T
     void* head_grad;           // [NOUT][HEAD_ROW] T, zeroed before the launch (written by head_reduce_kernel)
@@ -146,7 +147,7 @@ __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
         T w = T(0), w_im = T(0);
         if (valid) {
             if constexpr (NOUT == 1) {
-                w = (T)((a.eloc[sc] - a.mean_e) * a.inv_norm);
+                w = (T)((a.eloc[sc] - a.mean_e) * a.inv_norm * (a.wfac ? a.wfac[sc] : 1.0));
             } else {
                 const float2 e = a.eloc_c[sc];
                 w = (T)(((double)e.x - a.mean_e) * a.inv_norm);

@@ -18,6 +18,7 @@ int run_moments(rnnwf_handle* h, const void* eloc_dev, int64_t ns, bool complex_
 int run_tfim_eloc(rnnwf_handle* h, const uint32_t* bits, const double* lpq, int64_t ns, int Nx, int Ny,
                   const int32_t* pos_of_site_dev, const double* Jz_dev, double Bx, double* eloc_dev);
 int run_parity_combine(rnnwf_handle* h, const double* a, const double* b, int64_t n, double* out);
+int run_parity_share(rnnwf_handle* h, double* lpF, double* lpR, int64_t n);      // in place: P_F / (P_F + P_R), P_R / (P_F + P_R)
 
 // ---- weight image ---------------------------------------------------------------------------------
 int model_pack_image(rnnwf_handle* h, std::vector<char>& img);  // dispatches to the family below
@@ -59,6 +60,7 @@ int prnn_split_pack(rnnwf_handle* h, std::vector<char>& simg);
 int prnn_split_flip_stream(rnnwf_handle* h, const PrnnArgs& a, int kt16);
 double prnn_split_stream_flops_per_step(rnnwf_handle* h);
 int prnn_split_stream_pack(rnnwf_handle* h, std::vector<char>& simg);
+int prnn_teacher_base(rnnwf_handle* h, int64_t ns, bool reversed, double* out_lp);   // prnn.hip
 // the 16x16x32 form at 37..52 units (split_stream.hip; image in h->wsplit16)
 int prnn_split_flip_16n(rnnwf_handle* h, const PrnnArgs& a, int kt16);
 double prnn_split_16n_flops_per_step();

@@ -273,6 +273,16 @@ int64_t max_chains_per_pass(rnnwf_handle* h) {
 
 }  // namespace
 
+// Teacher-forced base pass with checkpoints over the resident spins (h->bits, or the reversed ones in h->bits2), log P of every
+// chain to out_lp: what a backward pass of the parity-symmetric model needs per direction (grad.hip).
+int rnnwf::prnn_teacher_base(rnnwf_handle* h, int64_t ns, bool reversed, double* out_lp) {
+    PrnnArgs a = base_args(h, ns);
+    a.bits = (uint32_t*)(reversed ? h->bits2.p : h->bits.p);
+    a.hck = h->hck.p;
+    a.out_lp = out_lp;
+    return launch_base(h, a);
+}
+
 int rnnwf::prnn_pack_image(rnnwf_handle* h, std::vector<char>& img) {
     // flip-pass engine: bf16x3 on the matrix core for the f32 models (RNNWF_ENGINE=f32 keeps the f32-input MFMA
     // everywhere; above 68 units the w3 fragments of the image are read through L2, split_stream.hip); the base pass, sampling and log_probability always run the f32-MFMA kernels

@@ -412,6 +412,11 @@ int rnnwf::run_parity_combine(rnnwf_handle* h, const double* a, const double* b,
     RNNWF_HIP(h, hipGetLastError());
     return 0;
 }
+int rnnwf::run_parity_share(rnnwf_handle* h, double* lpF, double* lpR, int64_t n) {
+    parity_share_kernel<<<(unsigned)((n + 255) / 256), 256, 0, h->stream>>>(lpF, lpR, n);
+    RNNWF_HIP(h, hipGetLastError());
+    return 0;
+}
 
 int rnnwf::model_pack_image(rnnwf_handle* h, std::vector<char>& img) {
     if (h->model == RNNWF_MODEL_MDRNN2D) return mdrnn_pack_image(h, img);

@@ -115,4 +115,14 @@ __global__ void parity_combine_kernel(const double* __restrict__ a, const double
     if (i < n) out[i] = log(0.5 * (exp(a[i]) + exp(b[i])));
 }
 
+// Parity-symmetric model, gradient: log P_sym = log(0.5 (P_F + P_R)) gives  d log P_sym = aF d log P_F + aR d log P_R  with the shares
+// aF = P_F / (P_F + P_R), aR = 1 - aF.  In place: lpF <- aF, lpR <- aR.
+__global__ void parity_share_kernel(double* __restrict__ lpF, double* __restrict__ lpR, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double aF = 1.0 / (1.0 + exp(lpR[i] - lpF[i]));
+    lpF[i] = aF;
+    lpR[i] = 1.0 - aF;
+}
+
 }  // namespace rnnwf

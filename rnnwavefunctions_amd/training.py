@@ -197,19 +197,24 @@ def _restore(save_dir, tag_mean, tag_var, tag_model, params, opt, scope):
 
 
 def run_1DTFIM(numsteps=10 ** 4, systemsize=20, num_units=50, Bx=1, num_layers=1, numsamples=500, learningrate=5e-3,
-               seed=111, save_dir=None, device=None, verbose=True, comm=None, restore=False):
+               seed=111, save_dir=None, device=None, verbose=True, comm=None, restore=False, parity_symmetric=False):
     """Train the 1D pRNN wave function on the open transverse-field Ising chain; returns (meanEnergy, varEnergy)
     lists with one entry per iteration, as the reference's run_1DTFIM.  `comm` (distributed.ShardComm, or "env" under
     torch.distributed.run) shards the batch over one process per GPU; `save_dir` turns on the reference's saving
-    (energies every 10 steps, TF checkpoint every 500), `restore=True` its restore branch (:172-183)."""
+    (energies every 10 steps, TF checkpoint every 500), `restore=True` its restore branch (:172-183).
+    `parity_symmetric=True` is the reference's import switch to RNNwavefunction_paritysym (1DTFIM/TrainingRNN_1DTFIM.py:10):
+    P_sym(s) = (P(s) + P(reversed s)) / 2, one layer."""
     if not 1 <= num_layers <= 3:
         raise ValueError("num_layers must be 1..3 (stacked layers: num_units <= 52)")
+    if parity_symmetric and num_layers != 1:
+        raise ValueError("the parity-symmetric model trains with one layer")
     N = systemsize
     scope = "RNNwavefunction"
     Jz = +np.ones(N)
     units = [num_units] * num_layers
     params = P.init_gru_params(units, seed=seed, scope=scope)
-    wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D, N, 1, tuple(units), device=_resolve_device(device, comm))
+    wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D_PARITY if parity_symmetric else _lib.MODEL_GRU1D, N, 1, tuple(units),
+                                 device=_resolve_device(device, comm))
     wf.set_params(params, scope=scope)
     comm = _resolve_comm(comm, wf)
     if verbose and (comm is None or comm.rank == 0):

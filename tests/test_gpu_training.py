@@ -48,6 +48,44 @@ def test_gradient_matches_finite_differences_of_the_oracle(N, H, ns):
     assert worst < 2e-3
 
 
+@pytest.mark.parametrize("N,H,ns", [(6, 6, 64), (9, 20, 48), (8, 50, 40), (5, 100, 24), (1, 10, 6)])
+def test_parity_symmetric_gradient_matches_finite_differences_of_the_oracle(N, H, ns):
+    """The reference's one-line switch to RNNwavefunction_paritysym (1DTFIM/TrainingRNN_1DTFIM.py:10) trains
+    log P_sym = log(0.5 (P(s) + P(reversed s))) (RNNwavefunction_paritysym.py:145): two backward passes, each sample weighted by
+    the direction's share of P_sym."""
+    from rnnwavefunctions_amd import _lib
+    from rnnwavefunctions_amd.training import cost_gradient
+    prm = P.randomize_biases(P.scale_kernels(P.init_gru_params([H], seed=H + 3), 1.5), H + 1)
+    wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D_PARITY, N, 1, (H,))
+    wf.set_params(prm, scope=SCOPE)
+    out = wf.vmc_step(ns, seed=3, step=0, couplings=np.append(np.ones(N), 1.0), want_samples=True, want_eloc=True)
+    s, e = out["samples"], out["eloc"]
+    grads = cost_gradient(wf, prm, SCOPE, e.mean(), ns)
+    assert set(grads) == set(prm)
+    prm64 = {k: v.astype(np.float64) for k, v in prm.items()}
+
+    def cost():
+        lp = M.prnn_paritysym_log_probability(prm64, s, dtype=np.float64)
+        return np.mean(lp * e) - np.mean(e) * np.mean(lp)
+
+    worst = _fd_check(grads, prm64, cost)
+    print("parity N=%d H=%d: max |grad - FD| / max|grad| = %.2e" % (N, H, worst))
+    assert worst < 2e-3
+    again = cost_gradient(wf, prm, SCOPE, e.mean(), ns)
+    assert all(np.array_equal(grads[k], again[k]) for k in grads)
+
+
+def test_run_1dtfim_with_the_parity_symmetric_model_reaches_the_ground_state():
+    from rnnwavefunctions_amd.training import run_1DTFIM
+    meanE, varE = run_1DTFIM(numsteps=500, systemsize=10, num_units=10, Bx=1, numsamples=200, learningrate=5e-3, seed=111,
+                             verbose=False, parity_symmetric=True)
+    ed = -12.38148999965476
+    final = np.mean(meanE[-50:])
+    print("run_1DTFIM parity-symmetric N=10: mean of last 50 steps = %.5f (ED %.5f), var %.4f" % (final, ed, np.mean(varE[-50:])))
+    assert final > ed - 0.02 and abs(final - ed) < 0.04
+    assert np.mean(varE[-50:]) < 0.5 * varE[0]
+
+
 def test_gradient_needs_a_resident_batch():
     from rnnwavefunctions_amd import _lib
     prm = P.init_gru_params([10], seed=1)
