@@ -161,7 +161,7 @@ int rnnwf_vmc_step(rnnwf_handle* h, int64_t numsamples, uint64_t seed, uint64_t 
                    const double* couplings, int64_t n_couplings, int32_t* out_samples, void* out_eloc,
                    double* moments);
 
-/* ---- gradient of the VMC cost (models GRU1D, CRNN_U1 (f32), GRU1D_F64, MDRNN2D (f64)) ----
+/* ---- gradient of the VMC cost (models GRU1D, GRU1D_PARITY, CRNN_U1 (f32), GRU1D_F64, MDRNN2D (f64)) ----
  * rnnwf_vmc_gradient <- optimizer.compute_gradients(cost) with
  *   cost = mean(log_probs * Eloc) - mean(Eloc) * mean(log_probs)      (1DTFIM/TrainingRNN_1DTFIM.py:151-162)
  *   evaluated on the batch of the LAST rnnwf_vmc_step (its samples, per-site hidden states and E_loc are still
@@ -173,7 +173,10 @@ int rnnwf_vmc_step(rnnwf_handle* h, int64_t numsamples, uint64_t seed, uint64_t 
  *   (Im E_s - mean_energy_im) d Im log psi]; mean_energy_im is ignored for the positive RNNs.
  *   The 2D drivers (2DTFIM_2DRNN/Training2DRNN_2DTFIM.py:163, 2DTFIM_1DRNN/Training1DRNN_2DTFIM.py:160) use the
  *   first cost in float64.  Every width rnnwf_create accepts (above 68 / 52 units the backward operand is read through
- *   L2 instead of LDS).  Stacked layers (len(units) 2..3, every GRU model): one backward pass per layer, top first.
+ *   L2 instead of LDS).  Stacked layers (len(units) 2..3, every GRU model but the parity-symmetric one): one backward pass per
+ *   layer, top first.  GRU1D_PARITY (one layer; the import switch of 1DTFIM/TrainingRNN_1DTFIM.py:10): log P_sym =
+ *   log(0.5 (P(s) + P(reversed s))), two backward passes weighted by each direction's share of P_sym.
+ *   Every reduction has a fixed order: the same batch gives the same bits.
  * rnnwf_get_grad     <- the gradient of one TF variable (same names and shapes as rnnwf_set_param).
  * rnnwf_allreduce_grads: one RCCL all-reduce (sum) over all gradient arrays of the handle.             */
 int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double mean_energy_im, double norm);
