@@ -173,8 +173,8 @@ int rnnwf_vmc_step(rnnwf_handle* h, int64_t numsamples, uint64_t seed, uint64_t 
  *   (Im E_s - mean_energy_im) d Im log psi]; mean_energy_im is ignored for the positive RNNs.
  *   The 2D drivers (2DTFIM_2DRNN/Training2DRNN_2DTFIM.py:163, 2DTFIM_1DRNN/Training1DRNN_2DTFIM.py:160) use the
  *   first cost in float64.  Every width rnnwf_create accepts (above 68 / 52 units the backward operand is read through
- *   L2 instead of LDS).  Stacked layers (len(units) 2..3, every GRU model but the parity-symmetric one): one backward pass per
- *   layer, top first.  GRU1D_PARITY (one layer; the import switch of 1DTFIM/TrainingRNN_1DTFIM.py:10): log P_sym =
+ *   L2 instead of LDS).  Stacked layers (len(units) 2..3, every GRU model): one backward pass per
+ *   layer, top first.  GRU1D_PARITY (the import switch of 1DTFIM/TrainingRNN_1DTFIM.py:10): log P_sym =
  *   log(0.5 (P(s) + P(reversed s))), two backward passes weighted by each direction's share of P_sym.
  *   Every reduction has a fixed order: the same batch gives the same bits.
  * rnnwf_get_grad     <- the gradient of one TF variable (same names and shapes as rnnwf_set_param).

@@ -261,6 +261,7 @@ struct MLGrad {
         const int N = h->N;
         const int64_t ns = h->last_ns, R = ns * N, nsb = (ns + kChains - 1) / kChains;
         const double inv_norm = (NOUT == 3 ? 2.0 : 1.0) / norm;     // the complex cost carries a factor 2 (TrainingRNN_J1J2.py:197)
+        const bool parity = h->model == RNNWF_MODEL_GRU1D_PARITY;
         if (!h->wbwd.p) {
             const std::vector<char> img = pack_all(h);
             if (int rc = ensure(h, h->wbwd, img.size())) return rc;
@@ -273,6 +274,36 @@ struct MLGrad {
         const size_t dx_bytes = (size_t)N * nsb * L0::KT * 64 * ES;
         for (int i = 0; i < (NL > 2 ? 2 : 1); ++i) if (int rc = ensure(h, h->gradDX[i], dx_bytes)) return rc;
         RNNWF_HIP(h, hipMemsetAsync(h->gradW.p, 0, (DW_FLOATS + HEAD) * ES, h->stream));
+        if (parity) {
+            // log P_sym = log(0.5 (P_F + P_R)): both directions, teacher-forced, each sample weighted by the direction's share of
+            // P_sym (the single-layer case in rnnwf_vmc_gradient below explains the sequence)
+            if constexpr (NOUT == 1 && sizeof(T) == 4) {
+                if (int rc = ensure(h, h->out_lp, (size_t)ns * 8)) return rc;
+                if (int rc = ensure(h, h->out_lp2, (size_t)ns * 8)) return rc;
+                double* lpF = (double*)h->out_lp.p;
+                double* lpR = (double*)h->out_lp2.p;
+                if (int rc = prnn_teacher_base(h, ns, false, lpF)) return rc;
+                if (int rc = prnn_teacher_base(h, ns, true, lpR)) return rc;
+                if (int rc = run_parity_share(h, lpF, lpR, ns)) return rc;
+                if (int rc = passes(h, mean_energy, mean_energy_im, inv_norm, (const uint32_t*)h->bits2.p, lpR)) return rc;
+                if (int rc = prnn_teacher_base(h, ns, false, nullptr)) return rc;
+                if (int rc = passes(h, mean_energy, mean_energy_im, inv_norm, (const uint32_t*)h->bits.p, lpF)) return rc;
+            }
+        } else {
+            if (int rc = passes(h, mean_energy, mean_energy_im, inv_norm, (const uint32_t*)h->bits.p, nullptr)) return rc;
+        }
+        std::vector<T> host(DW_FLOATS);
+        RNNWF_HIP(h, hipMemcpyAsync(host.data(), h->gradW.p, DW_FLOATS * ES, hipMemcpyDeviceToHost, h->stream));
+        RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+        G0::unpack(h, host.data(), DW0);                       // layer 0 + head (written by the top layer's pass)
+        for (int l = 1; l < NL; ++l) unpack_upper(h, host.data() + DW0 + HEAD + (size_t)(l - 1) * DWU, l);
+        return RNNWF_OK;
+    }
+
+    // one backward pass per layer, top first, over the resident checkpoints of the chains in `bits`; everything is ADDED to gradW
+    static int passes(rnnwf_handle* h, double mean_energy, double mean_energy_im, double inv_norm, const uint32_t* bits, const double* wfac) {
+        const int N = h->N;
+        const int64_t ns = h->last_ns, R = ns * N, nsb = (ns + kChains - 1) / kChains;
         T* dW = (T*)h->gradW.p;
         const char* bwd = (const char*)h->wbwd.p;
         const void* dh_in = nullptr;
@@ -283,7 +314,8 @@ struct MLGrad {
             a.whead = (const char*)h->wimg.p + L0::OFF_WD;
             a.N = N; a.layer = l; a.hck_nl = NL;
             a.ns = ns; a.nsb = nsb;
-            a.bits = (const uint32_t*)h->bits.p;
+            a.bits = bits;
+            a.wfac = wfac;
             a.hck = h->hck.p;
             a.eloc = (const double*)h->eloc.p;
             a.eloc_c = (const float2*)h->eloc.p;
@@ -304,7 +336,7 @@ struct MLGrad {
         a.wimg = h->wimg.p;
         a.wbwd = h->wbwd.p;
         a.N = N; a.ns = ns; a.nsb = nsb;
-        a.bits = (const uint32_t*)h->bits.p;
+        a.bits = bits;
         a.hck = h->hck.p;
         a.eloc = (const double*)h->eloc.p;
         a.eloc_c = (const float2*)h->eloc.p;
@@ -316,13 +348,7 @@ struct MLGrad {
         a.head_grad = dW + DW_FLOATS;          // scratch rows: layer 0 has no head term here (its adds are zeros)
         a.dh_in = dh_in;
         a.hck_nl = NL;
-        if (int rc = G0::run(h, a, R, dW)) return rc;
-        std::vector<T> host(DW_FLOATS);
-        RNNWF_HIP(h, hipMemcpyAsync(host.data(), h->gradW.p, DW_FLOATS * ES, hipMemcpyDeviceToHost, h->stream));
-        RNNWF_HIP(h, hipStreamSynchronize(h->stream));
-        G0::unpack(h, host.data(), DW0);                       // layer 0 + head (written by the top layer's pass)
-        for (int l = 1; l < NL; ++l) unpack_upper(h, host.data() + DW0 + HEAD + (size_t)(l - 1) * DWU, l);
-        return RNNWF_OK;
+        return G0::run(h, a, R, dW);
     }
 
     static void unpack_upper(rnnwf_handle* h, const T* dW, int layer) {
@@ -399,11 +425,7 @@ extern "C" int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double me
     if (!h->committed) return h->fail(RNNWF_ERR_STATE, "parameters not committed");
     if (h->model == RNNWF_MODEL_MDRNN2D) return mdrnn_vmc_gradient(h, mean_energy, norm);
     const bool parity = h->model == RNNWF_MODEL_GRU1D_PARITY;
-    if (parity && h->NL != 1)
-        return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: not implemented for the parity-symmetrised GRU RNN with stacked layers");
     if (h->NL != 1) {
-        if (h->model != RNNWF_MODEL_GRU1D && h->model != RNNWF_MODEL_CRNN_U1 && h->model != RNNWF_MODEL_GRU1D_F64)
-            return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: not implemented for the parity-symmetrised GRU RNN");
         if (h->last_ns <= 0 || !h->last_has_ckpt)
             return h->fail(RNNWF_ERR_STATE, "rnnwf_vmc_gradient: call rnnwf_vmc_step first (its samples, states and E_loc are reused)");
         if (!(norm > 0)) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: norm must be positive");

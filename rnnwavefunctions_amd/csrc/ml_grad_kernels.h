@@ -41,6 +41,7 @@ struct UpperGradArgs {
     const double* eloc;        // [ns] f64 (positive RNN) ...
     const float2* eloc_c;      // ... or [ns] complex64 (complex RNN)
     double mean_e, mean_im, inv_norm;
+    const double* wfac;        // [ns] extra factor of w_s or nullptr (parity-symmetric model: the direction's share of P_sym)
     const void* dh_in;         // [N][nsb][KT][64] T from the layer above (nullptr: top layer, head)
     void* dx_out;              // [N][nsb][KT][64] T
     void* P;
@@ -93,7 +94,7 @@ __global__ void __launch_bounds__(WAVES * 64) gru_upper_bwd_kernel(UpperGradArgs
         T w = T(0), w_im = T(0);
         if (TOP && valid) {
             if constexpr (NOUT == 1) {
-                w = (T)((a.eloc[sc] - a.mean_e) * a.inv_norm);
+                w = (T)((a.eloc[sc] - a.mean_e) * a.inv_norm * (a.wfac ? a.wfac[sc] : 1.0));
             } else {
                 const float2 e = a.eloc_c[sc];
                 w = (T)(((double)e.x - a.mean_e) * a.inv_norm);

@@ -203,11 +203,9 @@ def run_1DTFIM(numsteps=10 ** 4, systemsize=20, num_units=50, Bx=1, num_layers=1
     torch.distributed.run) shards the batch over one process per GPU; `save_dir` turns on the reference's saving
     (energies every 10 steps, TF checkpoint every 500), `restore=True` its restore branch (:172-183).
     `parity_symmetric=True` is the reference's import switch to RNNwavefunction_paritysym (1DTFIM/TrainingRNN_1DTFIM.py:10):
-    P_sym(s) = (P(s) + P(reversed s)) / 2, one layer."""
+    P_sym(s) = (P(s) + P(reversed s)) / 2."""
     if not 1 <= num_layers <= 3:
         raise ValueError("num_layers must be 1..3 (stacked layers: num_units <= 52)")
-    if parity_symmetric and num_layers != 1:
-        raise ValueError("the parity-symmetric model trains with one layer")
     N = systemsize
     scope = "RNNwavefunction"
     Jz = +np.ones(N)

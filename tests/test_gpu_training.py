@@ -48,15 +48,15 @@ def test_gradient_matches_finite_differences_of_the_oracle(N, H, ns):
     assert worst < 2e-3
 
 
-@pytest.mark.parametrize("N,H,ns", [(6, 6, 64), (9, 20, 48), (8, 50, 40), (5, 100, 24), (1, 10, 6)])
-def test_parity_symmetric_gradient_matches_finite_differences_of_the_oracle(N, H, ns):
+@pytest.mark.parametrize("N,H,ns,L", [(6, 6, 64, 1), (9, 20, 48, 1), (8, 50, 40, 1), (5, 100, 24, 1), (1, 10, 6, 1), (7, 20, 40, 2), (6, 10, 48, 3)])
+def test_parity_symmetric_gradient_matches_finite_differences_of_the_oracle(N, H, ns, L):
     """The reference's one-line switch to RNNwavefunction_paritysym (1DTFIM/TrainingRNN_1DTFIM.py:10) trains
     log P_sym = log(0.5 (P(s) + P(reversed s))) (RNNwavefunction_paritysym.py:145): two backward passes, each sample weighted by
     the direction's share of P_sym."""
     from rnnwavefunctions_amd import _lib
     from rnnwavefunctions_amd.training import cost_gradient
-    prm = P.randomize_biases(P.scale_kernels(P.init_gru_params([H], seed=H + 3), 1.5), H + 1)
-    wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D_PARITY, N, 1, (H,))
+    prm = P.randomize_biases(P.scale_kernels(P.init_gru_params([H] * L, seed=H + 3), 1.5), H + 1)
+    wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D_PARITY, N, 1, (H,) * L)
     wf.set_params(prm, scope=SCOPE)
     out = wf.vmc_step(ns, seed=3, step=0, couplings=np.append(np.ones(N), 1.0), want_samples=True, want_eloc=True)
     s, e = out["samples"], out["eloc"]
@@ -69,7 +69,7 @@ def test_parity_symmetric_gradient_matches_finite_differences_of_the_oracle(N, H
         return np.mean(lp * e) - np.mean(e) * np.mean(lp)
 
     worst = _fd_check(grads, prm64, cost)
-    print("parity N=%d H=%d: max |grad - FD| / max|grad| = %.2e" % (N, H, worst))
+    print("parity N=%d H=%d L=%d: max |grad - FD| / max|grad| = %.2e" % (N, H, L, worst))
     assert worst < 2e-3
     again = cost_gradient(wf, prm, SCOPE, e.mean(), ns)
     assert all(np.array_equal(grads[k], again[k]) for k in grads)
