@@ -107,6 +107,8 @@ struct CMLaunch {
                 case 1: { using K = CMLaunch<1, 2, 4>; EXPR; }  \
                 case 2: { using K = CMLaunch<2, 2, 4>; EXPR; }  \
                 case 3: { using K = CMLaunch<3, 2, 8>; EXPR; }  \
+                case 4: { using K = CMLaunch<4, 2, 4>; EXPR; }  \
+                case 6: { using K = CMLaunch<6, 2, 4>; EXPR; }  \
             }                                                   \
             break;                                              \
         }                                                       \
@@ -115,6 +117,8 @@ struct CMLaunch {
                 case 1: { using K = CMLaunch<1, 3, 4>; EXPR; }  \
                 case 2: { using K = CMLaunch<2, 3, 8>; EXPR; }  \
                 case 3: { using K = CMLaunch<3, 3, 8>; EXPR; }  \
+                case 4: { using K = CMLaunch<4, 3, 4>; EXPR; }  \
+                case 6: { using K = CMLaunch<6, 3, 4>; EXPR; }  \
             }                                                   \
             break;                                              \
         }                                                       \

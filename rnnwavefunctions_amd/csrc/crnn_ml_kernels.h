@@ -32,7 +32,7 @@ struct CrnnMlCore {
         for (int l = 1; l < NL; ++l) {
             const size_t off = C0::L::BYTES + (size_t)(l - 1) * CU::U::BYTES;
             if (l < NL - SPILL) CU::step(lds + off, h[l - 1], h[l], lane);
-            else CU::step(reinterpret_cast<const char*>(wimg) + off, h[l - 1], h[l], lane);
+            else CU::step(reinterpret_cast<const char*>(wimg) + off, h[l - 1], h[l], lane, NFULL >= 4);      // wide layers: bounded look-ahead
         }
         C0::head(lds, h[NL - 1], lane, z);
     }

@@ -231,7 +231,7 @@ struct MLGrad {
     template <bool TOP>
     static int upper_pass(rnnwf_handle* h, UpperGradArgs a) {
         const void* fn = (const void*)gru_upper_bwd_kernel<T, NFULL, WAVES, TOP, NOUT>;
-        const size_t lds = U::BYTES + GU::BWD_BYTES + (TOP ? GU::HEAD_BYTES : 0);
+        const size_t lds = GU::WIDE ? GU::HEAD_BYTES : U::BYTES + GU::BWD_BYTES + (TOP ? GU::HEAD_BYTES : 0);
         if (lds > 160 * 1024) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: stacked-layer images (%zu B) exceed the 160 KB LDS", lds);
         int bpc = 0;
         if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, lds, &bpc)) return rc;
@@ -398,12 +398,16 @@ struct MLGrad {
                 case 1: { using K = MLGrad<1, 2, 4, NOUT>; EXPR; }      \
                 case 2: { using K = MLGrad<2, 2, 4, NOUT>; EXPR; }      \
                 case 3: { using K = MLGrad<3, 2, 4, NOUT>; EXPR; }      \
+                case 4: { using K = MLGrad<4, 2, 4, NOUT>; EXPR; }      \
+                case 6: { using K = MLGrad<6, 2, 4, NOUT>; EXPR; }      \
             }                                                           \
         } else if ((h)->NL == 3) {                                      \
             switch ((h)->NFULL) {                                       \
                 case 1: { using K = MLGrad<1, 3, 4, NOUT>; EXPR; }      \
                 case 2: { using K = MLGrad<2, 3, 4, NOUT>; EXPR; }      \
                 case 3: { using K = MLGrad<3, 3, 4, NOUT>; EXPR; }      \
+                case 4: { using K = MLGrad<4, 3, 4, NOUT>; EXPR; }      \
+                case 6: { using K = MLGrad<6, 3, 4, NOUT>; EXPR; }      \
             }                                                           \
         }                                                               \
     } while (0)

@@ -275,13 +275,62 @@ struct UpperCore {
     using VA = typename F::VA;
     static constexpr int KT = U::KT, NT = U::NT, NT2 = U::NT2, NG = U::NG, VW = U::VW;
 
+    // `streamed` (a compile-time constant at every call site: forced inlining folds the branch): the image is in global memory
+    // (layout.h: MlSpill), its fragments are requested two groups of five tiles ahead of their MFMAs - and no further: left alone,
+    // hipcc issues every load of the block up front and spills hundreds of registers.
     template <bool XBLOCK>
-    static __device__ __forceinline__ void block(const char* lds, const T (&v)[KT], V4 (&acc)[NT2], int lane) {
+    static __device__ __forceinline__ void block(const char* lds, const T (&v)[KT], V4 (&acc)[NT2], int lane, const bool streamed = false) {
         const VA* av = reinterpret_cast<const VA*>(lds + (XBLOCK ? U::OFF_AX : U::OFF_AH)) + lane;
         const T* ar = reinterpret_cast<const T*>(lds + (XBLOCK ? U::OFF_AXR : U::OFF_AHR)) + lane;
         // block tile t -> accumulator tile: r, u unchanged; third group -> y (X block) or q (H block); mixed last
         auto dst = [](int t) { return t < 2 * NFULL ? t : t < 3 * NFULL ? (XBLOCK ? t + NFULL : t) : NT2 - 1; };
         constexpr int TC = 5;
+        if (streamed) {
+            // buffer loads: one resource descriptor for the block's fragments, the lane's slot as the VGPR offset, the fragment's
+            // position as the scalar offset - with flat loads hipcc keeps one loop-invariant 64-bit address per 4 KB window
+            // (hundreds of registers at 100 units) and spills them
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(lds + (XBLOCK ? U::OFF_AX : U::OFF_AH)), 0, (int)(U::SZ_AVEC + U::SZ_AREM), 0x00020000);
+            constexpr int NTG = (NT + TC - 1) / TC, NGR = NG * NTG, AHEAD = 2;
+            VA ring[AHEAD + 1][TC];
+            auto request = [&](int k, VA (&dstv)[TC]) {
+                const int g = k / NTG, t0 = (k % NTG) * TC;
+#pragma unroll
+                for (int t = 0; t < TC; ++t)
+                    if (t0 + t < NT) {
+                        const u32x4_t w = __builtin_amdgcn_raw_buffer_load_b128(rv, lane * 16, ((t0 + t) * NG + g) * 64 * 16, 0);
+                        dstv[t] = __builtin_bit_cast(VA, w);
+                    }
+            };
+#pragma unroll
+            for (int k = 0; k < AHEAD && k < NGR; ++k) request(k, ring[k]);
+#pragma unroll
+            for (int k = 0; k < NGR; ++k) {
+                if (k + AHEAD < NGR) request(k + AHEAD, ring[(k + AHEAD) % (AHEAD + 1)]);
+                asm volatile("" ::: "memory");
+                const int g = k / NTG, t0 = (k % NTG) * TC;
+#pragma unroll
+                for (int j = 0; j < VW; ++j)
+#pragma unroll
+                    for (int t = 0; t < TC; ++t)
+                        if (t0 + t < NT) acc[dst(t0 + t)] = F::mfma(ring[k % (AHEAD + 1)][t][j], v[g * VW + j], acc[dst(t0 + t)]);
+            }
+            // the kt = KT - 1 column: [NT][64] T right behind the vectors (OFF_AXR = OFF_AX + SZ_AVEC, likewise for the H block)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                T a;
+                if constexpr (sizeof(T) == 4) {
+                    a = __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(rv, lane * 4, (int)U::SZ_AVEC + t * 64 * 4, 0));
+                } else {
+                    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                    const u32x2_t w = __builtin_amdgcn_raw_buffer_load_b64(rv, lane * 8, (int)U::SZ_AVEC + t * 64 * 8, 0);
+                    a = __builtin_bit_cast(T, w);
+                }
+                acc[dst(t)] = F::mfma(a, v[KT - 1], acc[dst(t)]);
+            }
+            return;
+        }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
 #pragma unroll
@@ -301,7 +350,8 @@ struct UpperCore {
         for (int t = 0; t < NT; ++t) acc[dst(t)] = F::mfma(ar[t * 64], v[KT - 1], acc[dst(t)]);
     }
 
-    static __device__ __forceinline__ void products(const char* lds, const T (&x)[KT], const T (&h)[KT], V4 (&acc)[NT2], int lane) {
+    static __device__ __forceinline__ void products(const char* lds, const T (&x)[KT], const T (&h)[KT], V4 (&acc)[NT2], int lane,
+                                                    const bool streamed = false) {
         const int q = lane >> 4;
         asm volatile("" ::: "memory");
         {
@@ -309,17 +359,17 @@ struct UpperCore {
 #pragma unroll
             for (int t = 0; t < NT2; ++t) acc[t] = *reinterpret_cast<const V4*>(b + (size_t)t * 16 * sizeof(T));
         }
-        block<true>(lds, x, acc, lane);
+        block<true>(lds, x, acc, lane, streamed);
         asm volatile("" ::: "memory");
-        block<false>(lds, h, acc, lane);
+        block<false>(lds, h, acc, lane, streamed);
     }
 
     // forward step that keeps this lane's gate values for the backward pass (q = h Wch + bch un-scaled)
     static __device__ __forceinline__ void step_keep(const char* lds, const T (&x)[KT], const T (&h)[KT],
                                                      T (&hn)[KT], T (&rg)[KT], T (&ug)[KT], T (&cc)[KT],
-                                                     T (&qv)[KT], int lane) {
+                                                     T (&qv)[KT], int lane, const bool streamed = false) {
         V4 acc[NT2];
-        products(lds, x, h, acc, lane);
+        products(lds, x, h, acc, lane, streamed);
         const T inv_cs = (T)(1.0 / A::kCandScale);
 #pragma unroll
         for (int m = 0; m < NFULL; ++m)
@@ -342,9 +392,9 @@ struct UpperCore {
         }
     }
 
-    static __device__ __forceinline__ void step(const char* lds, const T (&x)[KT], T (&h)[KT], int lane) {
+    static __device__ __forceinline__ void step(const char* lds, const T (&x)[KT], T (&h)[KT], int lane, const bool streamed = false) {
         V4 acc[NT2];
-        products(lds, x, h, acc, lane);
+        products(lds, x, h, acc, lane, streamed);
 #pragma unroll
         for (int m = 0; m < NFULL; ++m)
 #pragma unroll

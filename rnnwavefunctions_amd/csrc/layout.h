@@ -105,10 +105,18 @@ struct UpperLayout {
 // Where the images of all layers exceed the 160 KB of LDS (three layers of 50 units: 171 KB; run_1dTFIM.py's width with
 // num_layers = 3) the top layer's image stays in global memory (MlSpill<...>::value = 1): its A fragments are then read
 // through L2 every step (67 KB per wave-step, every wave the same lines) - slower, but the configuration runs.
+// Wider stacks (round 3: 53..100 units, float) spill as many of the top layers as it takes - all NL - 1 of them at 100 units,
+// where one upper image is 250 KB; the first layer's image always fits.
 template <int NFULL, int NL, typename T, int NOUT = 1>
 struct MlSpill {
-    static constexpr size_t ALL = GruLayout<T, NFULL, NOUT>::BYTES + (size_t)(NL - 1) * UpperLayout<NFULL, T>::BYTES;
-    static constexpr int value = ALL > 160 * 1024 ? 1 : 0;
+    static constexpr size_t L0 = GruLayout<T, NFULL, NOUT>::BYTES, UP = UpperLayout<NFULL, T>::BYTES;
+    static constexpr int pick() {
+        for (int s = 0; s < NL; ++s)
+            if (L0 + (size_t)(NL - 1 - s) * UP <= 160 * 1024) return s;
+        return NL - 1;
+    }
+    static constexpr int value = pick();
+    static_assert(L0 <= 160 * 1024, "the first layer's image must fit LDS");
 };
 
 // row index inside a 16-row tile  <->  (lane quarter q of the C/D fragment, register r)

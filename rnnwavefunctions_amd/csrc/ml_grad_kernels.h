@@ -28,6 +28,9 @@ struct UpperGradLayout {
     static constexpr int WD_Q = ((NOUT * KT + 3) / 4) * 4;               // GruLayout<T, NFULL, NOUT>::WD_Q
     static constexpr size_t HEAD_BYTES = ((size_t)4 * WD_Q * sizeof(T) + 32 + 15) / 16 * 16;   // [4 q][KT][NOUT] + bias (OFF_WD .. end of the image)
     static constexpr int HEAD_ROW = 4 * KT + 4;                          // as GradLayout::HEAD_ROW
+    // forward image + both backward operands + head rows beyond the 160 KB of LDS (53..100 units): read through L2 instead
+    static constexpr bool WIDE = UpperLayout<NFULL, T>::BYTES + BWD_BYTES + HEAD_BYTES > 160 * 1024;
+    static constexpr size_t LDS_BYTES = WIDE ? HEAD_BYTES : UpperLayout<NFULL, T>::BYTES + BWD_BYTES + HEAD_BYTES;
 };
 
 struct UpperGradArgs {
@@ -61,25 +64,43 @@ __global__ void __launch_bounds__(WAVES * 64) gru_upper_bwd_kernel(UpperGradArgs
     const T* hck = reinterpret_cast<const T*>(a.hck);
     const T* dh_in = reinterpret_cast<const T*>(a.dh_in);
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    // WIDE (53..100 units): the layer's forward image and its two backward operands exceed LDS; both stay in global memory and are
+    // read through L2 with buffer loads (forward: UpperCore::block's bounded look-ahead; backward: one k-group ahead); LDS holds
+    // the head rows only
+    constexpr bool WIDE = G::WIDE;
+    constexpr size_t HEAD_OFF = WIDE ? 0 : CU::U::BYTES + G::BWD_BYTES;
     {
         auto copy = [&](char* dst_, const void* src_, size_t bytes) {
             const uint4* src = reinterpret_cast<const uint4*>(src_);
             uint4* dst = reinterpret_cast<uint4*>(dst_);
             for (int i = threadIdx.x; i < (int)(bytes / 16); i += blockDim.x) dst[i] = src[i];
         };
-        copy(lds, a.wup, CU::U::BYTES);
-        copy(lds + CU::U::BYTES, a.wbwd, G::BWD_BYTES);
-        if (TOP) copy(lds + CU::U::BYTES + G::BWD_BYTES, a.whead, G::HEAD_BYTES);
+        if constexpr (!WIDE) {
+            copy(lds, a.wup, CU::U::BYTES);
+            copy(lds + CU::U::BYTES, a.wbwd, G::BWD_BYTES);
+        }
+        if (TOP) copy(lds + HEAD_OFF, a.whead, G::HEAD_BYTES);
         __syncthreads();
     }
+    const char* fwd = WIDE ? reinterpret_cast<const char*>(a.wup) : lds;
     const char* lbh = lds + CU::U::BYTES;
     const char* lbx = lbh + G::SIDE_BYTES;
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rbwd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wbwd), 0, (int)G::BWD_BYTES, 0x00020000);
+    auto bwd_frag = [&](int side, int t, int kg) -> VA {    // side 0: H operand, 1: X operand
+        if constexpr (WIDE) {
+            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rbwd, (threadIdx.x & 63) * 16, side * (int)G::SIDE_BYTES + (t * G::KBG + kg) * 64 * 16, 0);
+            return __builtin_bit_cast(VA, v);
+        } else {
+            return (reinterpret_cast<const VA*>(side ? lbx : lbh) + (threadIdx.x & 63))[(t * G::KBG + kg) * 64];
+        }
+    };
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int64_t gw = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * WAVES;
     const int N = a.N;
-    const T* wd = reinterpret_cast<const T*>(lds + CU::U::BYTES + G::BWD_BYTES) + q * G::WD_Q;
-    const T* bd = reinterpret_cast<const T*>(lds + CU::U::BYTES + G::BWD_BYTES) + 4 * G::WD_Q;
+    const T* wd = reinterpret_cast<const T*>(lds + HEAD_OFF) + q * G::WD_Q;
+    const T* bd = reinterpret_cast<const T*>(lds + HEAD_OFF) + 4 * G::WD_Q;
     T hg[NOUT][KT], gb[NOUT];
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) {
@@ -132,7 +153,7 @@ __global__ void __launch_bounds__(WAVES * 64) gru_upper_bwd_kernel(UpperGradArgs
 #pragma unroll
             for (int k = 0; k < KT; ++k) { x[k] = xpf[k]; h[k] = hpf[k]; }
             if (n > 0) fetch_inputs(n - 1, xpf, hpf);
-            CU::step_keep(lds, x, h, hn, rg, ug, cc, qv, lane);
+            CU::step_keep(fwd, x, h, hn, rg, ug, cc, qv, lane, WIDE);
             T g[NOUT];
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) g[o] = T(0);
@@ -220,15 +241,21 @@ __global__ void __launch_bounds__(WAVES * 64) gru_upper_bwd_kernel(UpperGradArgs
 #pragma unroll
             for (int t = 0; t < G::NTO; ++t) accH[t] = accX[t] = V4{T(0), T(0), T(0), T(0)};
             asm volatile("" ::: "memory");
-            const VA* abh = reinterpret_cast<const VA*>(lbh) + lane;
-            const VA* abx = reinterpret_cast<const VA*>(lbx) + lane;
+            VA afh[G::NTO], afx[G::NTO], nfh[G::NTO], nfx[G::NTO];
+#pragma unroll
+            for (int t = 0; t < G::NTO; ++t) {
+                afh[t] = bwd_frag(0, t, 0);
+                afx[t] = bwd_frag(1, t, 0);
+            }
 #pragma unroll
             for (int kg = 0; kg < G::KBG; ++kg) {
-                VA afh[G::NTO], afx[G::NTO];
+                if (WIDE && kg + 1 < G::KBG) {
 #pragma unroll
-                for (int t = 0; t < G::NTO; ++t) {
-                    afh[t] = abh[(t * G::KBG + kg) * 64];
-                    afx[t] = abx[(t * G::KBG + kg) * 64];
+                    for (int t = 0; t < G::NTO; ++t) {
+                        nfh[t] = bwd_frag(0, t, kg + 1);
+                        nfx[t] = bwd_frag(1, t, kg + 1);
+                    }
+                    asm volatile("" ::: "memory");
                 }
 #pragma unroll
                 for (int j = 0; j < VW; ++j)
@@ -237,6 +264,13 @@ __global__ void __launch_bounds__(WAVES * 64) gru_upper_bwd_kernel(UpperGradArgs
                         accH[t] = Frag<T>::mfma(afh[t][j], dpH[VW * kg + j], accH[t]);
                         accX[t] = Frag<T>::mfma(afx[t][j], dpX[VW * kg + j], accX[t]);
                     }
+                if (kg + 1 < G::KBG) {
+#pragma unroll
+                    for (int t = 0; t < G::NTO; ++t) {
+                        afh[t] = WIDE ? nfh[t] : bwd_frag(0, t, kg + 1);
+                        afx[t] = WIDE ? nfx[t] : bwd_frag(1, t, kg + 1);
+                    }
+                }
             }
             T* dxo = reinterpret_cast<T*>(a.dx_out) + (((int64_t)n * a.nsb + sb) * KT) * 64 + lane;
 #pragma unroll

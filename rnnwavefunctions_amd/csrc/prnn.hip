@@ -125,12 +125,16 @@ struct MLaunchL {
                 case 1: { using K = MLaunchL<float, 1, 2, 4>; EXPR; }                       \
                 case 2: { using K = MLaunchL<float, 2, 2, 4>; EXPR; }                       \
                 case 3: { using K = MLaunchL<float, 3, 2, 8>; EXPR; }                       \
+                case 4: { using K = MLaunchL<float, 4, 2, 4>; EXPR; }                       \
+                case 6: { using K = MLaunchL<float, 6, 2, 4>; EXPR; }                       \
             }                                                                               \
         } else if ((h)->NL == 3) {                                                          \
             switch ((h)->NFULL) {                                                           \
                 case 1: { using K = MLaunchL<float, 1, 3, 4>; EXPR; }                       \
                 case 2: { using K = MLaunchL<float, 2, 3, 8>; EXPR; }                       \
                 case 3: { using K = MLaunchL<float, 3, 3, 8>; EXPR; }                       \
+                case 4: { using K = MLaunchL<float, 4, 3, 4>; EXPR; }                       \
+                case 6: { using K = MLaunchL<float, 6, 3, 4>; EXPR; }                       \
             }                                                                               \
         } else if (!(h)->f64) {                                                             \
             switch ((h)->NFULL) {                                                           \

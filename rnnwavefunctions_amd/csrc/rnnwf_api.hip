@@ -141,8 +141,9 @@ extern "C" int rnnwf_create(const rnnwf_config* cfg, rnnwf_handle** out) {
         if (cfg->model == RNNWF_MODEL_GRU1D_F64) {
             if (cfg->units[0] > 36)
                 return bad("rnnwf_create: stacked float64 layers: num_units <= 36, the LDS budget of the weight images");
-        } else if (cfg->units[0] > 52) {
-            return bad("rnnwf_create: stacked layers: num_units <= 52, the LDS budget of the weight images");
+        } else if (cfg->units[0] > 100) {
+            // (above 52 units the upper layers' images are read through L2: layout.h, MlSpill)
+            return bad("rnnwf_create: stacked layers: num_units <= 100");
         }
     }
     const bool two_d = cfg->model == RNNWF_MODEL_MDRNN2D || cfg->model == RNNWF_MODEL_GRU1D_F64;

@@ -205,7 +205,7 @@ def run_1DTFIM(numsteps=10 ** 4, systemsize=20, num_units=50, Bx=1, num_layers=1
     `parity_symmetric=True` is the reference's import switch to RNNwavefunction_paritysym (1DTFIM/TrainingRNN_1DTFIM.py:10):
     P_sym(s) = (P(s) + P(reversed s)) / 2."""
     if not 1 <= num_layers <= 3:
-        raise ValueError("num_layers must be 1..3 (stacked layers: num_units <= 52)")
+        raise ValueError("num_layers must be 1..3 (stacked layers: num_units <= 100)")
     N = systemsize
     scope = "RNNwavefunction"
     Jz = +np.ones(N)
@@ -239,7 +239,7 @@ def run_J1J2(numsteps=10 ** 5, systemsize=20, J1_=1.0, J2_=0.0, Marshall_sign=Fa
     (J1J2/TrainingRNN_J1J2.py:118): Marshall_sign=True therefore selects the PERIODIC chain
     without a Marshall sign - reproduced here on purpose so that runs compare with the reference's."""
     if not 1 <= num_layers <= 3:
-        raise ValueError("num_layers must be 1..3 (stacked layers: num_units <= 52)")
+        raise ValueError("num_layers must be 1..3 (stacked layers: num_units <= 100)")
     N = systemsize
     scope = "RNNwavefunction"
     lr = np.float64(learningrate)

@@ -458,7 +458,8 @@ def make_stacked(model, N, H, L, prm):
 
 
 @pytest.mark.parametrize("N,H,L,B", [(12, 20, 2, 40), (9, 10, 3, 33), (20, 50, 2, 24), (7, 36, 3, 17), (10, 4, 2, 16),
-                                      (16, 52, 2, 16), (20, 50, 3, 24), (9, 52, 3, 70)])     # 3 x 50: top layer's image read through L2
+                                      (16, 52, 2, 16), (20, 50, 3, 24), (9, 52, 3, 70),      # 3 x 50: top layer's image read through L2
+                                      (8, 53, 2, 20), (9, 64, 2, 33), (7, 68, 3, 17), (6, 69, 2, 20), (8, 100, 2, 24), (6, 100, 3, 18)])   # 53..100 units: upper images through L2
 def test_stacked_layers_log_prob_and_eloc_match_oracle(N, H, L, B):
     from rnnwavefunctions_amd import _lib
     prm = stacked_like(H, L, seed=H + L)
@@ -510,8 +511,9 @@ def test_stacked_layers_limits_and_facade():
     from rnnwavefunctions_amd.TFIM1D.RNNwavefunction import RNNwavefunction
     with pytest.raises(ValueError, match="equal num_units"):
         _lib.NativeWavefunction(_lib.MODEL_GRU1D, 10, 1, (20, 10))
-    with pytest.raises(ValueError, match="LDS budget"):
-        _lib.NativeWavefunction(_lib.MODEL_GRU1D, 10, 1, (64, 64))
+    _lib.NativeWavefunction(_lib.MODEL_GRU1D, 10, 1, (64, 64))          # above 52 units the upper layers' images are read through L2
+    with pytest.raises(ValueError, match="num_units <= 100"):
+        _lib.NativeWavefunction(_lib.MODEL_GRU1D, 10, 1, (104, 104))
     with pytest.raises(ValueError, match="one layer"):          # the reference: "num_layers is not supported yet"
         _lib.NativeWavefunction(_lib.MODEL_MDRNN2D, 4, 4, (10, 10))
     with pytest.raises(ValueError, match="float64 layers"):
