@@ -60,7 +60,7 @@ typedef struct {
     int32_t nx;                       /* systemsize (1D) or systemsize_x (2D)                     */
     int32_t ny;                       /* 1 for 1D models, systemsize_y for 2D                     */
     int32_t num_layers;               /* len(units) of the reference ctor: 1; 2..3 (equal widths,  */
-                                      /* <= 100 units, float64: <= 36) for the GRU models          */
+                                      /* <= 100 units, float64: <= 68) for the GRU models          */
     int32_t units[RNNWF_MAX_LAYERS];  /* units[n]                                                 */
     int32_t device;                   /* HIP device ordinal                                       */
     int32_t reserved[6];

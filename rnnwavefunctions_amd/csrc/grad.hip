@@ -419,6 +419,10 @@ struct MLGrad {
             if ((h)->NL == 2 && (h)->NFULL == 2) { using K = MLGrad<2, 2, 4, 1, double>; EXPR; } \
             if ((h)->NL == 3 && (h)->NFULL == 1) { using K = MLGrad<1, 3, 4, 1, double>; EXPR; } \
             if ((h)->NL == 3 && (h)->NFULL == 2) { using K = MLGrad<2, 3, 4, 1, double>; EXPR; } \
+            if ((h)->NL == 2 && (h)->NFULL == 3) { using K = MLGrad<3, 2, 4, 1, double>; EXPR; } \
+            if ((h)->NL == 2 && (h)->NFULL == 4) { using K = MLGrad<4, 2, 4, 1, double>; EXPR; } \
+            if ((h)->NL == 3 && (h)->NFULL == 3) { using K = MLGrad<3, 3, 4, 1, double>; EXPR; } \
+            if ((h)->NL == 3 && (h)->NFULL == 4) { using K = MLGrad<4, 3, 4, 1, double>; EXPR; } \
         } else MLGRAD_DISPATCH_(h, 1, EXPR);                            \
     } while (0)
 

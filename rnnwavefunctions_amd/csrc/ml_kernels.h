@@ -33,7 +33,7 @@ struct MlCore {
         for (int l = 1; l < NL; ++l) {
             const size_t off = C0::L::BYTES + (size_t)(l - 1) * CU::U::BYTES;
             if (l < NL - SPILL) CU::step(lds + off, h[l - 1], h[l], lane);
-            else CU::step(reinterpret_cast<const char*>(wimg) + off, h[l - 1], h[l], lane, NFULL >= 4);      // wide layers: bounded look-ahead (UpperCore::block)
+            else CU::step(reinterpret_cast<const char*>(wimg) + off, h[l - 1], h[l], lane, NFULL * (int)sizeof(T) >= 16);      // wide layers (f32 >= 53, f64 >= 37 units): bounded look-ahead (UpperCore::block)
         }
         T z[1];
         C0::head(lds, h[NL - 1], lane, z);

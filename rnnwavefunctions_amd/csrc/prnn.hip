@@ -114,11 +114,15 @@ struct MLaunchL {
             switch ((h)->NFULL) {                                                           \
                 case 1: { using K = MLaunchL<double, 1, 2, 4>; EXPR; }                      \
                 case 2: { using K = MLaunchL<double, 2, 2, 8>; EXPR; }                      \
+                case 3: { using K = MLaunchL<double, 3, 2, 4>; EXPR; }                      \
+                case 4: { using K = MLaunchL<double, 4, 2, 4>; EXPR; }                      \
             }                                                                               \
         } else if ((h)->NL == 3 && (h)->f64) {                                              \
             switch ((h)->NFULL) {                                                           \
                 case 1: { using K = MLaunchL<double, 1, 3, 4>; EXPR; }                      \
                 case 2: { using K = MLaunchL<double, 2, 3, 4>; EXPR; }                      \
+                case 3: { using K = MLaunchL<double, 3, 3, 4>; EXPR; }                      \
+                case 4: { using K = MLaunchL<double, 4, 3, 4>; EXPR; }                      \
             }                                                                               \
         } else if ((h)->NL == 2) {                                                          \
             switch ((h)->NFULL) {                                                           \

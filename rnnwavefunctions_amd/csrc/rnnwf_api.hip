@@ -139,8 +139,8 @@ extern "C" int rnnwf_create(const rnnwf_config* cfg, rnnwf_handle** out) {
         // two layer images (one forward + its two backward operands in the gradient pass) must fit the 160 KB of LDS;
         // a third layer's image is read through L2 where three do not fit (layout.h: MlSpill)
         if (cfg->model == RNNWF_MODEL_GRU1D_F64) {
-            if (cfg->units[0] > 36)
-                return bad("rnnwf_create: stacked float64 layers: num_units <= 36, the LDS budget of the weight images");
+            if (cfg->units[0] > 68)
+                return bad("rnnwf_create: stacked float64 layers: num_units <= 68");
         } else if (cfg->units[0] > 100) {
             // (above 52 units the upper layers' images are read through L2: layout.h, MlSpill)
             return bad("rnnwf_create: stacked layers: num_units <= 100");

@@ -302,7 +302,7 @@ def run_2DTFIM_1DRNN(numsteps=2 * 10 ** 4, systemsize_x=5, systemsize_y=5, Bx=+2
     1 / (1/lr + it/10)  (Training1DRNN_2DTFIM.py:231).  The reference seeds numpy / TF with `seed` but builds the
     wave function with its class default seed 111 (:104); the initial weights here follow the latter."""
     if not 1 <= num_layers <= 3:
-        raise ValueError("num_layers must be 1..3 (stacked float64 layers: num_units <= 36)")
+        raise ValueError("num_layers must be 1..3 (stacked float64 layers: num_units <= 68)")
     Nx, Ny = systemsize_x, systemsize_y
     lr = np.float64(learningrate)
     units = [num_units] * num_layers

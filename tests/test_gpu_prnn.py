@@ -175,7 +175,8 @@ def test_gru_f64_on_2d_lattice_matches_reference_golden(golden_estimators):
     assert np.allclose(e, g["g4c_eloc"], rtol=1e-10)
 
 
-@pytest.mark.parametrize("Nx,Ny,H,L", [(3, 4, 7, 2), (4, 4, 20, 2), (3, 3, 36, 2), (4, 3, 10, 3), (3, 3, 20, 3), (4, 3, 36, 3)])
+@pytest.mark.parametrize("Nx,Ny,H,L", [(3, 4, 7, 2), (4, 4, 20, 2), (3, 3, 36, 2), (4, 3, 10, 3), (3, 3, 20, 3), (4, 3, 36, 3),
+                                       (3, 3, 37, 2), (4, 4, 50, 2), (3, 3, 68, 2), (4, 3, 50, 3), (3, 2, 68, 3)])      # 37..68 units: upper images through L2
 def test_stacked_gru_f64_on_2d_lattice_matches_oracle(Nx, Ny, H, L):
     """2DTFIM_1DRNN with units=[num_units]*num_layers (Training1DRNN_2DTFIM.py:94): log-probabilities, the sampler's
     stream and the 2D local energies against the float64 oracle."""
@@ -516,8 +517,9 @@ def test_stacked_layers_limits_and_facade():
         _lib.NativeWavefunction(_lib.MODEL_GRU1D, 10, 1, (104, 104))
     with pytest.raises(ValueError, match="one layer"):          # the reference: "num_layers is not supported yet"
         _lib.NativeWavefunction(_lib.MODEL_MDRNN2D, 4, 4, (10, 10))
+    _lib.NativeWavefunction(_lib.MODEL_GRU1D_F64, 4, 4, (40, 40))       # likewise above 36 units in float64
     with pytest.raises(ValueError, match="float64 layers"):
-        _lib.NativeWavefunction(_lib.MODEL_GRU1D_F64, 4, 4, (40, 40))
+        _lib.NativeWavefunction(_lib.MODEL_GRU1D_F64, 4, 4, (72, 72))
     _lib.NativeWavefunction(_lib.MODEL_GRU1D, 20, 1, (50, 50, 50))      # run_1dTFIM.py's width with num_layers = 3
     wf = RNNwavefunction(10, cell="CudnnCompatibleGRUCell", units=[10, 10], seed=111)
     # layer 0: 12*20 + 20 + 2*10 + 10 + 10*10 + 10 = 400; layer 1: 20*20 + 20 + 10*10 + 10 + 10*10 + 10 = 640; head 22

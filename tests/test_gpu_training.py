@@ -225,7 +225,8 @@ def test_gru_f64_gradient_matches_finite_differences_of_the_oracle(Nx, Ny, H, ns
 
 
 @pytest.mark.parametrize("Nx,Ny,H,L,ns", [(3, 3, 6, 2, 64), (4, 3, 20, 2, 48), (3, 3, 36, 2, 32), (3, 3, 10, 3, 40), (3, 2, 20, 3, 24),
-                                          (3, 2, 36, 3, 24)])
+                                          (3, 2, 36, 3, 24),
+                                          (3, 2, 37, 2, 24), (3, 3, 50, 2, 24), (2, 2, 68, 2, 20), (3, 2, 50, 3, 16), (2, 2, 68, 3, 16)])   # 37..68 units: images through L2
 def test_stacked_gru_f64_gradient_matches_finite_differences_of_the_oracle(Nx, Ny, H, L, ns):
     from rnnwavefunctions_amd import _lib
     from rnnwavefunctions_amd.training import cost_gradient
