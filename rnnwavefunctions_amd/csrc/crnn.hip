@@ -19,7 +19,7 @@ constexpr int64_t kChunk = (int64_t)1 << 20;
 template <int NFULL, int WAVES>
 struct CLaunch {
     using L = GruLayout<float, NFULL, 3>;
-    static int blocks_per_cu(rnnwf_handle* h, const void* fn, int* out) { return rnnwf::blocks_per_cu(h, fn, WAVES * 64, L::BYTES, out); }
+    static int blocks_per_cu(rnnwf_handle* h, const void* fn, int* out) { return rnnwf::blocks_per_cu(h, fn, WAVES * 64, L::LDS_BYTES, out); }
     static int base_coop(rnnwf_handle* h, const CrnnArgs& a) {
         if constexpr (NFULL <= 4) {
             const void* fn = (const void*)crnn_base_coop_kernel<NFULL>;
@@ -43,7 +43,7 @@ struct CLaunch {
         const int64_t need = (a.nsb + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
         TimedLaunch tl(h, 0);
-        crnn_base_kernel<NFULL, WAVES><<<grid, WAVES * 64, L::BYTES, h->stream>>>(a);
+        crnn_base_kernel<NFULL, WAVES><<<grid, WAVES * 64, L::LDS_BYTES, h->stream>>>(a);
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }
@@ -55,7 +55,7 @@ struct CLaunch {
         const int64_t need = (max_tiles + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
         TimedLaunch tl(h, 1);
-        crnn_swap_kernel<NFULL, WAVES><<<grid, WAVES * 64, L::BYTES, h->stream>>>(a);
+        crnn_swap_kernel<NFULL, WAVES><<<grid, WAVES * 64, L::LDS_BYTES, h->stream>>>(a);
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }
@@ -128,6 +128,9 @@ struct CMLaunch {
             case 3: { using K = CLaunch<3, 4>; EXPR; }          \
             case 4: { using K = CLaunch<4, 4>; EXPR; }          \
             case 6: { using K = CLaunch<6, 8>; EXPR; }         \
+            case 8: { using K = CLaunch<8, 4>; EXPR; }          \
+            case 12: { using K = CLaunch<12, 4>; EXPR; }        \
+            case 16: { using K = CLaunch<16, 4>; EXPR; }        \
         }                                                       \
     } while (0)
 
@@ -250,7 +253,7 @@ int64_t collect_totals(rnnwf_handle* h, int64_t ns) {
 int rnnwf::crnn_pack_image(rnnwf_handle* h, std::vector<char>& img) {
     // swap-pass engine: bf16x3 on the matrix core (RNNWF_ENGINE=f32: f32-input MFMA everywhere; above 68 units the w3
     // fragments are read through L2, split_stream.hip)
-    h->engine_split = h->NL == 1 && h->knobs.engine != 1;                      // stacked layers: f32-input MFMA
+    h->engine_split = h->NL == 1 && h->knobs.engine != 1 && h->NFULL <= 6;     // stacked layers, > 100 units: f32-input MFMA
     if (h->engine_split) {
         std::vector<char> simg;
         if (int rc = crnn_split_pack(h, simg)) return rc;

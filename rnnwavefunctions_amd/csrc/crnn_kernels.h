@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(WAVES * 64) crnn_base_kernel(CrnnArgs a) {
     using C = GruCore<float, NFULL, 3>;
     constexpr int KT = C::KT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    C::stage(lds, a.wimg);
+    const char* img = C::stage(lds, a.wimg);       // LDS, or the global image where it exceeds LDS (GruLayout::SPILL)
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int64_t gw = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * WAVES;
@@ -95,9 +95,9 @@ __global__ void __launch_bounds__(WAVES * 64) crnn_base_kernel(CrnnArgs a) {
         double re = 0.0, im = 0.0;
         for (int n = 0; n < N; ++n) {
             if (!a.sampling && (n & 31) == 0) word = a.bits[(int64_t)(n >> 5) * a.ns + sc];
-            C::template step<true>(lds, sig_in, h, lane);    // bias last: bit-identical to crnn_base_coop_kernel
+            C::template step<true>(img, sig_in, h, lane);    // bias last: bit-identical to crnn_base_coop_kernel
             float z[3];
-            C::head(lds, h, lane, z);
+            C::head(img, h, lane, z);
             float la0, la1, w0, ph0, ph1;
             crnn_site(z, n, N, num_up, la0, la1, w0, ph0, ph1);
             int sig;
@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(WAVES * 64) crnn_swap_kernel(CrnnArgs a) {
     using C = GruCore<float, NFULL, 3>;
     constexpr int KT = C::KT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    C::stage(lds, a.wimg);
+    const char* img = C::stage(lds, a.wimg);       // LDS, or the global image where it exceeds LDS (GruLayout::SPILL)
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int64_t gw = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * WAVES;
@@ -388,9 +388,9 @@ __global__ void __launch_bounds__(WAVES * 64) crnn_swap_kernel(CrnnArgs a) {
         double re = 0.0, im = 0.0;
         for (int n = lo + 1; n < N; ++n) {
             if ((n & 31) == 0) word = a.bits[(int64_t)(n >> 5) * a.ns + s];
-            C::step(lds, sig_in, h, lane);
+            C::step(img, sig_in, h, lane);
             float z[3];
-            C::head(lds, h, lane, z);
+            C::head(img, h, lane, z);
             float la0, la1, w0, ph0, ph1;
             crnn_site(z, n, N, num_up, la0, la1, w0, ph0, ph1);
             const int sig = (int)((word >> (n & 31)) & 1) ^ (n == it.hi ? 1 : 0);

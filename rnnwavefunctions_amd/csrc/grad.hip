@@ -17,7 +17,7 @@ struct GLaunch {
     using L = GruLayout<T, NFULL, NOUT>;
     using G = GradLayout<NFULL, T>;
     static constexpr bool STREAM = GradStream<T, NFULL, NOUT>::value;       // backward operand read through L2 (grad_kernels.h)
-    static constexpr size_t LDS = L::BYTES + (STREAM ? 0 : G::BWD_BYTES);
+    static constexpr size_t LDS = L::LDS_BYTES + (STREAM ? 0 : G::BWD_BYTES);
 
     static std::vector<char> pack_bwd(const rnnwf_handle* h) {
         const int H = h->H;
@@ -151,6 +151,9 @@ struct GLaunch {
                 case 3: { using K = GLaunch<float, 3, 4, 3>; EXPR; }    \
                 case 4: { using K = GLaunch<float, 4, 4, 3>; EXPR; }    \
                 case 6: { using K = GLaunch<float, 6, 4, 3>; EXPR; }    \
+                case 8: { using K = GLaunch<float, 8, 8, 3>; EXPR; }    /* 8 waves: with AGPRs in reach hipcc 7.2 crashes in */ \
+                case 12: { using K = GLaunch<float, 12, 8, 3>; EXPR; }  /* 'AMDGPU Rewrite AGPR-Copy-MFMA' on these two      */ \
+                case 16: { using K = GLaunch<float, 16, 4, 3>; EXPR; }  \
             }                                                           \
         } else if ((h)->model == RNNWF_MODEL_GRU1D_F64) {               \
             switch ((h)->NFULL) {                                       \
@@ -166,6 +169,9 @@ struct GLaunch {
                 case 3: { using K = GLaunch<float, 3, 4, 1>; EXPR; }    \
                 case 4: { using K = GLaunch<float, 4, 4, 1>; EXPR; }    \
                 case 6: { using K = GLaunch<float, 6, 4, 1>; EXPR; }    \
+                case 8: { using K = GLaunch<float, 8, 4, 1>; EXPR; }    \
+                case 12: { using K = GLaunch<float, 12, 4, 1>; EXPR; }  \
+                case 16: { using K = GLaunch<float, 16, 4, 1>; EXPR; }  \
             }                                                           \
         }                                                               \
     } while (0)

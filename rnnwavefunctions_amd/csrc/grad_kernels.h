@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
     constexpr int KT = C::KT, NT = C::NT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr bool STREAM = GradStream<T, NFULL, NOUT>::value;
-    C::stage(lds, a.wimg);
+    const char* img = C::stage(lds, a.wimg);       // LDS, or the global image where it exceeds LDS (GruLayout::SPILL)
     if constexpr (!STREAM) {
         char* lb = lds + C::L::BYTES;
         const uint4* src = reinterpret_cast<const uint4*>(a.wbwd);
@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
     const int64_t gw = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * WAVES;
     const int N = a.N;
-    const T* wd = reinterpret_cast<const T*>(lds + C::L::OFF_WD) + q * C::L::WD_Q;
+    const T* wd = reinterpret_cast<const T*>(img + C::L::OFF_WD) + q * C::L::WD_Q;
     const int hck_nl = a.hck_nl > 1 ? a.hck_nl : 1;
     T hg[NOUT][KT], gb[NOUT];                             // head-row sums over all chains of this wave
 #pragma unroll
@@ -188,9 +188,9 @@ __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
                 wcur = wlow;
                 wlow = n >= 64 ? word((n >> 5) - 2) : 0u;
             }
-            C::step_keep(lds, sig_in, h, hn, rg, ug, cc, qv, lane);
+            C::step_keep(img, sig_in, h, hn, rg, ug, cc, qv, lane);
             T z[NOUT];
-            C::head(lds, hn, lane, z);
+            C::head(img, hn, lane, z);
             // gradient of this site's term w.r.t. the head rows
             T g[NOUT];
             const T p1 = T(1) - prob0(z[0]);

@@ -96,12 +96,60 @@ struct GruCore {
     static constexpr int KT = L::KT, NT = L::NT, NG = L::NG, VW = L::VW;
     static constexpr int TC = 5;  // tiles per MFMA issue group (independent accumulators back to back)
 
-    // Stage the packed weight image into LDS (all threads of the workgroup).
-    static __device__ __forceinline__ void stage(char* lds, const void* wimg) {
-        const uint4* src = reinterpret_cast<const uint4*>(wimg);
-        uint4* dst = reinterpret_cast<uint4*>(lds);
-        for (int i = threadIdx.x; i < (int)(L::BYTES / 16); i += blockDim.x) dst[i] = src[i];
-        __syncthreads();
+    // Stage the packed weight image into LDS (all threads of the workgroup) and return where the step functions find it: LDS, or
+    // - L::SPILL, the image exceeds LDS - the global image itself.
+    static __device__ __forceinline__ const char* stage(char* lds, const void* wimg) {
+        if constexpr (L::SPILL) {
+            return reinterpret_cast<const char*>(wimg);
+        } else {
+            const uint4* src = reinterpret_cast<const uint4*>(wimg);
+            uint4* dst = reinterpret_cast<uint4*>(lds);
+            for (int i = threadIdx.x; i < (int)(L::BYTES / 16); i += blockDim.x) dst[i] = src[i];
+            __syncthreads();
+            return lds;
+        }
+    }
+    // L::SPILL: the products  acc += A h  with the fragments read through L2 - buffer loads with the fragment's position as the scalar
+    // offset, two groups of five tiles ahead of their MFMAs and no further (UpperCore::block explains why)
+    static __device__ __forceinline__ void mfma_streamed(const char* img, const T (&h)[KT], V4 (&acc)[NT], int lane) {
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(img), 0, (int)L::OFF_BINIT, 0x00020000);
+        constexpr int NTG = (NT + TC - 1) / TC, NGR = NG * NTG, AHEAD = 2;
+        VA ring[AHEAD + 1][TC];
+        auto request = [&](int k, VA (&dstv)[TC]) {
+            const int g = k / NTG, t0 = (k % NTG) * TC;
+#pragma unroll
+            for (int t = 0; t < TC; ++t)
+                if (t0 + t < NT) {
+                    const u32x4_t w = __builtin_amdgcn_raw_buffer_load_b128(rv, lane * 16, ((t0 + t) * NG + g) * 64 * 16, 0);
+                    dstv[t] = __builtin_bit_cast(VA, w);
+                }
+        };
+#pragma unroll
+        for (int k = 0; k < AHEAD && k < NGR; ++k) request(k, ring[k]);
+#pragma unroll
+        for (int k = 0; k < NGR; ++k) {
+            if (k + AHEAD < NGR) request(k + AHEAD, ring[(k + AHEAD) % (AHEAD + 1)]);
+            asm volatile("" ::: "memory");
+            const int g = k / NTG, t0 = (k % NTG) * TC;
+#pragma unroll
+            for (int j = 0; j < VW; ++j)
+#pragma unroll
+                for (int t = 0; t < TC; ++t)
+                    if (t0 + t < NT) acc[t0 + t] = F::mfma(ring[k % (AHEAD + 1)][t][j], h[g * VW + j], acc[t0 + t]);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            T a;
+            if constexpr (sizeof(T) == 4) {
+                a = __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(rv, lane * 4, (int)L::OFF_AREM + t * 64 * 4, 0));
+            } else {
+                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                const u32x2_t w = __builtin_amdgcn_raw_buffer_load_b64(rv, lane * 8, (int)L::OFF_AREM + t * 64 * 8, 0);
+                a = __builtin_bit_cast(T, w);
+            }
+            acc[t] = F::mfma(a, h[KT - 1], acc[t]);
+        }
     }
 
     // h[kt] of lane (c, q) holds unit 4 kt + q of chain c.  sig: input spin of this step (-1: zero vector).
@@ -135,7 +183,9 @@ struct GruCore {
         // config 5 (measured round 2: 320.8 vs 297.3 ms; round 1 had the regions by accident, through the run-time
         // diagnostics branches that stood here).
         __builtin_amdgcn_sched_barrier(0);
-        if (!RNNWF_ABLATED(ablate, 1)) {
+        if constexpr (L::SPILL) {
+            mfma_streamed(lds, h, acc, lane);
+        } else if (!RNNWF_ABLATED(ablate, 1)) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
 #pragma unroll
@@ -194,6 +244,9 @@ struct GruCore {
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = *reinterpret_cast<const V4*>(b + (size_t)t * 16 * sizeof(T));
         }
+        if constexpr (L::SPILL) {
+            mfma_streamed(lds, h, acc, lane);
+        } else {
         const VA* av = reinterpret_cast<const VA*>(lds + L::OFF_AVEC) + lane;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -214,6 +267,7 @@ struct GruCore {
             const T* ar = reinterpret_cast<const T*>(lds + L::OFF_AREM) + lane;
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = F::mfma(ar[t * 64], h[KT - 1], acc[t]);
+        }
         }
         const char* x = lds + L::OFF_XC + (size_t)(sig + 1) * L::SZ_XC_VARIANT + (size_t)q * 4 * sizeof(T);
         const T inv_cs = T(1.0 / A::kCandScale);

@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_base_kernel(PrnnArgs a) {
     using C = GruCore<T, NFULL, 1>;
     constexpr int KT = C::KT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    C::stage(lds, a.wimg);
+    const char* img = C::stage(lds, a.wimg);       // LDS, or the global image where it exceeds LDS (GruLayout::SPILL)
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int64_t gw = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * WAVES;
@@ -62,9 +62,9 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_base_kernel(PrnnArgs a) {
         double cum = 0.0;
         for (int n = 0; n < N; ++n) {
             if (!a.sampling && (n & 31) == 0) word = a.bits[(int64_t)(n >> 5) * a.ns + sc];
-            C::template step<true>(lds, sig_in, h, lane);
+            C::template step<true>(img, sig_in, h, lane);
             T z[1];
-            C::head(lds, h, lane, z);
+            C::head(img, h, lane, z);
             T lp0, lp1;
             log_softmax2(z[0], lp0, lp1);
             int sig;
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_flip_kernel(PrnnArgs a) {
     using C = GruCore<T, NFULL, 1>;
     constexpr int KT = C::KT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    C::stage(lds, a.wimg);
+    const char* img = C::stage(lds, a.wimg);       // LDS, or the global image where it exceeds LDS (GruLayout::SPILL)
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int64_t gw = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * WAVES;
@@ -130,10 +130,10 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_flip_kernel(PrnnArgs a) {
         double lp = 0.0;
         for (int n = i + 1; n < N; ++n) {
             const int sig = spin(n);
-            C::step(lds, sig_in, h, lane, a.ablate);
+            C::step(img, sig_in, h, lane, a.ablate);
             if (!RNNWF_ABLATED(a.ablate, 4)) {
                 T z[1];
-                C::head(lds, h, lane, z);
+                C::head(img, h, lane, z);
                 T lp0, lp1;
                 log_softmax2(z[0], lp0, lp1);
                 lp += (double)(sig ? lp1 : lp0);

@@ -56,6 +56,10 @@ struct GruLayout {
     static constexpr size_t OFF_WD = OFF_XC + 3 * SZ_XC_VARIANT;                     // [4 q][KT][NOUT] T, WD_Q per q
     static constexpr size_t OFF_BD = OFF_WD + (size_t)4 * WD_Q * sizeof(T);          // [NOUT] T (padded to 32 B)
     static constexpr size_t BYTES = ((OFF_BD + 32 + 15) / 16) * 16;
+    // above 100 units (float) / 68 (double) the image no longer fits the 160 KB of LDS: it stays in global memory, its A fragments
+    // are read through L2 with buffer loads (GruCore::mfma_streamed), the small tables with plain loads
+    static constexpr bool SPILL = BYTES > 160 * 1024;
+    static constexpr size_t LDS_BYTES = SPILL ? 0 : BYTES;
 };
 
 // bf16x3 operand image of the COOPERATIVE base pass (gru_kernels.h: coop_base_pass_bf; f32 models, NFULL <= 3): the same tiles,

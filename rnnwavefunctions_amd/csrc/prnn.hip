@@ -19,7 +19,7 @@ constexpr int64_t kLogProbChunk = (int64_t)1 << 20;
 template <typename T, int NFULL, int WAVES>
 struct Launch {
     using L = GruLayout<T, NFULL, 1>;
-    static int blocks_per_cu(rnnwf_handle* h, const void* fn, int* out) { return rnnwf::blocks_per_cu(h, fn, WAVES * 64, L::BYTES, out); }
+    static int blocks_per_cu(rnnwf_handle* h, const void* fn, int* out) { return rnnwf::blocks_per_cu(h, fn, WAVES * 64, L::LDS_BYTES, out); }
     // fewer 16-chain blocks than SIMDs: the cooperative kernel (NFULL + 1 waves per block) cuts the per-site latency
     static int base_coop(rnnwf_handle* h, const PrnnArgs& a) {
         if constexpr (std::is_same<T, float>::value && NFULL <= 4) {
@@ -46,7 +46,7 @@ struct Launch {
         const int64_t need = (a.nsb + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
         TimedLaunch tl(h, 0);
-        prnn_base_kernel<T, NFULL, WAVES><<<grid, WAVES * 64, L::BYTES, h->stream>>>(a);
+        prnn_base_kernel<T, NFULL, WAVES><<<grid, WAVES * 64, L::LDS_BYTES, h->stream>>>(a);
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }
@@ -57,7 +57,7 @@ struct Launch {
         const int64_t need = (a.ntiles + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
         TimedLaunch tl(h, 1);
-        prnn_flip_kernel<T, NFULL, WAVES><<<grid, WAVES * 64, L::BYTES, h->stream>>>(a);
+        prnn_flip_kernel<T, NFULL, WAVES><<<grid, WAVES * 64, L::LDS_BYTES, h->stream>>>(a);
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }
@@ -147,6 +147,9 @@ struct MLaunchL {
                 case 3: { using K = Launch<float, 3, 4>; EXPR; }                            \
                 case 4: { using K = Launch<float, 4, 4>; EXPR; }                            \
                 case 6: { using K = Launch<float, 6, 8>; EXPR; }                            \
+                case 8: { using K = Launch<float, 8, 4>; EXPR; }                            \
+                case 12: { using K = Launch<float, 12, 4>; EXPR; }                          \
+                case 16: { using K = Launch<float, 16, 4>; EXPR; }                          \
             }                                                                               \
         } else {                                                                            \
             switch ((h)->NFULL) {                                                           \
@@ -294,7 +297,7 @@ int rnnwf::prnn_teacher_base(rnnwf_handle* h, int64_t ns, bool reversed, double*
 int rnnwf::prnn_pack_image(rnnwf_handle* h, std::vector<char>& img) {
     // flip-pass engine: bf16x3 on the matrix core for the f32 models (RNNWF_ENGINE=f32 keeps the f32-input MFMA
     // everywhere; above 68 units the w3 fragments of the image are read through L2, split_stream.hip); the base pass, sampling and log_probability always run the f32-MFMA kernels
-    h->engine_split = !h->f64 && h->NL == 1 && h->knobs.engine != 1;
+    h->engine_split = !h->f64 && h->NL == 1 && h->knobs.engine != 1 && h->NFULL <= 6;     // above 100 units: f32-input MFMA, image through L2
     h->engine_forced = h->knobs.engine >= 2;
     if (h->engine_split) {
         std::vector<char> simg;

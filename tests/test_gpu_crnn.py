@@ -36,7 +36,7 @@ def zero_mag_batch(ns, N, seed):
     return np.stack([rng.permutation(np.repeat([0, 1], N // 2)) for _ in range(ns)]).astype(np.int32)
 
 
-@pytest.mark.parametrize("N,H,B", [(10, 11, 50), (40, 50, 100), (34, 20, 70), (16, 100, 33)])
+@pytest.mark.parametrize("N,H,B", [(10, 11, 50), (40, 50, 100), (34, 20, 70), (16, 100, 33), (12, 128, 24), (8, 200, 20), (8, 256, 17)])
 def test_log_amplitude_matches_oracle(N, H, B):
     prm = trained_like(H, seed=H)
     wf = make_wf(N, H, prm)
@@ -128,6 +128,26 @@ def test_both_swap_engines_agree_with_the_f64_oracle(N, H, ns, monkeypatch):
         print("cRNN N=%d H=%d %-6s: max |E_loc - f64| / max|E| = %.2e" % (N, H, engine, err))
         assert err < 3e-5
     assert np.allclose(got["f32"], got["bf16x3"], rtol=5e-5, atol=5e-5)
+
+
+@pytest.mark.parametrize("N,H,ns", [(12, 128, 33), (8, 196, 20), (8, 256, 17)])
+def test_local_energies_above_100_units(N, H, ns):
+    """Above 100 units the weight image no longer fits LDS: it stays in global memory and the kernels (f32-input MFMA) read its
+    fragments through L2 (GruLayout::SPILL).  Sampling respects the U(1) mask, local energies match the float64 oracle."""
+    prm = trained_like(H, seed=N + H)
+    prm64 = {k: v.astype(np.float64) for k, v in prm.items()}
+    wf = make_wf(N, H, prm)
+    rng = np.random.RandomState(4)
+    J1, J2, Bz = 1.0 + 0.1 * rng.standard_normal(N), 0.4 * np.ones(N), np.zeros(N)
+    s = zero_mag_batch(ns, N, 5)
+    e, _ = wf.j1j2_eloc(s, J1, J2, Bz, False, False)
+    assert wf.engine_name() == "f32mfma"
+    e64 = E.j1j2_local_energies(J1, J2, Bz, s, lambda x: M.crnn_log_amplitude(prm64, x, dtype=np.float64), False, False)
+    err = np.abs(e - e64).max() / max(1.0, np.abs(e64).max())
+    print("cRNN N=%d H=%d: max |E_loc - f64| / max|E| = %.2e" % (N, H, err))
+    assert err < 3e-5
+    drawn = wf.sample(64, seed=3, step=0)
+    assert np.all(drawn.sum(axis=1) == N // 2)
 
 
 @pytest.mark.parametrize("H", [20, 36, 37, 50, 52, 53, 60, 64, 68, 69, 100])

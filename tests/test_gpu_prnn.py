@@ -33,7 +33,8 @@ def trained_like(H, seed, dtype=np.float32, heads=("wf_dense",)):
     return P.randomize_biases(P.scale_kernels(P.init_gru_params([H], seed=seed, dtype=dtype, heads=heads), 2.0), seed + 1)
 
 
-@pytest.mark.parametrize("N,H,B", [(10, 12, 37), (33, 20, 200), (40, 36, 64), (70, 50, 130), (20, 64, 48), (24, 100, 40)])
+@pytest.mark.parametrize("N,H,B", [(10, 12, 37), (33, 20, 200), (40, 36, 64), (70, 50, 130), (20, 64, 48), (24, 100, 40),
+                                   (12, 101, 24), (12, 128, 24), (9, 133, 20), (8, 200, 20), (6, 256, 17), (5, 260, 16)])     # > 100 units: the image is read through L2
 def test_log_prob_matches_oracle(N, H, B):
     from rnnwavefunctions_amd import _lib
     prm = trained_like(H, seed=H)
@@ -94,7 +95,7 @@ def test_tfim_eloc_matches_reference_golden(golden_estimators):
     assert np.allclose(e0, g["g4a_eloc_bx0"], atol=1e-12)          # Bx = 0: diagonal only, exact
 
 
-@pytest.mark.parametrize("N,H,ns", [(33, 20, 50), (65, 50, 21), (16, 100, 17)])
+@pytest.mark.parametrize("N,H,ns", [(33, 20, 50), (65, 50, 21), (16, 100, 17), (12, 128, 21), (9, 196, 17), (8, 256, 17)])
 def test_tfim_eloc_fused_equals_reference_formulation(N, H, ns):
     from rnnwavefunctions_amd import _lib
     prm = trained_like(H, seed=N)
@@ -515,6 +516,9 @@ def test_stacked_layers_limits_and_facade():
     _lib.NativeWavefunction(_lib.MODEL_GRU1D, 10, 1, (64, 64))          # above 52 units the upper layers' images are read through L2
     with pytest.raises(ValueError, match="num_units <= 100"):
         _lib.NativeWavefunction(_lib.MODEL_GRU1D, 10, 1, (104, 104))
+    with pytest.raises(ValueError, match="num_units too large"):
+        _lib.NativeWavefunction(_lib.MODEL_GRU1D, 10, 1, (261,))
+    _lib.NativeWavefunction(_lib.MODEL_GRU1D, 10, 1, (260,))            # above 100 units the image is read through L2
     with pytest.raises(ValueError, match="one layer"):          # the reference: "num_layers is not supported yet"
         _lib.NativeWavefunction(_lib.MODEL_MDRNN2D, 4, 4, (10, 10))
     _lib.NativeWavefunction(_lib.MODEL_GRU1D_F64, 4, 4, (40, 40))       # likewise above 36 units in float64

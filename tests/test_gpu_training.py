@@ -17,7 +17,8 @@ def oracle_cost(prm64, samples, eloc):
 
 
 @pytest.mark.parametrize("N,H,ns", [(6, 6, 64), (9, 20, 48), (7, 50, 32), (6, 64, 32), (6, 100, 24), (5, 80, 40),   # > 68 units: backward operand through L2
-                                    (1, 10, 5), (2, 6, 3), (35, 20, 7), (67, 10, 9)])   # fewer rows than one GEMM step; spin words beyond the first
+                                    (1, 10, 5), (2, 6, 3), (35, 20, 7), (67, 10, 9),   # fewer rows than one GEMM step; spin words beyond the first
+                                    (5, 128, 24), (4, 200, 16), (3, 256, 16)])         # > 100 units: forward image through L2 as well
 def test_gradient_matches_finite_differences_of_the_oracle(N, H, ns):
     from rnnwavefunctions_amd import _lib
     from rnnwavefunctions_amd.training import cost_gradient
@@ -115,7 +116,7 @@ def oracle_cost_complex(prm64, samples, eloc):
     return 2 * np.real(np.mean(np.conj(la) * eloc) - np.conj(np.mean(la)) * np.mean(eloc))   # TrainingRNN_J1J2.py:197
 
 
-@pytest.mark.parametrize("N,H,ns", [(8, 6, 64), (12, 20, 48), (10, 50, 32), (8, 100, 24)])
+@pytest.mark.parametrize("N,H,ns", [(8, 6, 64), (12, 20, 48), (10, 50, 32), (8, 100, 24), (6, 128, 24), (4, 196, 16), (4, 256, 16)])
 def test_complex_gradient_matches_finite_differences_of_the_oracle(N, H, ns):
     from rnnwavefunctions_amd import _lib
     from rnnwavefunctions_amd.training import cost_gradient

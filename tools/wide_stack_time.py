@@ -1,4 +1,5 @@
-"""Times vmc_step and the gradient for stacked layers wider than 52 units (upper images read through L2): python tools/wide_stack_time.py"""
+"""Times vmc_step and the gradient for the widths whose weight images are read through L2 - stacked layers above 52 units, single
+layers above 100: python tools/wide_stack_time.py"""
 import time, numpy as np, sys
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rnnwavefunctions_amd import _lib, params as P
@@ -27,3 +28,8 @@ run(_lib.MODEL_GRU1D, N, 100, 2, 500, ("wf_dense",), np.append(np.ones(N), 1.0))
 run(_lib.MODEL_GRU1D, N, 64, 2, 500, ("wf_dense",), np.append(np.ones(N), 1.0))
 run(_lib.MODEL_GRU1D, N, 50, 2, 500, ("wf_dense",), np.append(np.ones(N), 1.0))
 run(_lib.MODEL_GRU1D, 80, 100, 3, 10000, ("wf_dense",), np.append(np.ones(80), 1.0))
+for H in (100, 128, 256):
+    run(_lib.MODEL_GRU1D, 20, H, 1, 500, ("wf_dense",), np.append(np.ones(20), 1.0))
+run(_lib.MODEL_GRU1D, 80, 128, 1, 10000, ("wf_dense",), np.append(np.ones(80), 1.0))
+run(_lib.MODEL_GRU1D, 80, 256, 1, 10000, ("wf_dense",), np.append(np.ones(80), 1.0))
+run(_lib.MODEL_CRNN_U1, 40, 256, 1, 10000, ("wf_dense_ampl", "wf_dense_phase"), np.concatenate([np.ones(40), 0.5 * np.ones(40), np.zeros(40), [0.0, 0.0]]))
