@@ -161,6 +161,7 @@ struct GLaunch {
                 case 2: { using K = GLaunch<double, 2, 4, 1>; EXPR; }   \
                 case 3: { using K = GLaunch<double, 3, 4, 1>; EXPR; }   \
                 case 4: { using K = GLaunch<double, 4, 4, 1>; EXPR; }   \
+                case 6: { using K = GLaunch<double, 6, 8, 1>; EXPR; }   /* 8 waves: see the complex RNN's wide cases */ \
             }                                                           \
         } else {                                                        \
             switch ((h)->NFULL) {                                       \

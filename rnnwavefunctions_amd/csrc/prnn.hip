@@ -157,6 +157,7 @@ struct MLaunchL {
                 case 2: { using K = Launch<double, 2, 4>; EXPR; }                           \
                 case 3: { using K = Launch<double, 3, 4>; EXPR; }                           \
                 case 4: { using K = Launch<double, 4, 8>; EXPR; }                           \
+                case 6: { using K = Launch<double, 6, 4>; EXPR; }                           \
             }                                                                               \
         }                                                                                   \
     } while (0)

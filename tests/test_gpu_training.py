@@ -204,7 +204,8 @@ def test_mdrnn_gradient_matches_finite_differences_of_the_oracle(Nx, Ny, H, ns):
     assert worst < 1e-6
 
 
-@pytest.mark.parametrize("Nx,Ny,H,ns", [(3, 3, 6, 64), (4, 3, 20, 48), (3, 4, 50, 32), (3, 3, 60, 24), (3, 2, 68, 24)])
+@pytest.mark.parametrize("Nx,Ny,H,ns", [(3, 3, 6, 64), (4, 3, 20, 48), (3, 4, 50, 32), (3, 3, 60, 24), (3, 2, 68, 24),
+                                        (3, 2, 69, 24), (2, 2, 100, 16)])      # 69..100 units: the image is read through L2
 def test_gru_f64_gradient_matches_finite_differences_of_the_oracle(Nx, Ny, H, ns):
     from rnnwavefunctions_amd import _lib
     from rnnwavefunctions_amd.training import cost_gradient
