@@ -517,11 +517,15 @@ extern "C" int rnnwf_get_grad(rnnwf_handle* h, const char* name, void* data, int
     if (!h || !name || !data) return RNNWF_ERR_INVALID;
     auto it = h->grads.find(name);
     if (it == h->grads.end()) return h->fail(RNNWF_ERR_STATE, "no gradient for '%s' (call rnnwf_vmc_gradient first)", name);
-    if ((int64_t)it->second.size() != count)
+    auto ps = h->params.find(name);                  // the gradient is computed for the padded parameter; the caller gets its own shape
+    if (ps == h->params.end() || it->second.size() != ps->second.value.size())
+        return h->fail(RNNWF_ERR_STATE, "gradient '%s' does not match a parameter of this model", name);
+    const std::vector<int64_t>& slot = ps->second.slot;
+    if ((int64_t)slot.size() != count)
         return h->fail(RNNWF_ERR_INVALID, "gradient '%s' has %lld elements, caller passed %lld", name,
-                       (long long)it->second.size(), (long long)count);
-    if (dtype == RNNWF_F32) for (int64_t i = 0; i < count; ++i) ((float*)data)[i] = (float)it->second[i];
-    else if (dtype == RNNWF_F64) for (int64_t i = 0; i < count; ++i) ((double*)data)[i] = it->second[i];
+                       (long long)slot.size(), (long long)count);
+    if (dtype == RNNWF_F32) for (int64_t i = 0; i < count; ++i) ((float*)data)[i] = (float)it->second[slot[i]];
+    else if (dtype == RNNWF_F64) for (int64_t i = 0; i < count; ++i) ((double*)data)[i] = it->second[slot[i]];
     else return h->fail(RNNWF_ERR_INVALID, "unknown dtype %d", dtype);
     return RNNWF_OK;
 }

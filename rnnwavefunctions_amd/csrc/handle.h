@@ -37,8 +37,11 @@ struct Knobs {
 };
 
 struct ParamSpec {
-    std::vector<int64_t> shape;
-    std::vector<double> value;  // stored in f64, converted to the model type when packed
+    std::vector<int64_t> shape; // as the caller sees it (the reference's TF variable)
+    std::vector<double> value;  // stored in f64, converted to the model type when packed.  Layers of unequal width are held PADDED
+                                // to the widest layer (zeros: a padded unit stays exactly 0 and feeds nothing), so that the packers
+                                // and kernels see one width; `slot` maps the caller's flat index to the padded one.
+    std::vector<int64_t> slot;  // size = number of elements the caller sees
     bool set = false;
 };
 

@@ -18,13 +18,27 @@ static std::string g_create_error;
 // -------------------------------------------------------------------------------------------------
 // parameter table per model
 // -------------------------------------------------------------------------------------------------
-static void declare(rnnwf_handle* h, const std::string& name, std::vector<int64_t> shape) {
+// rows / cols: segments (true length, padded length) of the two axes (a vector has one row segment {1, 1}); the caller's element
+// (i, j) lands at the padded position of its segment
+typedef std::vector<std::pair<int64_t, int64_t>> Segs;
+static void declare(rnnwf_handle* h, const std::string& name, std::vector<int64_t> shape, const Segs& rows, const Segs& cols) {
     ParamSpec s;
     s.shape = shape;
-    int64_t n = 1;
-    for (auto d : shape) n *= d;
-    s.value.assign((size_t)n, 0.0);
+    int64_t tr = 0, tc = 0, pr = 0, pc = 0;
+    for (auto& g : rows) { tr += g.first; pr += g.second; }
+    for (auto& g : cols) { tc += g.first; pc += g.second; }
+    s.value.assign((size_t)(pr * pc), 0.0);
+    std::vector<int64_t> rmap, cmap;
+    { int64_t off = 0; for (auto& g : rows) { for (int64_t i = 0; i < g.first; ++i) rmap.push_back(off + i); off += g.second; } }
+    { int64_t off = 0; for (auto& g : cols) { for (int64_t j = 0; j < g.first; ++j) cmap.push_back(off + j); off += g.second; } }
+    s.slot.reserve((size_t)(tr * tc));
+    for (int64_t i = 0; i < tr; ++i)
+        for (int64_t j = 0; j < tc; ++j) s.slot.push_back(rmap[i] * pc + cmap[j]);
     h->params[name] = s;
+}
+static void declare(rnnwf_handle* h, const std::string& name, std::vector<int64_t> shape) {      // nothing padded
+    if (shape.size() == 1) declare(h, name, shape, {{1, 1}}, {{shape[0], shape[0]}});
+    else declare(h, name, shape, {{shape[0], shape[0]}}, {{shape[1], shape[1]}});
 }
 
 static void declare_params(rnnwf_handle* h) {
@@ -39,29 +53,25 @@ static void declare_params(rnnwf_handle* h) {
         declare(h, "wf_dense/bias", {2});
         return;
     }
-    const std::string pre = kGruPre;
-    declare(h, pre + "gates/kernel", {2 + H, 2 * H});
-    declare(h, pre + "gates/bias", {2 * H});
-    declare(h, pre + "candidate/input_projection/kernel", {2, H});
-    declare(h, pre + "candidate/input_projection/bias", {H});
-    declare(h, pre + "candidate/hidden_projection/kernel", {H, H});
-    declare(h, pre + "candidate/hidden_projection/bias", {H});
-    for (int l = 1; l < h->NL; ++l) {
+    // layer l of width w_l (input width d_l: 2 for the first layer, w_{l-1} above), everything padded to H = max w
+    for (int l = 0; l < h->NL; ++l) {
         const std::string pl = "multi_rnn_cell/cell_" + std::to_string(l) + "/cudnn_compatible_gru_cell/";
-        declare(h, pl + "gates/kernel", {H + H, 2 * H});
-        declare(h, pl + "gates/bias", {2 * H});
-        declare(h, pl + "candidate/input_projection/kernel", {H, H});
-        declare(h, pl + "candidate/input_projection/bias", {H});
-        declare(h, pl + "candidate/hidden_projection/kernel", {H, H});
-        declare(h, pl + "candidate/hidden_projection/bias", {H});
+        const int64_t w = h->cfg.units[l], d = l ? h->cfg.units[l - 1] : 2, dp = l ? H : 2;
+        declare(h, pl + "gates/kernel", {d + w, 2 * w}, {{d, dp}, {w, H}}, {{w, H}, {w, H}});
+        declare(h, pl + "gates/bias", {2 * w}, {{1, 1}}, {{w, H}, {w, H}});
+        declare(h, pl + "candidate/input_projection/kernel", {d, w}, {{d, dp}}, {{w, H}});
+        declare(h, pl + "candidate/input_projection/bias", {w}, {{1, 1}}, {{w, H}});
+        declare(h, pl + "candidate/hidden_projection/kernel", {w, w}, {{w, H}}, {{w, H}});
+        declare(h, pl + "candidate/hidden_projection/bias", {w}, {{1, 1}}, {{w, H}});
     }
+    const int64_t wt = h->cfg.units[h->NL - 1];
     if (h->model == RNNWF_MODEL_CRNN_U1) {
-        declare(h, "wf_dense_ampl/kernel", {H, 2});
+        declare(h, "wf_dense_ampl/kernel", {wt, 2}, {{wt, H}}, {{2, 2}});
         declare(h, "wf_dense_ampl/bias", {2});
-        declare(h, "wf_dense_phase/kernel", {H, 2});
+        declare(h, "wf_dense_phase/kernel", {wt, 2}, {{wt, H}}, {{2, 2}});
         declare(h, "wf_dense_phase/bias", {2});
     } else {
-        declare(h, "wf_dense/kernel", {H, 2});
+        declare(h, "wf_dense/kernel", {wt, 2}, {{wt, H}}, {{2, 2}});
         declare(h, "wf_dense/bias", {2});
     }
 }
@@ -136,13 +146,13 @@ extern "C" int rnnwf_create(const rnnwf_config* cfg, rnnwf_handle** out) {
         if (cfg->model == RNNWF_MODEL_MDRNN2D)
             return bad("rnnwf_create: the 2D RNN has one layer (the reference: 'num_layers is not supported yet', 2DTFIM_2DRNN/run_2dTFIM.py:9)");
         for (int l = 1; l < cfg->num_layers; ++l)
-            if (cfg->units[l] != cfg->units[0]) return bad("rnnwf_create: stacked layers must have equal num_units");
+            if (cfg->units[l] < 1) return bad("rnnwf_create: every units[n] must be positive");
         // two layer images (one forward + its two backward operands in the gradient pass) must fit the 160 KB of LDS;
         // a third layer's image is read through L2 where three do not fit (layout.h: MlSpill)
         if (cfg->model == RNNWF_MODEL_GRU1D_F64) {
-            if (cfg->units[0] > 68)
+            if (*std::max_element(cfg->units, cfg->units + cfg->num_layers) > 68)
                 return bad("rnnwf_create: stacked float64 layers: num_units <= 68");
-        } else if (cfg->units[0] > 100) {
+        } else if (*std::max_element(cfg->units, cfg->units + cfg->num_layers) > 100) {
             // (above 52 units the upper layers' images are read through L2: layout.h, MlSpill)
             return bad("rnnwf_create: stacked layers: num_units <= 100");
         }
@@ -163,7 +173,7 @@ extern "C" int rnnwf_create(const rnnwf_config* cfg, rnnwf_handle** out) {
     h->cfg = *cfg;
     h->model = cfg->model;
     h->f64 = cfg->model == RNNWF_MODEL_GRU1D_F64 || cfg->model == RNNWF_MODEL_MDRNN2D;
-    h->H = cfg->units[0];
+    h->H = *std::max_element(cfg->units, cfg->units + cfg->num_layers);      // layers of unequal width are padded to the widest (handle.h: ParamSpec)
     h->Nx = cfg->nx;
     h->Ny = cfg->ny;
     h->N = cfg->nx * cfg->ny;
@@ -224,9 +234,9 @@ static int find_param(rnnwf_handle* h, const char* name, int64_t count, ParamSpe
     if (!name) return h->fail(RNNWF_ERR_INVALID, "parameter name is null");
     auto it = h->params.find(name);
     if (it == h->params.end()) return h->fail(RNNWF_ERR_INVALID, "unknown parameter '%s' for this model", name);
-    if ((int64_t)it->second.value.size() != count)
+    if ((int64_t)it->second.slot.size() != count)
         return h->fail(RNNWF_ERR_INVALID, "parameter '%s' has %lld elements, caller passed %lld", name,
-                       (long long)it->second.value.size(), (long long)count);
+                       (long long)it->second.slot.size(), (long long)count);
     *out = &it->second;
     return 0;
 }
@@ -235,8 +245,8 @@ extern "C" int rnnwf_set_param(rnnwf_handle* h, const char* name, const void* da
     if (!h || !data) return RNNWF_ERR_INVALID;
     ParamSpec* p;
     if (int rc = find_param(h, name, count, &p)) return rc;
-    if (dtype == RNNWF_F32) for (int64_t i = 0; i < count; ++i) p->value[i] = ((const float*)data)[i];
-    else if (dtype == RNNWF_F64) for (int64_t i = 0; i < count; ++i) p->value[i] = ((const double*)data)[i];
+    if (dtype == RNNWF_F32) for (int64_t i = 0; i < count; ++i) p->value[p->slot[i]] = ((const float*)data)[i];
+    else if (dtype == RNNWF_F64) for (int64_t i = 0; i < count; ++i) p->value[p->slot[i]] = ((const double*)data)[i];
     else return h->fail(RNNWF_ERR_INVALID, "unknown dtype %d", dtype);
     p->set = true;
     h->committed = false;
@@ -247,15 +257,15 @@ extern "C" int rnnwf_get_param(rnnwf_handle* h, const char* name, void* data, in
     if (!h || !data) return RNNWF_ERR_INVALID;
     ParamSpec* p;
     if (int rc = find_param(h, name, count, &p)) return rc;
-    if (dtype == RNNWF_F32) for (int64_t i = 0; i < count; ++i) ((float*)data)[i] = (float)p->value[i];
-    else if (dtype == RNNWF_F64) for (int64_t i = 0; i < count; ++i) ((double*)data)[i] = p->value[i];
+    if (dtype == RNNWF_F32) for (int64_t i = 0; i < count; ++i) ((float*)data)[i] = (float)p->value[p->slot[i]];
+    else if (dtype == RNNWF_F64) for (int64_t i = 0; i < count; ++i) ((double*)data)[i] = p->value[p->slot[i]];
     else return h->fail(RNNWF_ERR_INVALID, "unknown dtype %d", dtype);
     return RNNWF_OK;
 }
 
 extern "C" int64_t rnnwf_num_params(const rnnwf_handle* h) {
     int64_t n = 0;
-    if (h) for (auto& kv : h->params) n += (int64_t)kv.second.value.size();
+    if (h) for (auto& kv : h->params) n += (int64_t)kv.second.slot.size();
     return n;
 }
 
@@ -266,12 +276,15 @@ extern "C" int rnnwf_init_params(rnnwf_handle* h, uint64_t seed) {
     const int64_t H = h->H;
     const bool f32 = !h->f64;
     auto draw = [&](const std::string& name, int64_t rows, int64_t cols, bool vector = false) {
-        glorot_fill(rng, rows, cols, vector, f32, h->params.at(name).value);
-        h->params.at(name).set = true;
+        auto& p = h->params.at(name);
+        std::vector<double> tmp;                               // the caller's shape (what the numpy stream is drawn for), then padded
+        glorot_fill(rng, rows, cols, vector, f32, tmp);
+        for (size_t i = 0; i < p.slot.size(); ++i) p.value[p.slot[i]] = tmp[i];
+        p.set = true;
     };
     auto constant = [&](const std::string& name, double v) {
         auto& p = h->params.at(name);
-        std::fill(p.value.begin(), p.value.end(), v);
+        for (size_t i = 0; i < p.slot.size(); ++i) p.value[p.slot[i]] = v;          // padded entries stay 0
         p.set = true;
     };
     if (h->model == RNNWF_MODEL_MDRNN2D) {                 // params.init_mdrnn_params: every tensor xavier, incl. b
@@ -283,24 +296,25 @@ extern "C" int rnnwf_init_params(rnnwf_handle* h, uint64_t seed) {
         draw("wf_dense/kernel", H, 2);
         constant("wf_dense/bias", 0.0);
     } else {                                               // params.init_gru_params
-        int64_t d = 2;
+        int64_t d = 2, w = H;
         for (int l = 0; l < h->NL; ++l) {
             const std::string pre = "multi_rnn_cell/cell_" + std::to_string(l) + "/cudnn_compatible_gru_cell/";
-            draw(pre + "gates/kernel", d + H, 2 * H);
+            w = h->cfg.units[l];
+            draw(pre + "gates/kernel", d + w, 2 * w);
             constant(pre + "gates/bias", 1.0);
-            draw(pre + "candidate/input_projection/kernel", d, H);
+            draw(pre + "candidate/input_projection/kernel", d, w);
             constant(pre + "candidate/input_projection/bias", 0.0);
-            draw(pre + "candidate/hidden_projection/kernel", H, H);
+            draw(pre + "candidate/hidden_projection/kernel", w, w);
             constant(pre + "candidate/hidden_projection/bias", 0.0);
-            d = H;
+            d = w;
         }
         if (h->model == RNNWF_MODEL_CRNN_U1) {
-            draw("wf_dense_ampl/kernel", H, 2);
+            draw("wf_dense_ampl/kernel", w, 2);
             constant("wf_dense_ampl/bias", 0.0);
-            draw("wf_dense_phase/kernel", H, 2);
+            draw("wf_dense_phase/kernel", w, 2);
             constant("wf_dense_phase/bias", 0.0);
         } else {
-            draw("wf_dense/kernel", H, 2);
+            draw("wf_dense/kernel", w, 2);
             constant("wf_dense/bias", 0.0);
         }
     }

@@ -508,11 +508,44 @@ def test_stacked_layers_sampling_vmc_step_and_parity_model():
     assert np.allclose(wfp.log_prob(sp), ref, rtol=0, atol=4e-6 * N + 2e-6)
 
 
+@pytest.mark.parametrize("N,units,B", [(12, (20, 10), 40), (10, (10, 20), 33), (9, (36, 50, 20), 24), (8, (50, 7, 33), 17), (7, (64, 20), 20),
+                                        (6, (30, 100), 16)])
+def test_stacked_layers_of_unequal_width(N, units, B):
+    """`units` is any list in the reference's constructor (1DTFIM/RNNwavefunction.py:32: MultiRNNCell([cell(units[n]) ...])).  Layers
+    narrower than the widest are held zero-padded inside the library (a padded unit stays exactly 0 and feeds nothing); the caller
+    sees the reference's shapes.  log P and local energies against the float64 oracle; the library's own initialiser gives
+    params.init_gru_params' values."""
+    from rnnwavefunctions_amd import _lib
+    prm = P.randomize_biases(P.scale_kernels(P.init_gru_params(list(units), seed=sum(units)), 1.6), 5)
+    wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D, N, 1, units)
+    wf.set_params(prm, scope=SCOPE)
+    assert wf.num_params() == P.count_params(prm)
+    for k, v in prm.items():
+        assert np.array_equal(wf.get_param(k[len(SCOPE) + 1:], v.shape, np.float32), v), k
+    rng = np.random.RandomState(N)
+    s = rng.randint(0, 2, (B, N)).astype(np.int32)
+    prm64 = {k: v.astype(np.float64) for k, v in prm.items()}
+    ref64 = M.prnn_log_probability(prm64, s, dtype=np.float64)
+    got = wf.log_prob(s)
+    print("units=%s N=%d: |hip-oracle64|=%.2e" % (units, N, np.abs(got - ref64).max()))
+    assert np.abs(got - ref64).max() <= 2e-6 * N * len(units) + 2e-6
+    Jz = 1.0 + 0.1 * rng.standard_normal(N)
+    e = wf.tfim_eloc(s, Jz, 0.8)
+    e64 = E.ising_local_energies(Jz, 0.8, s, lambda x: M.prnn_log_probability(prm64, x, dtype=np.float64))
+    assert np.abs(e - e64).max() <= 3e-5 * max(1.0, np.abs(e64).max())        # (a local energy may sit near zero)
+    wf2 = _lib.NativeWavefunction(_lib.MODEL_GRU1D, N, 1, units)
+    wf2.init_params(77)
+    ini = P.init_gru_params(list(units), seed=77)
+    for k, v in ini.items():
+        assert np.array_equal(wf2.get_param(k[len(SCOPE) + 1:], v.shape, np.float32), v), k
+    drawn = wf2.sample(50, seed=1, step=0)
+    assert np.allclose(wf2.log_prob(drawn), M.prnn_log_probability(ini, drawn), rtol=0, atol=1e-4)
+
+
 def test_stacked_layers_limits_and_facade():
     from rnnwavefunctions_amd import _lib
     from rnnwavefunctions_amd.TFIM1D.RNNwavefunction import RNNwavefunction
-    with pytest.raises(ValueError, match="equal num_units"):
-        _lib.NativeWavefunction(_lib.MODEL_GRU1D, 10, 1, (20, 10))
+    _lib.NativeWavefunction(_lib.MODEL_GRU1D, 10, 1, (20, 10))          # unequal widths: padded to the widest layer inside the library
     _lib.NativeWavefunction(_lib.MODEL_GRU1D, 10, 1, (64, 64))          # above 52 units the upper layers' images are read through L2
     with pytest.raises(ValueError, match="num_units <= 100"):
         _lib.NativeWavefunction(_lib.MODEL_GRU1D, 10, 1, (104, 104))

@@ -399,6 +399,37 @@ def test_stacked_complex_gradient_matches_finite_differences_of_the_oracle(N, H,
     assert worst < 2e-3
 
 
+@pytest.mark.parametrize("model,N,units,ns", [("gru", 6, (20, 10), 48), ("gru", 5, (10, 36, 20), 40), ("gru", 5, (64, 20), 24),
+                                             ("crnn", 8, (20, 36), 32), ("gru64", 6, (20, 12), 32)])
+def test_gradient_with_layers_of_unequal_width_matches_finite_differences(model, N, units, ns):
+    """The gradient arrives in the caller's shapes (the padded entries inside the library have zero gradient and are dropped)."""
+    from rnnwavefunctions_amd import _lib
+    from rnnwavefunctions_amd.training import cost_gradient
+    if model == "crnn":
+        prm = P.randomize_biases(P.scale_kernels(P.init_gru_params(list(units), seed=3, heads=("wf_dense_ampl", "wf_dense_phase")), 1.5), 4)
+        wf = _lib.NativeWavefunction(_lib.MODEL_CRNN_U1, N, 1, units)
+        couplings = np.concatenate([np.ones(N), 0.5 * np.ones(N), np.zeros(N), [0.0, 0.0]])
+    elif model == "gru64":
+        prm = P.randomize_biases(P.scale_kernels(P.init_gru_params(list(units), seed=3, dtype=np.float64), 1.5), 4)
+        wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D_F64, 3, 2, units)
+        couplings = np.append(np.ones(N), 2.0)
+    else:
+        prm = P.randomize_biases(P.scale_kernels(P.init_gru_params(list(units), seed=3), 1.5), 4)
+        wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D, N, 1, units)
+        couplings = np.append(np.ones(N), 1.0)
+    wf.set_params(prm, scope=SCOPE)
+    out = wf.vmc_step(ns, seed=3, step=0, couplings=couplings, want_samples=True, want_eloc=True)
+    s = out["samples"].reshape(ns, N)
+    e = out["eloc"].astype(np.complex128) if model == "crnn" else out["eloc"]
+    grads = cost_gradient(wf, prm, SCOPE, e.mean(), ns)
+    assert set(grads) == set(prm) and all(grads[k].shape == prm[k].shape for k in prm)
+    prm64 = {k: v.astype(np.float64) for k, v in prm.items()}
+    cost = (lambda: oracle_cost_complex(prm64, s, e)) if model == "crnn" else (lambda: oracle_cost(prm64, s, e))
+    worst = _fd_check(grads, prm64, cost)
+    print("%s units=%s: max |grad - FD| / max|grad| = %.2e" % (model, units, worst))
+    assert worst < (1e-6 if model == "gru64" else 2e-3)
+
+
 def test_run_j1j2_with_two_layers_trains():
     """run_J1J2(num_layers=2) (J1J2/TrainingRNN_J1J2.py:130,148): the energy falls towards the N=10 ground state."""
     from rnnwavefunctions_amd.J1J2.TrainingRNN_J1J2 import run_J1J2
