@@ -565,6 +565,11 @@ def test_stacked_layers_limits_and_facade():
     smp = wf._native.sample(50, seed=111, step=0)
     lp = wf._native.log_prob(smp)
     assert np.allclose(lp, M.prnn_log_probability(prm, smp), rtol=0, atol=1e-4)
+    wf = RNNwavefunction(10, cell="CudnnCompatibleGRUCell", units=[20, 10], seed=111)       # any list, as in the reference
+    prm = wf.get_params()
+    assert prm[SCOPE + "/multi_rnn_cell/cell_1/cudnn_compatible_gru_cell/gates/kernel"].shape == (30, 20)
+    smp = wf._native.sample(50, seed=111, step=0)
+    assert np.allclose(wf._native.log_prob(smp), M.prnn_log_probability(prm, smp), rtol=0, atol=1e-4)
 
 
 @pytest.mark.parametrize("H", [10, 20, 36, 37, 44, 50, 51, 52, 53, 60, 64, 68, 69, 85, 100])
