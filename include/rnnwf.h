@@ -63,7 +63,7 @@ typedef struct {
                                       /* <= 100 units, float64: <= 68) for the GRU models          */
     int32_t units[RNNWF_MAX_LAYERS];  /* units[n]: one layer <= 260 (float GRU models; above 100 the */
                                       /* weight image is read through L2), <= 100 (float64 GRU;   */
-                                      /* above 68 likewise), <= 68 (2D RNN)                       */
+                                      /* above 68 likewise), <= 84 (2D RNN)                       */
     int32_t device;                   /* HIP device ordinal                                       */
     int32_t reserved[6];
 } rnnwf_config;

@@ -159,16 +159,17 @@ struct MLaunch {
             case 2: { using K = MLaunch<2, 4>; EXPR; }          \
             case 3: { using K = MLaunch<3, 4>; EXPR; }          \
             case 4: { using K = MLaunch<4, 4>; EXPR; }          \
+            case 5: { using K = MLaunch<5, 4>; EXPR; }          \
         }                                                       \
     } while (0)
 
 int launch_base(rnnwf_handle* h, const MdArgs& a) {
     MD_DISPATCH(h, return K::base(h, a));
-    return h->fail(RNNWF_ERR_INVALID, "MDRNN: num_units > 68 is not implemented on gfx950 yet");
+    return h->fail(RNNWF_ERR_INVALID, "MDRNN: num_units > 84 is not implemented on gfx950 yet");
 }
 int launch_flip(rnnwf_handle* h, const MdArgs& a) {
     MD_DISPATCH(h, return K::flip(h, a));
-    return h->fail(RNNWF_ERR_INVALID, "MDRNN: num_units > 68 is not implemented on gfx950 yet");
+    return h->fail(RNNWF_ERR_INVALID, "MDRNN: num_units > 84 is not implemented on gfx950 yet");
 }
 size_t hs_bytes_per_block(rnnwf_handle* h) {
     MD_DISPATCH(h, return K::hs_bytes_per_block());
@@ -260,7 +261,7 @@ int eloc_on_device(rnnwf_handle* h, int64_t ns, const Maps& m, bool sampling, ui
 int rnnwf::mdrnn_pack_image(rnnwf_handle* h, std::vector<char>& img) {
     if (h->N > 256) return h->fail(RNNWF_ERR_INVALID, "MDRNN: lattices above 256 sites are not implemented");
     MD_DISPATCH(h, { img = K::pack(h); return 0; });
-    return h->fail(RNNWF_ERR_INVALID, "MDRNN: num_units > 68 is not implemented on gfx950 yet");
+    return h->fail(RNNWF_ERR_INVALID, "MDRNN: num_units > 84 is not implemented on gfx950 yet");
 }
 
 int rnnwf::mdrnn_log_prob(rnnwf_handle* h, const int32_t* samples, int64_t B, double* out) {
@@ -467,13 +468,14 @@ struct MGrad {
             case 2: { using K = MGrad<2, 4>; EXPR; }            \
             case 3: { using K = MGrad<3, 4>; EXPR; }            \
             case 4: { using K = MGrad<4, 4>; EXPR; }            \
+            case 5: { using K = MGrad<5, 4>; EXPR; }            \
         }                                                       \
     } while (0)
 
 }  // namespace
 
 int rnnwf::mdrnn_vmc_gradient(rnnwf_handle* h, double mean_energy, double norm) {
-    if (h->NFULL > 4) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: num_units > 68 not implemented");
+    if (h->NFULL > 5) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: num_units > 84 not implemented");
     if (h->last_ns <= 0 || !h->last_has_ckpt)
         return h->fail(RNNWF_ERR_STATE, "rnnwf_vmc_gradient: call rnnwf_vmc_step first (its samples, states and E_loc are reused)");
     if (!(norm > 0)) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: norm must be positive");

@@ -105,10 +105,11 @@ int rnnwf::upload_couplings(rnnwf_handle* h, const double* src, size_t n) {
 }
 
 static int pick_nfull(int H, bool f64, bool mdrnn) {
-    const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16};
+    const int cand[] = {1, 2, 3, 4, 5, 6, 8, 12, 16};
     for (int nf : cand) {
+        if (nf == 5 && !mdrnn) continue;          // (the 84-unit layout exists for the 2D RNN only)
         if (16 * nf + 4 < H) continue;
-        if (mdrnn && nf > 4) return -1;           // the 2D RNN's image must fit the 160 KiB LDS
+        if (mdrnn && nf > 5) return -1;           // the 2D RNN's image must fit the 160 KiB LDS: <= 84 units
         if (f64 && nf > 6) return -1;             // float64 GRU: <= 100 units (above 68 the image is read through L2)
         return nf;                                // float GRU above 100 units (nf 8, 12, 16: <= 132, 196, 260): image read through L2
     }
@@ -181,7 +182,7 @@ extern "C" int rnnwf_create(const rnnwf_config* cfg, rnnwf_handle** out) {
     h->NFULL = pick_nfull(h->H, h->f64, h->model == RNNWF_MODEL_MDRNN2D);
     if (h->NFULL < 0) {
         delete h;
-        return bad("rnnwf_create: num_units too large (f32 GRU: <= 260, f64 GRU: <= 100, 2D RNN: <= 68)");
+        return bad("rnnwf_create: num_units too large (f32 GRU: <= 260, f64 GRU: <= 100, 2D RNN: <= 84)");
     }
     auto fail_hip = [&](const char* what, hipError_t err) {
         g_create_error = std::string("rnnwf_create: ") + what + ": " + hipGetErrorString(err);

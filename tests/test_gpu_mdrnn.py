@@ -23,7 +23,7 @@ def make_wf(Nx, Ny, H, prm):
 
 
 @pytest.mark.parametrize("Nx,Ny,H,B", [(4, 4, 9, 40), (3, 5, 20, 33), (6, 6, 50, 50), (12, 12, 50, 20), (5, 4, 36, 17),
-                                        (4, 3, 64, 19)])
+                                        (4, 3, 64, 19), (4, 3, 68, 19), (3, 4, 69, 17), (4, 4, 84, 20)])      # 69..84 units: the five-tile layout
 def test_log_prob_matches_oracle(Nx, Ny, H, B):
     prm = P.scale_kernels(P.init_mdrnn_params(H, seed=H), 1.5 if Nx * Ny <= 64 else 1.0)
     wf = make_wf(Nx, Ny, H, prm)
@@ -55,7 +55,7 @@ def test_tfim2d_eloc_matches_reference_golden(golden_estimators):
     assert np.allclose(e, g["g4b_eloc"], rtol=1e-10)
 
 
-@pytest.mark.parametrize("Nx,Ny,H,ns", [(5, 3, 20, 37), (6, 6, 50, 16), (3, 6, 9, 70)])
+@pytest.mark.parametrize("Nx,Ny,H,ns", [(5, 3, 20, 37), (6, 6, 50, 16), (3, 6, 9, 70), (4, 3, 72, 21), (3, 3, 84, 17)])
 def test_tfim2d_eloc_fused_equals_reference_formulation(Nx, Ny, H, ns):
     prm = P.scale_kernels(P.init_mdrnn_params(H, seed=7), 1.5)
     wf = make_wf(Nx, Ny, H, prm)

@@ -183,7 +183,7 @@ def _fd_check(grads, prm64, cost, n_per_tensor=10, eps=1e-6):
     return worst
 
 
-@pytest.mark.parametrize("Nx,Ny,H,ns", [(3, 3, 6, 64), (4, 3, 20, 48), (3, 4, 50, 32), (5, 2, 64, 20)])
+@pytest.mark.parametrize("Nx,Ny,H,ns", [(3, 3, 6, 64), (4, 3, 20, 48), (3, 4, 50, 32), (5, 2, 64, 20), (3, 3, 70, 20), (3, 2, 84, 16)])
 def test_mdrnn_gradient_matches_finite_differences_of_the_oracle(Nx, Ny, H, ns):
     from rnnwavefunctions_amd import _lib
     from rnnwavefunctions_amd.training import cost_gradient
