@@ -59,7 +59,7 @@ typedef struct {
     int32_t model;                    /* rnnwf_model                                              */
     int32_t nx;                       /* systemsize (1D) or systemsize_x (2D)                     */
     int32_t ny;                       /* 1 for 1D models, systemsize_y for 2D                     */
-    int32_t num_layers;               /* len(units) of the reference ctor: 1; 2..3 (any widths     */
+    int32_t num_layers;               /* len(units) of the reference ctor: 1; 2..4 (any widths     */
                                       /* <= 100 units, float64: <= 68) for the GRU models          */
     int32_t units[RNNWF_MAX_LAYERS];  /* units[n]: one layer <= 260 (float GRU models; above 100 the */
                                       /* weight image is read through L2), <= 100 (float64 GRU;   */

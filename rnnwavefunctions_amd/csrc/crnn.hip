@@ -112,6 +112,16 @@ struct CMLaunch {
             }                                                   \
             break;                                              \
         }                                                       \
+        if ((h)->NL == 4) {                                     \
+            switch ((h)->NFULL) {                               \
+                case 1: { using K = CMLaunch<1, 4, 4>; EXPR; }  \
+                case 2: { using K = CMLaunch<2, 4, 4>; EXPR; }  \
+                case 3: { using K = CMLaunch<3, 4, 4>; EXPR; }  \
+                case 4: { using K = CMLaunch<4, 4, 4>; EXPR; }  \
+                case 6: { using K = CMLaunch<6, 4, 4>; EXPR; }  \
+            }                                                   \
+            break;                                              \
+        }                                                       \
         if ((h)->NL == 3) {                                     \
             switch ((h)->NFULL) {                               \
                 case 1: { using K = CMLaunch<1, 3, 4>; EXPR; }  \

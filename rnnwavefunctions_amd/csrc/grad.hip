@@ -408,6 +408,14 @@ struct MLGrad {
                 case 4: { using K = MLGrad<4, 2, 4, NOUT>; EXPR; }      \
                 case 6: { using K = MLGrad<6, 2, 4, NOUT>; EXPR; }      \
             }                                                           \
+        } else if ((h)->NL == 4) {                                      \
+            switch ((h)->NFULL) {                                       \
+                case 1: { using K = MLGrad<1, 4, 4, NOUT>; EXPR; }      \
+                case 2: { using K = MLGrad<2, 4, 4, NOUT>; EXPR; }      \
+                case 3: { using K = MLGrad<3, 4, 4, NOUT>; EXPR; }      \
+                case 4: { using K = MLGrad<4, 4, 4, NOUT>; EXPR; }      \
+                case 6: { using K = MLGrad<6, 4, 4, NOUT>; EXPR; }      \
+            }                                                           \
         } else if ((h)->NL == 3) {                                      \
             switch ((h)->NFULL) {                                       \
                 case 1: { using K = MLGrad<1, 3, 4, NOUT>; EXPR; }      \
@@ -430,6 +438,10 @@ struct MLGrad {
             if ((h)->NL == 2 && (h)->NFULL == 4) { using K = MLGrad<4, 2, 4, 1, double>; EXPR; } \
             if ((h)->NL == 3 && (h)->NFULL == 3) { using K = MLGrad<3, 3, 4, 1, double>; EXPR; } \
             if ((h)->NL == 3 && (h)->NFULL == 4) { using K = MLGrad<4, 3, 4, 1, double>; EXPR; } \
+            if ((h)->NL == 4 && (h)->NFULL == 1) { using K = MLGrad<1, 4, 4, 1, double>; EXPR; } \
+            if ((h)->NL == 4 && (h)->NFULL == 2) { using K = MLGrad<2, 4, 4, 1, double>; EXPR; } \
+            if ((h)->NL == 4 && (h)->NFULL == 3) { using K = MLGrad<3, 4, 4, 1, double>; EXPR; } \
+            if ((h)->NL == 4 && (h)->NFULL == 4) { using K = MLGrad<4, 4, 4, 1, double>; EXPR; } \
         } else MLGRAD_DISPATCH_(h, 1, EXPR);                            \
     } while (0)
 

@@ -124,6 +124,21 @@ struct MLaunchL {
                 case 3: { using K = MLaunchL<double, 3, 3, 4>; EXPR; }                      \
                 case 4: { using K = MLaunchL<double, 4, 3, 4>; EXPR; }                      \
             }                                                                               \
+        } else if ((h)->NL == 4 && (h)->f64) {                                              \
+            switch ((h)->NFULL) {                                                           \
+                case 1: { using K = MLaunchL<double, 1, 4, 4>; EXPR; }                      \
+                case 2: { using K = MLaunchL<double, 2, 4, 4>; EXPR; }                      \
+                case 3: { using K = MLaunchL<double, 3, 4, 4>; EXPR; }                      \
+                case 4: { using K = MLaunchL<double, 4, 4, 4>; EXPR; }                      \
+            }                                                                               \
+        } else if ((h)->NL == 4) {                                                          \
+            switch ((h)->NFULL) {                                                           \
+                case 1: { using K = MLaunchL<float, 1, 4, 4>; EXPR; }                       \
+                case 2: { using K = MLaunchL<float, 2, 4, 4>; EXPR; }                       \
+                case 3: { using K = MLaunchL<float, 3, 4, 4>; EXPR; }                       \
+                case 4: { using K = MLaunchL<float, 4, 4, 4>; EXPR; }                       \
+                case 6: { using K = MLaunchL<float, 6, 4, 4>; EXPR; }                       \
+            }                                                                               \
         } else if ((h)->NL == 2) {                                                          \
             switch ((h)->NFULL) {                                                           \
                 case 1: { using K = MLaunchL<float, 1, 2, 4>; EXPR; }                       \

@@ -138,8 +138,8 @@ extern "C" int rnnwf_create(const rnnwf_config* cfg, rnnwf_handle** out) {
     if (cfg->abi_version != RNNWF_ABI_VERSION) return bad("rnnwf_create: ABI version mismatch");
     if (cfg->model < 0 || cfg->model > RNNWF_MODEL_MDRNN2D) return bad("rnnwf_create: unknown model");
     if (cfg->nx < 1 || cfg->ny < 1) return bad("rnnwf_create: system size must be positive");
-    if (cfg->num_layers < 1 || cfg->num_layers > 3)
-        return bad("rnnwf_create: len(units) must be 1..3");
+    if (cfg->num_layers < 1 || cfg->num_layers > RNNWF_MAX_LAYERS)
+        return bad("rnnwf_create: len(units) must be 1..4");
     if (cfg->units[0] < 1) return bad("rnnwf_create: units[0] must be positive");
     if (cfg->num_layers > 1) {
         // MultiRNNCell stacks (1DTFIM/RNNwavefunction.py:32, J1J2/ComplexRNNwavefunction.py:40,

@@ -204,8 +204,8 @@ def run_1DTFIM(numsteps=10 ** 4, systemsize=20, num_units=50, Bx=1, num_layers=1
     (energies every 10 steps, TF checkpoint every 500), `restore=True` its restore branch (:172-183).
     `parity_symmetric=True` is the reference's import switch to RNNwavefunction_paritysym (1DTFIM/TrainingRNN_1DTFIM.py:10):
     P_sym(s) = (P(s) + P(reversed s)) / 2."""
-    if not 1 <= num_layers <= 3:
-        raise ValueError("num_layers must be 1..3 (stacked layers: num_units <= 100)")
+    if not 1 <= num_layers <= 4:
+        raise ValueError("num_layers must be 1..4 (stacked layers: num_units <= 100)")
     N = systemsize
     scope = "RNNwavefunction"
     Jz = +np.ones(N)
@@ -238,8 +238,8 @@ def run_J1J2(numsteps=10 ** 5, systemsize=20, J1_=1.0, J2_=0.0, Marshall_sign=Fa
     As in the reference, `Marshall_sign` reaches J1J2MatrixElements through J1J2Slices' `periodic` slot
     (J1J2/TrainingRNN_J1J2.py:118): Marshall_sign=True therefore selects the PERIODIC chain
     without a Marshall sign - reproduced here on purpose so that runs compare with the reference's."""
-    if not 1 <= num_layers <= 3:
-        raise ValueError("num_layers must be 1..3 (stacked layers: num_units <= 100)")
+    if not 1 <= num_layers <= 4:
+        raise ValueError("num_layers must be 1..4 (stacked layers: num_units <= 100)")
     N = systemsize
     scope = "RNNwavefunction"
     lr = np.float64(learningrate)
@@ -301,8 +301,8 @@ def run_2DTFIM_1DRNN(numsteps=2 * 10 ** 4, systemsize_x=5, systemsize_y=5, Bx=+2
     """Train the float64 1D GRU wave function over the raster path of the square lattice; learning rate
     1 / (1/lr + it/10)  (Training1DRNN_2DTFIM.py:231).  The reference seeds numpy / TF with `seed` but builds the
     wave function with its class default seed 111 (:104); the initial weights here follow the latter."""
-    if not 1 <= num_layers <= 3:
-        raise ValueError("num_layers must be 1..3 (stacked float64 layers: num_units <= 68)")
+    if not 1 <= num_layers <= 4:
+        raise ValueError("num_layers must be 1..4 (stacked float64 layers: num_units <= 68)")
     Nx, Ny = systemsize_x, systemsize_y
     lr = np.float64(learningrate)
     units = [num_units] * num_layers

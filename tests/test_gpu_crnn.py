@@ -306,7 +306,8 @@ def stacked_like(H, L, seed):
 
 @pytest.mark.parametrize("N,H,L,B", [(12, 10, 2, 40), (10, 20, 3, 33), (20, 50, 2, 24), (8, 36, 3, 17), (16, 52, 2, 16),
                                       (12, 50, 3, 24),
-                                      (10, 53, 2, 20), (8, 64, 3, 17), (10, 100, 2, 24), (8, 100, 3, 18)])   # 53..100 units: upper images through L2
+                                      (10, 53, 2, 20), (8, 64, 3, 17), (10, 100, 2, 24), (8, 100, 3, 18),   # 53..100 units: upper images through L2
+                                      (10, 20, 4, 24), (8, 64, 4, 17)])      # four layers
 def test_stacked_layers_log_amplitude_sampling_and_eloc_match_oracle(N, H, L, B):
     from rnnwavefunctions_amd import _lib
     prm = stacked_like(H, L, seed=N + H)

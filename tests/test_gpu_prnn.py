@@ -177,7 +177,8 @@ def test_gru_f64_on_2d_lattice_matches_reference_golden(golden_estimators):
 
 
 @pytest.mark.parametrize("Nx,Ny,H,L", [(3, 4, 7, 2), (4, 4, 20, 2), (3, 3, 36, 2), (4, 3, 10, 3), (3, 3, 20, 3), (4, 3, 36, 3),
-                                       (3, 3, 37, 2), (4, 4, 50, 2), (3, 3, 68, 2), (4, 3, 50, 3), (3, 2, 68, 3)])      # 37..68 units: upper images through L2
+                                       (3, 3, 37, 2), (4, 4, 50, 2), (3, 3, 68, 2), (4, 3, 50, 3), (3, 2, 68, 3),      # 37..68 units: upper images through L2
+                                       (3, 3, 20, 4), (3, 2, 50, 4)])
 def test_stacked_gru_f64_on_2d_lattice_matches_oracle(Nx, Ny, H, L):
     """2DTFIM_1DRNN with units=[num_units]*num_layers (Training1DRNN_2DTFIM.py:94): log-probabilities, the sampler's
     stream and the 2D local energies against the float64 oracle."""
@@ -461,7 +462,8 @@ def make_stacked(model, N, H, L, prm):
 
 @pytest.mark.parametrize("N,H,L,B", [(12, 20, 2, 40), (9, 10, 3, 33), (20, 50, 2, 24), (7, 36, 3, 17), (10, 4, 2, 16),
                                       (16, 52, 2, 16), (20, 50, 3, 24), (9, 52, 3, 70),      # 3 x 50: top layer's image read through L2
-                                      (8, 53, 2, 20), (9, 64, 2, 33), (7, 68, 3, 17), (6, 69, 2, 20), (8, 100, 2, 24), (6, 100, 3, 18)])   # 53..100 units: upper images through L2
+                                      (8, 53, 2, 20), (9, 64, 2, 33), (7, 68, 3, 17), (6, 69, 2, 20), (8, 100, 2, 24), (6, 100, 3, 18),   # 53..100 units: upper images through L2
+                                      (8, 20, 4, 24), (7, 50, 4, 20), (6, 100, 4, 16)])      # four layers
 def test_stacked_layers_log_prob_and_eloc_match_oracle(N, H, L, B):
     from rnnwavefunctions_amd import _lib
     prm = stacked_like(H, L, seed=H + L)
@@ -509,7 +511,7 @@ def test_stacked_layers_sampling_vmc_step_and_parity_model():
 
 
 @pytest.mark.parametrize("N,units,B", [(12, (20, 10), 40), (10, (10, 20), 33), (9, (36, 50, 20), 24), (8, (50, 7, 33), 17), (7, (64, 20), 20),
-                                        (6, (30, 100), 16)])
+                                        (6, (30, 100), 16), (9, (20, 10, 36, 12), 24)])
 def test_stacked_layers_of_unequal_width(N, units, B):
     """`units` is any list in the reference's constructor (1DTFIM/RNNwavefunction.py:32: MultiRNNCell([cell(units[n]) ...])).  Layers
     narrower than the widest are held zero-padded inside the library (a padded unit stays exactly 0 and feeds nothing); the caller

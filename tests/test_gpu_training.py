@@ -228,7 +228,8 @@ def test_gru_f64_gradient_matches_finite_differences_of_the_oracle(Nx, Ny, H, ns
 
 @pytest.mark.parametrize("Nx,Ny,H,L,ns", [(3, 3, 6, 2, 64), (4, 3, 20, 2, 48), (3, 3, 36, 2, 32), (3, 3, 10, 3, 40), (3, 2, 20, 3, 24),
                                           (3, 2, 36, 3, 24),
-                                          (3, 2, 37, 2, 24), (3, 3, 50, 2, 24), (2, 2, 68, 2, 20), (3, 2, 50, 3, 16), (2, 2, 68, 3, 16)])   # 37..68 units: images through L2
+                                          (3, 2, 37, 2, 24), (3, 3, 50, 2, 24), (2, 2, 68, 2, 20), (3, 2, 50, 3, 16), (2, 2, 68, 3, 16),   # 37..68 units: images through L2
+                                          (3, 2, 20, 4, 24)])
 def test_stacked_gru_f64_gradient_matches_finite_differences_of_the_oracle(Nx, Ny, H, L, ns):
     from rnnwavefunctions_amd import _lib
     from rnnwavefunctions_amd.training import cost_gradient
@@ -360,7 +361,8 @@ def test_two_process_sharded_training_reproduces_the_single_process_run(tmp_path
 # ---- stacked layers: gradient layer by layer, top first ---------------------------------------------------------
 
 @pytest.mark.parametrize("N,H,L,ns", [(6, 6, 2, 64), (8, 20, 2, 48), (7, 50, 2, 32), (6, 10, 3, 40), (5, 36, 3, 24), (6, 50, 3, 40),
-                                      (5, 53, 2, 32), (5, 64, 2, 24), (4, 68, 3, 24), (4, 100, 2, 24), (3, 100, 3, 16)])   # 53..100 units: images through L2
+                                      (5, 53, 2, 32), (5, 64, 2, 24), (4, 68, 3, 24), (4, 100, 2, 24), (3, 100, 3, 16),   # 53..100 units: images through L2
+                                      (5, 20, 4, 32), (4, 64, 4, 24)])      # four layers
 def test_stacked_gradient_matches_finite_differences_of_the_oracle(N, H, L, ns):
     from rnnwavefunctions_amd import _lib
     from rnnwavefunctions_amd.training import cost_gradient
@@ -378,7 +380,7 @@ def test_stacked_gradient_matches_finite_differences_of_the_oracle(N, H, L, ns):
 
 
 @pytest.mark.parametrize("N,H,L,ns", [(8, 10, 2, 64), (10, 20, 2, 48), (8, 50, 2, 32), (6, 10, 3, 40), (8, 36, 3, 24), (6, 50, 3, 24),
-                                      (6, 64, 2, 24), (4, 100, 2, 24), (4, 100, 3, 16)])   # 53..100 units: images through L2
+                                      (6, 64, 2, 24), (4, 100, 2, 24), (4, 100, 3, 16), (6, 20, 4, 32)])   # 53..100 units: images through L2; four layers
 def test_stacked_complex_gradient_matches_finite_differences_of_the_oracle(N, H, L, ns):
     """units=[10, 10] is the complex wave function's default (J1J2/ComplexRNNwavefunction.py:16); run_J1J2 builds
     [num_units] * num_layers (J1J2/TrainingRNN_J1J2.py:148)."""
