@@ -71,7 +71,7 @@ def test_empty_and_bad_inputs():
     with pytest.raises(ValueError):
         wf.set_params({"wf_dense/bias": np.zeros(3, dtype=np.float32)})
     with pytest.raises(ValueError):
-        _lib.NativeWavefunction(_lib.MODEL_GRU1D, 8, 1, (10, 10, 10, 10))   # more than three layers: loud refusal
+        _lib.NativeWavefunction(_lib.MODEL_GRU1D, 8, 1, (10, 10, 10, 10, 10))   # more than four layers: loud refusal
     wf2 = _lib.NativeWavefunction(_lib.MODEL_GRU1D, 8, 1, (10,))
     with pytest.raises(_lib.RnnwfError):
         wf2.log_prob(np.zeros((4, 8), dtype=np.int32))                   # parameters never committed
