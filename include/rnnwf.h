@@ -188,6 +188,11 @@ int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double mean_energy_i
  * complex64[ns] as float pairs (complex RNN).  Runs the teacher-forced pass that stores the hidden-state checkpoints.  */
 int rnnwf_load_batch(rnnwf_handle* h, const int32_t* samples, int64_t ns, const void* eloc);
 int rnnwf_get_grad(rnnwf_handle* h, const char* tf_name, void* data, int64_t count, int32_t dtype);
+/* One call per training iteration instead of one per tensor: every tensor in the reference's shapes, float64, concatenated in
+ * the byte-wise order of the names (rnnwf_param_name(h, i, &count) lists them).  rnnwf_set_params_flat commits. */
+int rnnwf_set_params_flat(rnnwf_handle* h, const double* flat, int64_t count);
+int rnnwf_get_grads_flat(rnnwf_handle* h, double* flat, int64_t count);
+const char* rnnwf_param_name(const rnnwf_handle* h, int32_t i, int64_t* count);
 int rnnwf_allreduce_grads(rnnwf_handle* h);
 
 /* ---- multi-GPU: one RCCL all-reduce of the energy moments -------------------------------------

@@ -50,6 +50,9 @@ PROTOTYPES = {
     "rnnwf_vmc_gradient": (C.c_int, [_P, _F64, _F64, _F64]),
     "rnnwf_load_batch": (C.c_int, [_P, _I32P, _I64, _P]),
     "rnnwf_get_grad": (C.c_int, [_P, C.c_char_p, _P, _I64, _I32]),
+    "rnnwf_set_params_flat": (C.c_int, [_P, _F64P, _I64]),
+    "rnnwf_get_grads_flat": (C.c_int, [_P, _F64P, _I64]),
+    "rnnwf_param_name": (C.c_char_p, [_P, _I32, C.POINTER(_I64)]),
     "rnnwf_allreduce_grads": (C.c_int, [_P]),
     "rnnwf_comm_unique_id": (C.c_int, [_P]),
     "rnnwf_comm_init": (C.c_int, [_P, _P, _I32, _I32]),
@@ -148,8 +151,35 @@ class NativeWavefunction:
             pass
 
     # -- parameters -------------------------------------------------------------------------------
+    def _layout(self):
+        """[(tf name without scope, element count)] in the library's order (rnnwf_param_name)."""
+        lay = getattr(self, "_param_layout", None)
+        if lay is None:
+            lay, i, cnt = [], 0, _I64()
+            while True:
+                nm = self.lib.rnnwf_param_name(self.h, i, C.byref(cnt))
+                if nm is None:
+                    break
+                lay.append((nm.decode(), int(cnt.value)))
+                i += 1
+            self._param_layout = lay
+        return lay
+
     def set_params(self, params, scope=None):
-        """params: {tf_name: ndarray}; names may carry the ``<scope>/`` prefix."""
+        """params: {tf_name: ndarray}; names may carry the ``<scope>/`` prefix.  A complete set goes over in one call
+        (rnnwf_set_params_flat: what a training loop does every iteration), a partial one tensor by tensor."""
+        lay = self._layout()
+        pre = scope + "/" if scope else ""
+        if len(params) == len(lay) and all((pre + nm in params or nm in params) and
+                                           np.size(params[pre + nm] if pre + nm in params else params[nm]) == cnt for nm, cnt in lay):
+            flat = np.empty(sum(cnt for _, cnt in lay), dtype=np.float64)
+            off = 0
+            for nm, cnt in lay:
+                v = params[pre + nm] if pre + nm in params else params[nm]
+                flat[off:off + cnt] = np.asarray(v, dtype=np.float64).ravel()
+                off += cnt
+            self._check(self.lib.rnnwf_set_params_flat(self.h, flat.ctypes.data_as(_F64P), flat.size))
+            return
         for name, v in params.items():
             if scope and name.startswith(scope + "/"):
                 name = name[len(scope) + 1:]
@@ -279,6 +309,15 @@ class NativeWavefunction:
         self._check(self.lib.rnnwf_vmc_gradient(self.h, me.real, me.imag, float(norm)))
         if allreduce:
             self._check(self.lib.rnnwf_allreduce_grads(self.h))
+        lay = self._layout()
+        if len(shapes) == len(lay) and all(nm in shapes and int(np.prod(shapes[nm], dtype=np.int64)) == cnt for nm, cnt in lay):
+            flat = np.empty(sum(cnt for _, cnt in lay), dtype=np.float64)          # every tensor in one call
+            self._check(self.lib.rnnwf_get_grads_flat(self.h, flat.ctypes.data_as(_F64P), flat.size))
+            out, off = {}, 0
+            for nm, cnt in lay:
+                out[nm] = flat[off:off + cnt].reshape(shapes[nm])
+                off += cnt
+            return {name: out[name] for name in shapes}
         out = {}
         for name, shape in shapes.items():
             g = np.empty(shape, dtype=np.float64)

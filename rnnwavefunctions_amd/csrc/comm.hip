@@ -115,20 +115,6 @@ extern "C" int rnnwf_comm_reduce_in_step(rnnwf_handle* h, int32_t on) {
     return RNNWF_OK;
 }
 
-// Pinned staging of `bytes` (grown on demand, owned by the handle): a pageable source makes hipMemcpyAsync a hidden
-// synchronous copy through the runtime's own bounce buffer.
-static int ensure_staging(rnnwf_handle* h, size_t bytes) {
-    if (bytes <= h->staging_cap) return 0;
-    if (h->staging) RNNWF_HIP(h, hipHostFree(h->staging));
-    h->staging = nullptr;
-    h->staging_cap = 0;
-    const size_t want = bytes + bytes / 4 + 4096;
-    hipError_t e = hipHostMalloc(&h->staging, want, hipHostMallocDefault);
-    if (e != hipSuccess) return h->fail(RNNWF_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
-    h->staging_cap = want;
-    return 0;
-}
-
 // `count` doubles in pinned staging -> device scratch -> ncclAllReduce(sum) on the handle's stream -> staging; one host sync
 static int allreduce_staged(rnnwf_handle* h, size_t count) {
     RNNWF_HIP(h, hipSetDevice(h->cfg.device));
@@ -148,7 +134,7 @@ extern "C" int rnnwf_allreduce_f64(rnnwf_handle* h, double* data, int64_t count)
         return h->fail(RNNWF_ERR_STATE, "rnnwf_allreduce_f64: communicator not initialised");
     }
     if (count == 0) return RNNWF_OK;
-    if (int rc = ensure_staging(h, (size_t)count * sizeof(double))) return rc;
+    if (int rc = rnnwf::ensure_staging(h, (size_t)count * sizeof(double))) return rc;
     memcpy(h->staging, data, (size_t)count * sizeof(double));
     if (int rc = allreduce_staged(h, (size_t)count)) return rc;
     memcpy(data, h->staging, (size_t)count * sizeof(double));
@@ -169,7 +155,7 @@ extern "C" int rnnwf_allreduce_grads(rnnwf_handle* h) {
     }
     size_t total = 0;
     for (auto& kv : h->grads) total += kv.second.size();      // std::map: same order on every rank
-    if (int rc = ensure_staging(h, total * sizeof(double))) return rc;
+    if (int rc = rnnwf::ensure_staging(h, total * sizeof(double))) return rc;
     double* flat = static_cast<double*>(h->staging);
     size_t off = 0;
     for (auto& kv : h->grads) { std::copy(kv.second.begin(), kv.second.end(), flat + off); off += kv.second.size(); }

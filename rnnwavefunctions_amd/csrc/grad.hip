@@ -269,11 +269,11 @@ struct MLGrad {
         const int64_t ns = h->last_ns, R = ns * N, nsb = (ns + kChains - 1) / kChains;
         const double inv_norm = (NOUT == 3 ? 2.0 : 1.0) / norm;     // the complex cost carries a factor 2 (TrainingRNN_J1J2.py:197)
         const bool parity = h->model == RNNWF_MODEL_GRU1D_PARITY;
-        if (!h->wbwd.p) {
+        if (!h->wbwd_valid) {
             const std::vector<char> img = pack_all(h);
             if (int rc = ensure(h, h->wbwd, img.size())) return rc;
-            RNNWF_HIP(h, hipMemcpyAsync(h->wbwd.p, img.data(), img.size(), hipMemcpyHostToDevice, h->stream));
-            RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+            if (int rc = upload(h, h->wbwd.p, img.data(), img.size())) return rc;
+            h->wbwd_valid = true;
         }
         if (int rc = ensure(h, h->gradP, (size_t)R * GU::PCOLS * ES)) return rc;
         if (int rc = ensure(h, h->gradQ, (size_t)R * GU::QCOLS * ES)) return rc;
@@ -299,11 +299,12 @@ struct MLGrad {
         } else {
             if (int rc = passes(h, mean_energy, mean_energy_im, inv_norm, (const uint32_t*)h->bits.p, nullptr)) return rc;
         }
-        std::vector<T> host(DW_FLOATS);
-        RNNWF_HIP(h, hipMemcpyAsync(host.data(), h->gradW.p, DW_FLOATS * ES, hipMemcpyDeviceToHost, h->stream));
+        if (int rc = ensure_staging(h, DW_FLOATS * ES)) return rc;
+        const T* host = (const T*)h->staging;
+        RNNWF_HIP(h, hipMemcpyAsync(h->staging, h->gradW.p, DW_FLOATS * ES, hipMemcpyDeviceToHost, h->stream));
         RNNWF_HIP(h, hipStreamSynchronize(h->stream));
-        G0::unpack(h, host.data(), DW0);                       // layer 0 + head (written by the top layer's pass)
-        for (int l = 1; l < NL; ++l) unpack_upper(h, host.data() + DW0 + HEAD + (size_t)(l - 1) * DWU, l);
+        G0::unpack(h, host, DW0);                              // layer 0 + head (written by the top layer's pass)
+        for (int l = 1; l < NL; ++l) unpack_upper(h, host + DW0 + HEAD + (size_t)(l - 1) * DWU, l);
         return RNNWF_OK;
     }
 
@@ -471,12 +472,12 @@ extern "C" int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double me
     const int64_t ns = h->last_ns, R = ns * N;
     int pcols = 0, qcols = 0, hgn = 0;
     GRAD_DISPATCH(h, { pcols = K::G::PCOLS; qcols = K::G::QCOLS; hgn = K::G::HEAD_ROW * (cplx ? 3 : 1); break; });
-    if (!h->wbwd.p) {
+    if (!h->wbwd_valid) {
         std::vector<char> img;
         GRAD_DISPATCH(h, { img = K::pack_bwd(h); break; });
         if (int rc = ensure(h, h->wbwd, img.size())) return rc;
-        RNNWF_HIP(h, hipMemcpyAsync(h->wbwd.p, img.data(), img.size(), hipMemcpyHostToDevice, h->stream));
-        RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+        if (int rc = upload(h, h->wbwd.p, img.data(), img.size())) return rc;
+        h->wbwd_valid = true;
     }
     if (int rc = ensure(h, h->gradP, (size_t)R * pcols * es)) return rc;
     if (int rc = ensure(h, h->gradQ, (size_t)R * qcols * es)) return rc;
@@ -518,10 +519,10 @@ extern "C" int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double me
         a.wfac = lpF;
     }
     GRAD_DISPATCH(h, { if (int rc = K::run(h, a, R, h->gradW.p)) return rc; break; });
-    std::vector<char> host(dw_floats * es);
-    RNNWF_HIP(h, hipMemcpyAsync(host.data(), h->gradW.p, dw_floats * es, hipMemcpyDeviceToHost, h->stream));
+    if (int rc = ensure_staging(h, dw_floats * es)) return rc;        // pinned: the copy is a plain DMA, the one wait is ours
+    RNNWF_HIP(h, hipMemcpyAsync(h->staging, h->gradW.p, dw_floats * es, hipMemcpyDeviceToHost, h->stream));
     RNNWF_HIP(h, hipStreamSynchronize(h->stream));
-    GRAD_DISPATCH(h, { K::unpack(h, host.data(), (size_t)pcols * qcols); break; });
+    GRAD_DISPATCH(h, { K::unpack(h, h->staging, (size_t)pcols * qcols); break; });
     return RNNWF_OK;
 }
 
@@ -542,7 +543,25 @@ extern "C" int rnnwf_get_grad(rnnwf_handle* h, const char* name, void* data, int
     return RNNWF_OK;
 }
 
-// the weight image changed: the backward image must be rebuilt on the next gradient call
-void rnnwf::grad_invalidate(rnnwf_handle* h) {
-    if (h->wbwd.p) { hipFree(h->wbwd.p); h->wbwd.p = nullptr; h->wbwd.cap = 0; }
+// All gradients in ONE call, in the order and shapes of rnnwf_set_params_flat.
+extern "C" int rnnwf_get_grads_flat(rnnwf_handle* h, double* flat, int64_t count) {
+    if (!h || !flat) return RNNWF_ERR_INVALID;
+    if (h->grads.empty()) return h->fail(RNNWF_ERR_STATE, "rnnwf_get_grads_flat: no gradients (call rnnwf_vmc_gradient first)");
+    int64_t total = 0;
+    for (auto& kv : h->params) total += (int64_t)kv.second.slot.size();
+    if (count != total)
+        return h->fail(RNNWF_ERR_INVALID, "rnnwf_get_grads_flat: the model has %lld parameters, caller passed %lld", (long long)total, (long long)count);
+    int64_t off = 0;
+    for (auto& kv : h->params) {
+        auto it = h->grads.find(kv.first);
+        if (it == h->grads.end() || it->second.size() != kv.second.value.size())
+            return h->fail(RNNWF_ERR_STATE, "rnnwf_get_grads_flat: no gradient for '%s'", kv.first.c_str());
+        const std::vector<int64_t>& slot = kv.second.slot;
+        for (size_t i = 0; i < slot.size(); ++i) flat[off + (int64_t)i] = it->second[slot[i]];
+        off += (int64_t)slot.size();
+    }
+    return RNNWF_OK;
 }
+
+// the weight image changed: the backward image must be rebuilt on the next gradient call
+void rnnwf::grad_invalidate(rnnwf_handle* h) { h->wbwd_valid = false; }     // (the buffer stays: freeing and re-allocating it cost ~0.1 ms per training iteration)

@@ -2,7 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
+#include <cstring>
 #include <cstdio>
 #include <map>
 #include <string>
@@ -70,6 +72,7 @@ struct rnnwf_handle {
     rnnwf::DevBuf rowbuf;
     // gradient (grad.hip)
     rnnwf::DevBuf wbwd, gradP, gradQ, gradW;
+    bool wbwd_valid = false;      // the backward image matches the committed parameters (re-packed by the next gradient call otherwise)
     rnnwf::DevBuf gradPart, gradHeadPart;    // per-block partial sums of the weight-gradient GEMM; per-wave head-row sums
     std::vector<double> coupl_host;   // what h->coupl holds (couplings rarely change between steps: skip the upload)
     rnnwf::DevBuf gradDX[2];      // stacked layers: dL/dx of one layer's pass = dL/dh input of the pass below
@@ -88,8 +91,10 @@ struct rnnwf_handle {
     void* pinned = nullptr;  // small pinned staging (moments)
     void* pinned_dev = nullptr;   // the same memory as the device addresses it: kernels write the step's 32 + 24 result bytes there directly
     bool j1j2_cnt_clean = false;  // the J1-J2 item counters are zero (left so by the last assembly kernel)
-    void* staging = nullptr; // pinned staging of the host-side all-reduces (comm.hip), grown on demand
+    void* staging = nullptr; // pinned staging of the host-side all-reduces (comm.hip) and of the gradient's download, grown on demand
     size_t staging_cap = 0;
+    void* upbuf = nullptr;   // pinned buffer the weight images travel through on their way to the device (upload(), below)
+    size_t upbuf_cap = 0, upbuf_off = 0;
     rnnwf::DevBuf reduce_scratch;
 
     bool timing_on = false;
@@ -136,6 +141,49 @@ inline int ensure(rnnwf_handle* h, DevBuf& b, size_t bytes) {
     hipError_t e = hipMalloc(&b.p, want);
     if (e != hipSuccess) return h->fail(RNNWF_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
     b.cap = want;
+    return 0;
+}
+
+// Pinned staging of `bytes` (grown on demand, owned by the handle): a pageable source or destination makes hipMemcpyAsync a hidden
+// synchronous copy through the runtime's own bounce buffer.
+inline int ensure_staging(rnnwf_handle* h, size_t bytes) {
+    if (bytes <= h->staging_cap) return 0;
+    if (h->staging) RNNWF_HIP(h, hipHostFree(h->staging));
+    h->staging = nullptr;
+    h->staging_cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipHostMalloc(&h->staging, want, hipHostMallocDefault);
+    if (e != hipSuccess) return h->fail(RNNWF_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    h->staging_cap = want;
+    return 0;
+}
+
+// Host -> device copy of a freshly packed image, asynchronous on the handle's stream: the bytes are copied into the handle's
+// pinned upload buffer first (bump-allocated; upload_reset() at the start of a commit waits for the previous commit's copies,
+// which have long landed), so the caller's vector may die at once and nothing blocks.  A training iteration re-packs three to
+// four images; with blocking hipMemcpy each cost 10-20 us of host time (tools/iter_breakdown.py).
+inline int upload_reset(rnnwf_handle* h) {
+    if (h->upbuf_off) RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+    h->upbuf_off = 0;
+    return 0;
+}
+inline int upload(rnnwf_handle* h, void* dst, const void* src, size_t bytes) {
+    const size_t off = (h->upbuf_off + 255) & ~(size_t)255;
+    if (off + bytes > h->upbuf_cap) {                     // grow: wait for what is in flight, then start over in a larger buffer
+        RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+        if (h->upbuf) RNNWF_HIP(h, hipHostFree(h->upbuf));
+        h->upbuf = nullptr;
+        h->upbuf_cap = 0;
+        const size_t want = std::max<size_t>((size_t)1 << 20, 2 * (off + bytes));
+        hipError_t e = hipHostMalloc(&h->upbuf, want, hipHostMallocDefault);
+        if (e != hipSuccess) return h->fail(RNNWF_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        h->upbuf_cap = want;
+        h->upbuf_off = 0;
+        return upload(h, dst, src, bytes);
+    }
+    memcpy((char*)h->upbuf + off, src, bytes);
+    RNNWF_HIP(h, hipMemcpyAsync(dst, (char*)h->upbuf + off, bytes, hipMemcpyHostToDevice, h->stream));
+    h->upbuf_off = off + bytes;
     return 0;
 }
 

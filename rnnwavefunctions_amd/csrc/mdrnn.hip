@@ -486,12 +486,12 @@ int rnnwf::mdrnn_vmc_gradient(rnnwf_handle* h, double mean_energy, double norm) 
     const int64_t ns = h->last_ns, R = ns * N;
     int pcols = 0, qcols = 0, hgn = 0;
     MG_DISPATCH(h, { pcols = K::G::PCOLS; qcols = K::G::QCOLS; hgn = 2 * K::G::HEAD_ROW; break; });
-    if (!h->wbwd.p) {
+    if (!h->wbwd_valid) {
         std::vector<char> img;
         MG_DISPATCH(h, { img = K::pack(h); break; });
         if (int rc = ensure(h, h->wbwd, img.size())) return rc;
-        RNNWF_HIP(h, hipMemcpyAsync(h->wbwd.p, img.data(), img.size(), hipMemcpyHostToDevice, h->stream));
-        RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+        if (int rc = upload(h, h->wbwd.p, img.data(), img.size())) return rc;
+        h->wbwd_valid = true;
     }
     if (int rc = ensure(h, h->gradP, (size_t)R * pcols * 8)) return rc;
     if (int rc = ensure(h, h->gradQ, (size_t)R * qcols * 8)) return rc;
@@ -515,9 +515,10 @@ int rnnwf::mdrnn_vmc_gradient(rnnwf_handle* h, double mean_energy, double norm) 
     a.vert_pos = m.vert_pos;
     a.row_first = m.row_first;
     MG_DISPATCH(h, { if (int rc = K::run(h, a, R, (double*)h->gradW.p)) return rc; break; });
-    std::vector<double> host(dwn);
-    RNNWF_HIP(h, hipMemcpyAsync(host.data(), h->gradW.p, dwn * 8, hipMemcpyDeviceToHost, h->stream));
+    if (int rc = ensure_staging(h, dwn * 8)) return rc;
+    const double* host = (const double*)h->staging;
+    RNNWF_HIP(h, hipMemcpyAsync(h->staging, h->gradW.p, dwn * 8, hipMemcpyDeviceToHost, h->stream));
     RNNWF_HIP(h, hipStreamSynchronize(h->stream));
-    MG_DISPATCH(h, { K::unpack(h, host.data(), host.data() + (size_t)pcols * qcols); break; });
+    MG_DISPATCH(h, { K::unpack(h, host, host + (size_t)pcols * qcols); break; });
     return RNNWF_OK;
 }

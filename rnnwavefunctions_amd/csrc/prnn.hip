@@ -319,8 +319,7 @@ int rnnwf::prnn_pack_image(rnnwf_handle* h, std::vector<char>& img) {
         std::vector<char> simg;
         if (int rc = prnn_split_pack(h, simg)) return rc;
         if (int rc = ensure(h, h->wsplit, simg.size())) return rc;
-        RNNWF_HIP(h, hipStreamSynchronize(h->stream));
-        RNNWF_HIP(h, hipMemcpy(h->wsplit.p, simg.data(), simg.size(), hipMemcpyHostToDevice));
+        if (int rc = upload(h, h->wsplit.p, simg.data(), simg.size())) return rc;
     }
     if (int rc = base_bf_pack(h)) return rc;
     PRNN_DISPATCH(h, { img = K::pack(h); return 0; });

@@ -223,6 +223,7 @@ extern "C" int rnnwf_destroy(rnnwf_handle* h) {
     }
     if (h->pinned) hipHostFree(h->pinned);
     if (h->staging) hipHostFree(h->staging);
+    if (h->upbuf) hipHostFree(h->upbuf);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
     return RNNWF_OK;
@@ -262,6 +263,35 @@ extern "C" int rnnwf_get_param(rnnwf_handle* h, const char* name, void* data, in
     else if (dtype == RNNWF_F64) for (int64_t i = 0; i < count; ++i) ((double*)data)[i] = p->value[p->slot[i]];
     else return h->fail(RNNWF_ERR_INVALID, "unknown dtype %d", dtype);
     return RNNWF_OK;
+}
+
+// All parameters in ONE call: `flat` holds every tensor in the caller's shapes, concatenated in the order of their names
+// (byte-wise sorted, the order of rnnwf_param_name); commits.  What a training loop calls once per iteration instead of
+// 8..26 rnnwf_set_param calls + rnnwf_commit_params.
+extern "C" int rnnwf_set_params_flat(rnnwf_handle* h, const double* flat, int64_t count) {
+    if (!h || !flat) return RNNWF_ERR_INVALID;
+    if (count != rnnwf_num_params(h))
+        return h->fail(RNNWF_ERR_INVALID, "rnnwf_set_params_flat: the model has %lld parameters, caller passed %lld",
+                       (long long)rnnwf_num_params(h), (long long)count);
+    int64_t off = 0;
+    for (auto& kv : h->params) {
+        ParamSpec& p = kv.second;
+        for (size_t i = 0; i < p.slot.size(); ++i) p.value[p.slot[i]] = flat[off + (int64_t)i];
+        off += (int64_t)p.slot.size();
+        p.set = true;
+    }
+    h->committed = false;
+    return rnnwf_commit_params(h);
+}
+// name of the i-th tensor of that order (nullptr past the end) and its element count
+extern "C" const char* rnnwf_param_name(const rnnwf_handle* h, int32_t i, int64_t* count) {
+    if (!h || i < 0) return nullptr;
+    for (auto& kv : h->params)
+        if (i-- == 0) {
+            if (count) *count = (int64_t)kv.second.slot.size();
+            return kv.first.c_str();
+        }
+    return nullptr;
 }
 
 extern "C" int64_t rnnwf_num_params(const rnnwf_handle* h) {
@@ -328,11 +358,11 @@ extern "C" int rnnwf_commit_params(rnnwf_handle* h) {
     for (auto& kv : h->params)
         if (!kv.second.set) return h->fail(RNNWF_ERR_STATE, "parameter '%s' was never set", kv.first.c_str());
     RNNWF_HIP(h, hipSetDevice(h->cfg.device));
+    if (int rc = upload_reset(h)) return rc;      // the images travel through one pinned buffer, asynchronously (handle.h: upload)
     std::vector<char> img;
     if (int rc = model_pack_image(h, img)) return rc;
     if (int rc = ensure(h, h->wimg, img.size())) return rc;
-    RNNWF_HIP(h, hipStreamSynchronize(h->stream));
-    RNNWF_HIP(h, hipMemcpy(h->wimg.p, img.data(), img.size(), hipMemcpyHostToDevice));
+    if (int rc = upload(h, h->wimg.p, img.data(), img.size())) return rc;
     h->committed = true;
     h->last_ns = 0;               // resident batch belongs to the old weights
     grad_invalidate(h);

@@ -221,8 +221,7 @@ int rnnwf::base_bf_pack(rnnwf_handle* h) {
         default: return 0;
     }
     if (int rc = ensure(h, h->wbasebf, img.size())) return rc;
-    RNNWF_HIP(h, hipStreamSynchronize(h->stream));
-    RNNWF_HIP(h, hipMemcpy(h->wbasebf.p, img.data(), img.size(), hipMemcpyHostToDevice));
+    if (int rc = upload(h, h->wbasebf.p, img.data(), img.size())) return rc;
     h->base_bf = true;
     return 0;
 }

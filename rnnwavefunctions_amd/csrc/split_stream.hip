@@ -103,8 +103,7 @@ double rnnwf::prnn_split_16n_flops_per_step() { return (double)S16nLayout<1>::NT
 int rnnwf::prnn_split_16n_pack(rnnwf_handle* h) {
     const std::vector<char> img16 = pack_split16n_image<1>(h);
     if (int rc = ensure(h, h->wsplit16, img16.size())) return rc;
-    RNNWF_HIP(h, hipStreamSynchronize(h->stream));
-    RNNWF_HIP(h, hipMemcpy(h->wsplit16.p, img16.data(), img16.size(), hipMemcpyHostToDevice));
+    if (int rc = upload(h, h->wsplit16.p, img16.data(), img16.size())) return rc;
     return 0;
 }
 
@@ -123,8 +122,7 @@ int rnnwf::prnn_split_stream_pack(rnnwf_handle* h, std::vector<char>& simg) {
         // the 16x16x32 form's image (split16_core.h) beside it: the default flip pass at these widths
         const std::vector<char> img16 = pack_split16_image<1>(h);
         if (int rc = ensure(h, h->wsplit16, img16.size())) return rc;
-        RNNWF_HIP(h, hipStreamSynchronize(h->stream));
-        RNNWF_HIP(h, hipMemcpy(h->wsplit16.p, img16.data(), img16.size(), hipMemcpyHostToDevice));
+        if (int rc = upload(h, h->wsplit16.p, img16.data(), img16.size())) return rc;
     } else {
         simg = pack_split_image<2, 2, 1, 3>(h);
     }
