@@ -87,6 +87,34 @@ def test_run_1dtfim_with_the_parity_symmetric_model_reaches_the_ground_state():
     assert np.mean(varE[-50:]) < 0.5 * varE[0]
 
 
+def test_one_call_parameter_and_gradient_transfer_equals_the_per_tensor_calls():
+    """rnnwf_set_params_flat / rnnwf_get_grads_flat (what a training loop uses every iteration) against rnnwf_set_param /
+    rnnwf_get_grad tensor by tensor, for a stack of unequal widths (padded inside the library)."""
+    import ctypes as C
+    from rnnwavefunctions_amd import _lib
+    units, N, ns = (20, 12), 8, 64
+    prm = P.randomize_biases(P.scale_kernels(P.init_gru_params(list(units), seed=9), 1.4), 3)
+    a = _lib.NativeWavefunction(_lib.MODEL_GRU1D, N, 1, units)
+    a.set_params(prm, scope=SCOPE)                                    # complete set: one call
+    b = _lib.NativeWavefunction(_lib.MODEL_GRU1D, N, 1, units)
+    for k, v in prm.items():                                          # tensor by tensor
+        b._check(b.lib.rnnwf_set_param(b.h, k[len(SCOPE) + 1:].encode(), v.ctypes.data_as(C.c_void_p), v.size, _lib.F32))
+    b._check(b.lib.rnnwf_commit_params(b.h))
+    names = [nm for nm, _ in a._layout()]
+    assert names == sorted(k[len(SCOPE) + 1:] for k in prm) and sum(c for _, c in a._layout()) == P.count_params(prm)
+    coup = np.append(np.ones(N), 1.0)
+    oa = a.vmc_step(ns, seed=2, step=0, couplings=coup, want_samples=True, want_eloc=True)
+    ob = b.vmc_step(ns, seed=2, step=0, couplings=coup, want_samples=True, want_eloc=True)
+    assert np.array_equal(oa["samples"], ob["samples"]) and np.array_equal(oa["eloc"], ob["eloc"])
+    shapes = {k[len(SCOPE) + 1:]: v.shape for k, v in prm.items()}
+    ga = a.vmc_gradient(oa["eloc"].mean(), ns, shapes)                # one call
+    b._check(b.lib.rnnwf_vmc_gradient(b.h, float(ob["eloc"].mean()), 0.0, float(ns)))
+    for nm, shape in shapes.items():
+        g = np.empty(shape, dtype=np.float64)
+        b._check(b.lib.rnnwf_get_grad(b.h, nm.encode(), g.ctypes.data_as(C.c_void_p), g.size, _lib.F64))
+        assert np.array_equal(g, ga[nm]), nm
+
+
 def test_gradient_needs_a_resident_batch():
     from rnnwavefunctions_amd import _lib
     prm = P.init_gru_params([10], seed=1)
