@@ -257,6 +257,121 @@ def train_leg(wl, wf, prm, couplings, steps, offset):
             "grad_l2_norm": gnorm, "finite": bool(np.isfinite(gnorm))}
 
 
+def dominant_kernel(wl, engine):
+    """The dominant kernel as rocprofv3 names it (release library: one kernel per model and width class)."""
+    H, L = wl["H"], wl.get("layers", 1)
+    if wl["kind"] == "tfim2d":
+        return "mdrnn_flip_kernel"
+    if wl["kind"] == "tfim2d_gru":
+        return "prnn_flip_kernel<double>"
+    if engine != "bf16x3":
+        return {"tfim1d": "prnn_ml_flip_kernel" if L > 1 else "prnn_flip_kernel", "j1j2": "crnn_ml_swap_kernel" if L > 1 else "crnn_swap_kernel"}[wl["kind"]]
+    pp = 37 <= H <= 50                     # the ping-pong form of the bf16x3 engine
+    if wl["kind"] == "j1j2":
+        return ("crnn_swap_pp_upper_kernel" if L > 1 else "crnn_swap_pp_kernel") if pp else "crnn_swap_split_kernel"
+    if L > 1:
+        return "prnn_flip_pp_upper_kernel"
+    return "prnn_flip_pp_kernel" if pp else "prnn_flip_riders16_asm_kernel" if H > 68 else "prnn_flip_split_kernel"
+
+
+def assemble_record(*, args, wl, world, dt, step_ms, per_rank_ms, infos, moments, flip, base, asm, engine, transport_fallback,
+                    cfg5, traffic, last_step):
+    """Rank 0's JSON line from what the ranks measured - a pure function of its arguments (no GPU, no torch), so that
+    tests/test_host.py can drive the N = 8 assembly with synthetic per-rank records before the first 8-GPU run does."""
+    ns, N = wl["ns"], wl["N"]
+    m = moments
+    ms_per_step = dt / args.steps * 1e3
+    value = world * ns * N / (dt / args.steps)
+    mean_e = m[0] / m[2]
+    var_e = m[1] / m[2] - mean_e ** 2
+    launches = max(flip["launches"], 1)
+    alg_flops_per_launch = flip["cell_evals"] / launches * f_cell(wl)
+    flip_ms = flip["total_ms"] / launches
+    achieved = alg_flops_per_launch / (flip_ms * 1e-3) / 1e12 if flip_ms > 0 else 0.0
+    dtype = "f64" if wl["kind"] in ("tfim2d", "tfim2d_gru") else "f32"
+    peak, peak_note = engine_peak(engine, dtype)
+    kernel = dominant_kernel(wl, engine)
+    issued = flip["mfma_flops"] / launches
+    step_ms = np.asarray(step_ms, dtype=float)
+    rec = {
+        "metric": "samples*sites/sec (autoregressive sample+local_energy), 1D TFIM N=80 nh=50"
+                  if args.workload == "cfg2" else "samples*sites/sec (autoregressive sample+local_energy), " + args.workload,
+        "value": value, "unit": "samples*sites/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        # the arithmetic the path computes in.  bf16x3: every f32 operand held EXACTLY as three bf16 parts, the six
+        # significant bf16 products accumulated in f32 (csrc/split_core.h) - f32-equivalent (both engines meet the same
+        # tolerance against the float64 oracle), not bitwise f32; the pure f32-input-MFMA run is `f32mfma_engine`
+        "dtype": dtype + (" (bf16x3 split, f32 accumulate)" if engine == "bf16x3" else ""),
+        "arithmetic": ("bf16x3: 3 exact bf16 parts per f32 operand, 6 bf16 MFMA products per f32 product, f32 accumulate, in the "
+                       "flip / swap pass and (one layer of 37..52 units) the cooperative base pass that samples; other base passes "
+                       "on the f32-input MFMA" if engine == "bf16x3" else "%s-input MFMA, %s accumulate" % (dtype, dtype)),
+        "data": "synthetic",
+        # SURVEY.md 8(d) asks for the median of >= 20 steps: per-step wall times (each step ends with its own host
+        # synchronisation) of THIS rank; `ms_per_step` / `value` stay the barrier-bracketed total over K steps, max over ranks
+        "ms_per_step_median": float(np.median(step_ms)), "ms_per_step_min": float(step_ms.min()), "ms_per_step_max": float(step_ms.max()),
+        "value_at_median_step": world * ns * N / (float(np.median(step_ms)) * 1e-3),
+        "ms_per_step_per_rank": list(per_rank_ms),
+        "config": {"workload": wl["desc"], "numsamples_per_gpu": ns, "global_numsamples": ns * world,
+                   "sites": N, "num_units": wl["H"], "layers": wl.get("layers", 1),
+                   "parallelism": "dp%d (sample shards, 1 %s all-reduce/step)" % (world, "RCCL" if args.transport == "rccl" else "gloo"),
+                   "weights": "glorot-uniform RandomState(111), gate bias 1" + (", kernels x 3 (trained-like)" if args.weights == "trained" else ""),
+                   "mean_E": mean_e, "var_E": var_e, "mean_E_at_step": last_step,
+                   "engine": engine},
+        # the communicator's own rank count (ncclCommCount), per rank with its device: N x dp1 cannot pass for dp-N
+        "rccl_nranks": min(i["nranks"] for i in infos) if args.transport == "rccl" and not transport_fallback else None,
+        "transport_fallback": transport_fallback,
+        "ranks": [{"rank": i["pid_rank"], "comm_rank": i["rank"], "comm_nranks": i["nranks"], "device": i["device"]} for i in infos],
+        "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": peak,
+                     "unit": "TFLOP/s", "frac": achieved / peak, "peak_is": peak_note,
+                     "engine_is_bf16x3": engine == "bf16x3",
+                     # the same achieved rate against the f32-input MFMA roof (what an f32 formulation could reach);
+                     # above 1 only because the bf16x3 engine left that pipe - informational, never the fraction
+                     "frac_of_f32_mfma_peak": achieved / PEAK_TFLOPS[dtype],
+                     # MFMA flops the kernel actually issued (padding included) over the peak of their pipe
+                     "mfma_issue_frac": (issued / (flip_ms * 1e-3) / 1e12 / (PEAK_TFLOPS["bf16"] if engine == "bf16x3" else PEAK_TFLOPS[dtype]))
+                                        if flip_ms > 0 else None,
+                     "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
+                     "traffic_source": ("replayed from %s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, build %s); "
+                                        "not measured by this run" % (TRAFFIC_FILE, (traffic or {}).get("build", "unknown")))
+                                       if traffic else None,
+                     "traffic_detail": traffic,
+                     "hbm_frac_of_8TBps": ((traffic["hbm_bytes_per_launch"] / (flip_ms * 1e-3) / 8e12)
+                                           if traffic and traffic.get("hbm_bytes_per_launch") and flip_ms > 0 else None),
+                     # clock the kernel held in an EARLIER profiler pass (GRBM_GUI_ACTIVE; the guide's peaks are quoted at
+                     # 2.4 GHz): informational, replayed like `traffic`, never the fraction
+                     "held_clock_ghz": (traffic or {}).get("held_clock_ghz"),
+                     "held_clock_source": (traffic or {}).get("held_clock_source"),
+                     "frac_at_held_clock": (achieved / peak * 2.4 / traffic["held_clock_ghz"]
+                                            if traffic and traffic.get("held_clock_ghz") else None),
+                     "algorithmic_flops_per_launch": alg_flops_per_launch,
+                     "mfma_flops_issued_per_launch": issued,
+                     "launches_per_step": flip["launches"] / max(args.steps, 1),
+                     "avg_launch_ms": flip_ms,
+                     "base_pass_ms": base["total_ms"] / max(base["launches"], 1),
+                     "assembly_ms": asm["total_ms"] / 3.0},            # per step (the three extra steps behind the timed region)
+    }
+    if cfg5 is not None:
+        rec["cfg5_sharded"] = cfg5
+    return rec
+
+
+def exit_status(rec, allow_fallback=False):
+    """(exit code, reason) of a finished run: a red parity leg or a scaling run that fell back to gloo must not hand the driver an
+    rc-0 number.  2: the oracle disagrees with the timed path (or the re-run did not reproduce the timed step); 3: RCCL fallback."""
+    par = rec.get("parity")
+    if par is not None:
+        if not par.get("pass"):
+            return 2, "parity leg failed: max |dE_loc|/N %.3g, d<E>/N %.3g against tolerance %.1g" % (
+                par.get("max_abs_dE_per_site", float("nan")), par.get("d_meanE_per_site", float("nan")), par.get("tolerance_per_site", 0.0))
+        if not par.get("reproduces_timed_step"):
+            return 2, "parity leg: the re-run of the last timed step did not reproduce its moments bit for bit"
+    if rec.get("transport_fallback") and not allow_fallback:
+        return 3, "RCCL communicator could not be created; the moments went over gloo (pass --allow-fallback to accept): " + rec["transport_fallback"]
+    if rec.get("n_gpus", 1) > 1 and rec.get("rccl_nranks") is not None and rec["rccl_nranks"] != rec["n_gpus"]:
+        return 3, "RCCL communicator spans %s ranks, the job %s" % (rec["rccl_nranks"], rec["n_gpus"])
+    return 0, None
+
+
 TRAFFIC_FILE = os.path.join("profiles", "pmc_traffic.json")
 
 
@@ -309,6 +424,9 @@ def main():
                     help="all-reduce of the moments: RCCL over xGMI (default) or the launcher's gloo group (rehearsal of "
                          "the multi-rank control flow on a box whose GPUs cannot host one rank each)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank on device 0")
+    ap.add_argument("--allow-fallback", action="store_true",
+                    help="multi-GPU runs: exit 0 even if the RCCL communicator could not be created and the moments went over gloo "
+                         "(without this flag such a run exits 3: a scaling number that silently measured gloo is worse than none)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -446,86 +564,12 @@ def main():
                 "global_numsamples": world * wl5["ns"], "mean_E": m5[0] / m5[2],
                 "note": "north-star config 5 (sharded over the ranks of this job, one RCCL all-reduce per step), "
                         "reported beside `value`, which stays on the metric's own workload so that it is comparable across N"}
+    rc = 0
     if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
-        value = world * ns * N / (dt / args.steps)
-        mean_e = m[0] / m[2]
-        var_e = m[1] / m[2] - mean_e ** 2
-        launches = max(flip["launches"], 1)
-        alg_flops_per_launch = flip["cell_evals"] / launches * f_cell(wl)
-        flip_ms = flip["total_ms"] / launches
-        achieved = alg_flops_per_launch / (flip_ms * 1e-3) / 1e12 if flip_ms > 0 else 0.0
-        dtype = "f64" if wl["kind"] in ("tfim2d", "tfim2d_gru") else "f32"
-        engine = wf.engine_name()
-        peak, peak_note = engine_peak(engine, dtype)
-        # the dominant kernel as rocprofv3 names it: 37..50 units run the ping-pong form of the bf16x3 engine
-        # (RNNWF_ENGINE=bf16x3-serial pins the older 4-wave form for A/B runs)
-        pp = engine == "bf16x3" and 37 <= wl["H"] <= 50 and os.environ.get("RNNWF_ENGINE") != "bf16x3-serial"
-        riders_asm = engine == "bf16x3" and wl["H"] > 68 and os.environ.get("RNNWF_ENGINE") != "bf16x3-hipcc"
-        riders_name = "prnn_flip_riders_asm_kernel" if os.environ.get("RNNWF_ENGINE") == "bf16x3-asm32" else "prnn_flip_riders16_asm_kernel"
-        kernel = {"tfim1d": "prnn_ml_flip_kernel" if wl.get("layers", 1) > 1 else
-                            ("prnn_flip_pp_kernel" if pp else riders_name if riders_asm else "prnn_flip_split_kernel")
-                            if engine == "bf16x3" else "prnn_flip_kernel",
-                  "j1j2": ("crnn_swap_pp_kernel" if pp else "crnn_swap_split_kernel") if engine == "bf16x3" else "crnn_swap_kernel",
-                  "tfim2d": "mdrnn_flip_kernel", "tfim2d_gru": "prnn_flip_kernel<double>"}[wl["kind"]]
-        traffic = load_traffic(args.workload)
-        issued = flip["mfma_flops"] / launches
-        rec = {
-            "metric": "samples*sites/sec (autoregressive sample+local_energy), 1D TFIM N=80 nh=50"
-                      if args.workload == "cfg2" else "samples*sites/sec (autoregressive sample+local_energy), " + args.workload,
-            "value": value, "unit": "samples*sites/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            # the arithmetic the path computes in.  bf16x3: every f32 operand held EXACTLY as three bf16 parts, the six
-            # significant bf16 products accumulated in f32 (csrc/split_core.h) - f32-equivalent (both engines meet the same
-            # tolerance against the float64 oracle), not bitwise f32; the pure f32-input-MFMA run is `f32mfma_engine`
-            "dtype": dtype + (" (bf16x3 split, f32 accumulate)" if engine == "bf16x3" else ""),
-            "arithmetic": ("bf16x3: 3 exact bf16 parts per f32 operand, 6 bf16 MFMA products per f32 product, f32 accumulate; "
-                           "base pass / sampling on the f32-input MFMA" if engine == "bf16x3" else "%s-input MFMA, %s accumulate" % (dtype, dtype)),
-            "data": "synthetic",
-            # SURVEY.md 8(d) asks for the median of >= 20 steps: per-step wall times (each step ends with its own host
-            # synchronisation) of THIS rank; `ms_per_step` / `value` stay the barrier-bracketed total over K steps, max over ranks
-            "ms_per_step_median": float(np.median(step_ms)), "ms_per_step_min": float(step_ms.min()), "ms_per_step_max": float(step_ms.max()),
-            "value_at_median_step": world * ns * N / (float(np.median(step_ms)) * 1e-3),
-            "ms_per_step_per_rank": per_rank_ms,
-            "config": {"workload": wl["desc"], "numsamples_per_gpu": ns, "global_numsamples": ns * world,
-                       "sites": N, "num_units": wl["H"], "parallelism": "dp%d (sample shards, 1 %s all-reduce/step)" % (world, "RCCL" if args.transport == "rccl" else "gloo"),
-                       "weights": "glorot-uniform RandomState(111), gate bias 1" + (", kernels x 3 (trained-like)" if args.weights == "trained" else ""),
-                       "mean_E": mean_e, "var_E": var_e, "mean_E_at_step": last_step,
-                       "engine": engine},
-            # the communicator's own rank count (ncclCommCount), per rank with its device: N x dp1 cannot pass for dp-N
-            "rccl_nranks": min(i["nranks"] for i in infos) if args.transport == "rccl" and not transport_note["fallback"] else None,
-            "transport_fallback": transport_note["fallback"],
-            "ranks": [{"rank": i["pid_rank"], "comm_rank": i["rank"], "comm_nranks": i["nranks"], "device": i["device"]} for i in infos],
-            "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": peak,
-                         "unit": "TFLOP/s", "frac": achieved / peak, "peak_is": peak_note,
-                         # the same achieved rate against the f32-input MFMA roof (what an f32 formulation could reach);
-                         # above 1 only because the bf16x3 engine left that pipe - informational, never the fraction
-                         "frac_of_f32_mfma_peak": achieved / PEAK_TFLOPS[dtype],
-                         # MFMA flops the kernel actually issued (padding included) over the peak of their pipe
-                         "mfma_issue_frac": (issued / (flip_ms * 1e-3) / 1e12 / (PEAK_TFLOPS["bf16"] if engine == "bf16x3" else PEAK_TFLOPS[dtype]))
-                                            if flip_ms > 0 else None,
-                         "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
-                         "traffic_source": ("replayed from %s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, build %s); "
-                                            "not measured by this run" % (TRAFFIC_FILE, (traffic or {}).get("build", "unknown")))
-                                           if traffic else None,
-                         "traffic_detail": traffic,
-                         "hbm_frac_of_8TBps": ((traffic["hbm_bytes_per_launch"] / (flip_ms * 1e-3) / 8e12)
-                                               if traffic and flip_ms > 0 else None),
-                         # clock the kernel held in an EARLIER profiler pass (GRBM_GUI_ACTIVE; the guide's peaks are quoted at
-                         # 2.4 GHz): informational, replayed like `traffic`, never the fraction
-                         "held_clock_ghz": (traffic or {}).get("held_clock_ghz"),
-                         "held_clock_source": (traffic or {}).get("held_clock_source"),
-                         "frac_at_held_clock": (achieved / peak * 2.4 / traffic["held_clock_ghz"]
-                                                if traffic and traffic.get("held_clock_ghz") else None),
-                         "algorithmic_flops_per_launch": alg_flops_per_launch,
-                         "mfma_flops_issued_per_launch": issued,
-                         "avg_launch_ms": flip_ms,
-                         "base_pass_ms": base["total_ms"] / max(base["launches"], 1),
-                         "assembly_ms": asm["total_ms"] / 3.0},            # per step (the three extra steps behind the timed region)
-        }
-        if cfg5 is not None:
-            rec["cfg5_sharded"] = cfg5
-        if engine == "bf16x3" and world == 1 and not args.no_alt_engine:
+        rec = assemble_record(args=args, wl=wl, world=world, dt=dt, step_ms=step_ms, per_rank_ms=per_rank_ms, infos=infos, moments=m,
+                              flip=flip, base=base, asm=asm, engine=wf.engine_name(), transport_fallback=transport_note["fallback"],
+                              cfg5=cfg5, traffic=load_traffic(args.workload), last_step=last_step)
+        if rec["roofline"]["engine_is_bf16x3"] and world == 1 and not args.no_alt_engine:
             rec["f32mfma_engine"] = alt_engine_run(wl, couplings, args.warmup, max(args.steps // 2, 3), last_step)
         # the oracle as CHECKER of the timed path's own output (outside the timed region, like the cpu_baseline leg)
         rec["parity"] = parity_leg(args.workload, wl, wf, prm, couplings, last_step, offset, m) if world == 1 and not args.no_parity else None
@@ -535,10 +579,18 @@ def main():
             rec["cpu_baseline"] = cpu_baseline(wl, prm)
         else:
             rec["cpu_baseline"] = None
+        rc, why = exit_status(rec, args.allow_fallback)
+        rec["exit_code"], rec["exit_reason"] = rc, why
         print(json.dumps(rec))
+        if rc:
+            print("bench.py: FAILED - " + why, file=sys.stderr)
     if dist is not None:
+        box = [rc]
+        dist.broadcast_object_list(box, src=0)      # every rank leaves with rank 0's verdict: the launcher sees one exit code
+        rc = box[0]
         dist.barrier()
         dist.destroy_process_group()
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -80,6 +80,8 @@ struct rnnwf_handle {
     rnnwf::DevBuf wsplit;
     rnnwf::DevBuf wsplit16;       // image of the 16x16x32 form of the flip pass at 69..100 units (split16_core.h)
     rnnwf::DevBuf wbasebf;        // bf16x3 A fragments of the cooperative base pass (layout.h: BaseBfLayout); valid iff base_bf
+    rnnwf::DevBuf wsplit_up[RNNWF_MAX_LAYERS - 1];   // stacked layers on the bf16x3 engine: image of layer l in [l - 1] (split_core.h: SplitUpperLayout)
+    rnnwf::DevBuf xrec[2];        // their layer pipeline: per-step state records of one layer, read by the kernel of the layer above
     bool base_bf = false;
     bool engine_split = false;
     bool engine_forced = false;   // RNNWF_ENGINE=bf16x3: no small-batch fallback to the f32-input MFMA

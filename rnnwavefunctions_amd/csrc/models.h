@@ -68,6 +68,15 @@ int prnn_split_16n_pack(rnnwf_handle* h);
 int crnn_split_swap_stream(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles, int kt16);
 double crnn_split_stream_flops_per_step(rnnwf_handle* h);
 int crnn_split_stream_pack(rnnwf_handle* h, std::vector<char>& simg);
+// stacked layers on the bf16x3 engine (split.hip; 37..50 units, ping-pong form): one kernel per layer over the same tiles, the new
+// state of every step handed upward through h->xrec (split_core.h: SplitUpperLayout)
+bool stack_split_available(const rnnwf_handle* h);
+size_t stack_record_bytes_per_32_chains(const rnnwf_handle* h, int64_t steps);   // h->xrec bytes per 32-chain tile column with `steps` wave-steps
+int prnn_stack_pack(rnnwf_handle* h);
+int prnn_stack_flip(rnnwf_handle* h, const PrnnArgs& a);
+int crnn_stack_pack(rnnwf_handle* h);
+int crnn_stack_swap(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles, int64_t max_records);
+double stack_split_flops_per_step(rnnwf_handle* h);
 int crnn_split_swap(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles);
 double crnn_split_flops_per_step(rnnwf_handle* h);
 int crnn_split_pack(rnnwf_handle* h, std::vector<char>& simg);

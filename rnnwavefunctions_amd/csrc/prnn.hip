@@ -227,6 +227,26 @@ bool use_split(rnnwf_handle* h, int64_t ns_pass) {
     return split;
 }
 
+// The flip pass of one direction on the engine the call chose, with its work counters (cell evaluations, MFMA flops issued).
+int flip_pass(rnnwf_handle* h, const PrnnArgs& a, int64_t ns) {
+    const int N = h->N;
+    const double wave_steps32 = (double)((ns + 31) / 32) * N * (N - 1) / 2.0;
+    if (use_split(h, ns)) {
+        if (h->NL > 1) {
+            if (int rc = prnn_stack_flip(h, a)) return rc;
+            h->work[1] += wave_steps32 * stack_split_flops_per_step(h);
+        } else {
+            if (int rc = prnn_split_flip(h, a)) return rc;
+            h->work[1] += wave_steps32 * prnn_split_flops_per_step(h);
+        }
+    } else {
+        if (int rc = launch_flip(h, a)) return rc;
+        h->work[1] += (double)a.nsb * N * (N - 1) / 2.0 * mfma_flops_per_step(h);
+    }
+    h->work[0] += (double)ns * N * (N - 1) / 2.0;
+    return 0;
+}
+
 // Fused local energies of ns chains whose packed spins are already in h->bits (and, for the parity
 // model, reversed in h->bits2): base pass with checkpoints -> flip pass -> assembly.  Leaves E_loc in
 // h->eloc and the log-prob queue in h->lpq.
@@ -251,14 +271,7 @@ int eloc_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
         a.ntiles = (int64_t)(N - 1) * nsb;
         a.sampling = 0;
         a.ablate |= h->knobs.ablate & 15;   // 0 unless a -DRNNWF_DIAGNOSTICS build read RNNWF_ABLATE
-        if (use_split(h, ns)) {
-            if (int rc = prnn_split_flip(h, a)) return rc;
-            h->work[1] += (double)((ns + 31) / 32) * N * (N - 1) / 2.0 * prnn_split_flops_per_step(h);
-        } else {
-            if (int rc = launch_flip(h, a)) return rc;
-            h->work[1] += (double)nsb * N * (N - 1) / 2.0 * mfma_flops_per_step(h);
-        }
-        h->work[0] += (double)ns * N * (N - 1) / 2.0;
+        if (int rc = flip_pass(h, a, ns)) return rc;
     }
     if (parity) {
         // second direction on the reversed chains, then log(0.5 (e^a + e^b)) row by row
@@ -276,14 +289,7 @@ int eloc_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
         if (int rc = launch_base(h, b)) return rc;
         if (Bx != 0.0 && N > 1) {
             b.ntiles = (int64_t)(N - 1) * nsb;
-            if (use_split(h, ns)) {
-                if (int rc = prnn_split_flip(h, b)) return rc;
-                h->work[1] += (double)((ns + 31) / 32) * N * (N - 1) / 2.0 * prnn_split_flops_per_step(h);
-            } else {
-                if (int rc = launch_flip(h, b)) return rc;
-                h->work[1] += (double)nsb * N * (N - 1) / 2.0 * mfma_flops_per_step(h);
-            }
-            h->work[0] += (double)ns * N * (N - 1) / 2.0;
+            if (int rc = flip_pass(h, b, ns)) return rc;
         }
         if (int rc = run_parity_combine(h, (const double*)h->lpq.p, (const double*)h->lpq2.p, (int64_t)(N + 1) * ns,
                                         (double*)h->lpq.p)) return rc;
@@ -293,7 +299,9 @@ int eloc_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
 }
 
 int64_t max_chains_per_pass(rnnwf_handle* h) {
-    const size_t per_block = (size_t)(h->NL > 1 ? h->N : std::max(h->N - 1, 1)) * hck_bytes_per_block(h);
+    size_t per_block = (size_t)(h->NL > 1 ? h->N : std::max(h->N - 1, 1)) * hck_bytes_per_block(h);
+    if (h->NL > 1 && h->engine_split)                         // per 16 chains: half a 32-chain tile column of the layer pipeline's records
+        per_block += stack_record_bytes_per_32_chains(h, (int64_t)h->N * (h->N - 1) / 2) / 2;
     const int64_t blocks = std::max<int64_t>(1, (int64_t)(state_budget_bytes(h, kHckBudget) / per_block));
     return blocks * kChains;
 }
@@ -313,9 +321,13 @@ int rnnwf::prnn_teacher_base(rnnwf_handle* h, int64_t ns, bool reversed, double*
 int rnnwf::prnn_pack_image(rnnwf_handle* h, std::vector<char>& img) {
     // flip-pass engine: bf16x3 on the matrix core for the f32 models (RNNWF_ENGINE=f32 keeps the f32-input MFMA
     // everywhere; above 68 units the w3 fragments of the image are read through L2, split_stream.hip); the base pass, sampling and log_probability always run the f32-MFMA kernels
-    h->engine_split = !h->f64 && h->NL == 1 && h->knobs.engine != 1 && h->NFULL <= 6;     // above 100 units: f32-input MFMA, image through L2
+    // stacked layers: 37..50 units run as a pipeline of bf16x3 kernels, one per layer (split.hip: prnn_stack_flip); other widths
+    // keep the f32-input MFMA
+    h->engine_split = !h->f64 && h->knobs.engine != 1 && (h->NL == 1 ? h->NFULL <= 6 : stack_split_available(h));     // above 100 units: f32-input MFMA, image through L2
     h->engine_forced = h->knobs.engine >= 2;
-    if (h->engine_split) {
+    if (h->engine_split && h->NL > 1) {
+        if (int rc = prnn_stack_pack(h)) return rc;
+    } else if (h->engine_split) {
         std::vector<char> simg;
         if (int rc = prnn_split_pack(h, simg)) return rc;
         if (int rc = ensure(h, h->wsplit, simg.size())) return rc;

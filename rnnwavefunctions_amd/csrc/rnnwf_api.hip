@@ -215,7 +215,9 @@ extern "C" int rnnwf_destroy(rnnwf_handle* h) {
     rnnwf_comm_destroy(h);
     DevBuf* bufs[] = {&h->wimg, &h->samples_i32, &h->bits, &h->bits2, &h->hck, &h->lpq, &h->lpq2, &h->out_lp,
                       &h->out_lp2, &h->eloc, &h->moments, &h->coupl, &h->maps, &h->camp, &h->tiles,
-                      &h->tile_count, &h->cbase, &h->cout, &h->rowbuf, &h->wbwd, &h->gradP, &h->gradQ, &h->gradW, &h->gradPart, &h->gradHeadPart, &h->wsplit, &h->wsplit16, &h->wbasebf, &h->gradDX[0], &h->gradDX[1], &h->reduce_scratch};
+                      &h->tile_count, &h->cbase, &h->cout, &h->rowbuf, &h->wbwd, &h->gradP, &h->gradQ, &h->gradW, &h->gradPart, &h->gradHeadPart, &h->wsplit, &h->wsplit16, &h->wbasebf, &h->gradDX[0], &h->gradDX[1], &h->reduce_scratch,
+                      &h->xrec[0], &h->xrec[1], &h->wsplit_up[0], &h->wsplit_up[1], &h->wsplit_up[2]};
+    static_assert(RNNWF_MAX_LAYERS == 4, "wsplit_up has RNNWF_MAX_LAYERS - 1 entries");
     for (DevBuf* b : bufs) free_buf(*b);
     for (auto& t : h->timers) {
         for (auto& ev : t.pending) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }

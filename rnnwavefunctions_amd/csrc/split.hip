@@ -50,7 +50,7 @@ struct SLaunch {
                 const size_t nwv = (size_t)grid * 8;
                 RNNWF_HIP(h, hipMalloc((void**)&b.stamps, nwv * 128));
                 RNNWF_HIP(h, hipMemsetAsync(b.stamps, 0, nwv * 128, h->stream));
-                prnn_flip_pp_kernel<NF32, RJ><<<grid, 512, L::BYTES, h->stream>>>(b, h->wsplit.p, kt16);
+                prnn_flip_pp_kernel<NF32, RJ><<<grid, 512, L::BYTES, h->stream>>>(b, h->wsplit.p, kt16, StackArgs{});
                 RNNWF_HIP(h, hipStreamSynchronize(h->stream));
                 std::vector<unsigned long long> st(nwv * 16);
                 RNNWF_HIP(h, hipMemcpy(st.data(), b.stamps, nwv * 128, hipMemcpyDeviceToHost));
@@ -69,7 +69,7 @@ struct SLaunch {
             }
 #endif
             TimedLaunch tl(h, 1);
-            prnn_flip_pp_kernel<NF32, RJ><<<grid, 512, L::BYTES, h->stream>>>(a, h->wsplit.p, kt16);
+            prnn_flip_pp_kernel<NF32, RJ><<<grid, 512, L::BYTES, h->stream>>>(a, h->wsplit.p, kt16, StackArgs{});
             RNNWF_HIP(h, hipGetLastError());
             return 0;
         } else {
@@ -246,6 +246,76 @@ int rnnwf::crnn_base_coop_bf(rnnwf_handle* h, const CrnnArgs& a0) {
         case 3: return BfBase<3>::launch(h, a, crnn_base_coop_kernel<3, true>, BfBase<3>::lds_bytes<3>());
     }
     return h->fail(RNNWF_ERR_INVALID, "no bf16 cooperative base kernel for NFULL=%d", h->NFULL);
+}
+
+
+// ---- stacked layers on the bf16x3 engine: a pipeline of one kernel per layer (split_core.h: SplitUpperLayout) -----------------
+namespace {
+constexpr int kStackNF32 = 1, kStackRJ = 9;                  // the K-packed layout of 37..50 units (SplitLayout MODE 2)
+using StackL0 = SplitLayout<kStackNF32, kStackRJ, 1, 2>;
+using StackU1 = SplitUpperLayout<kStackNF32, kStackRJ, 1>;
+using StackU3 = SplitUpperLayout<kStackNF32, kStackRJ, 3>;
+
+template <typename Kern>
+int stack_grid(rnnwf_handle* h, Kern kern, size_t lds, int64_t tiles, unsigned* grid) {
+    int bpc = 0;
+    if (int rc = rnnwf::blocks_per_cu(h, (const void*)kern, 512, lds, &bpc)) return rc;
+    *grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((tiles + 7) / 8, (int64_t)bpc * h->cu_count));
+    return 0;
+}
+}  // namespace
+
+bool rnnwf::stack_split_available(const rnnwf_handle* h) {
+    return !h->f64 && h->NL > 1 && h->NFULL == 3 && h->H <= 50 && h->knobs.engine != 1 &&
+           (h->model == RNNWF_MODEL_GRU1D || h->model == RNNWF_MODEL_GRU1D_PARITY || h->model == RNNWF_MODEL_CRNN_U1);
+}
+size_t rnnwf::stack_record_bytes_per_32_chains(const rnnwf_handle* h, int64_t steps) {
+    return (size_t)steps * StackU1::RECORD_FLOATS * 4 * (h->NL > 2 ? 2 : 1);
+}
+double rnnwf::stack_split_flops_per_step(rnnwf_handle* h) {
+    return ((double)StackL0::NT * StackL0::KS + (double)(h->NL - 1) * 2.0 * StackU1::NTB * StackL0::KS) * 32768.0;
+}
+
+int rnnwf::prnn_stack_pack(rnnwf_handle* h) {
+    {
+        const std::vector<char> img = pack_split_image<kStackNF32, kStackRJ, 1, 2>(h);
+        if (int rc = ensure(h, h->wsplit, img.size())) return rc;
+        if (int rc = upload(h, h->wsplit.p, img.data(), img.size())) return rc;
+    }
+    for (int l = 1; l < h->NL; ++l) {
+        const std::vector<char> img = pack_split_upper_image<kStackNF32, kStackRJ, 1>(h, l, l == h->NL - 1);
+        if (int rc = ensure(h, h->wsplit_up[l - 1], img.size())) return rc;
+        if (int rc = upload(h, h->wsplit_up[l - 1].p, img.data(), img.size())) return rc;
+    }
+    return 0;
+}
+
+int rnnwf::prnn_stack_flip(rnnwf_handle* h, const PrnnArgs& a) {
+    const int kt16 = 4 * h->NFULL + 1, NL = h->NL;
+    if (StackL0::HP > 4 * kt16) return h->fail(RNNWF_ERR_INVALID, "bf16x3 layout wider than the checkpoint rows (%d > %d)", StackL0::HP, 4 * kt16);
+    const int64_t nsb32 = (a.ns + 31) / 32;
+    const int64_t ntiles = (int64_t)(a.N - 1) * nsb32;
+    const int64_t nrec = nsb32 * (int64_t)a.N * (a.N - 1) / 2;
+    const size_t bytes = (size_t)nrec * StackU1::RECORD_FLOATS * 4;
+    if (int rc = ensure(h, h->xrec[0], bytes)) return rc;
+    if (NL > 2) if (int rc = ensure(h, h->xrec[1], bytes)) return rc;
+    unsigned g0 = 0, gu = 0, gl = 0;
+    if (int rc = stack_grid(h, prnn_flip_pp_kernel<kStackNF32, kStackRJ, true>, StackL0::BYTES, ntiles, &g0)) return rc;
+    if (int rc = stack_grid(h, prnn_flip_pp_upper_kernel<kStackNF32, kStackRJ, false>, StackU1::LDS_BYTES, ntiles, &gu)) return rc;
+    if (int rc = stack_grid(h, prnn_flip_pp_upper_kernel<kStackNF32, kStackRJ, true>, StackU1::LDS_BYTES, ntiles, &gl)) return rc;
+    TimedLaunch tl(h, 1);                                     // the whole pipeline is the "flip pass" of the timers
+    StackArgs st{nullptr, (float*)h->xrec[0].p, NL * kt16, 0};
+    prnn_flip_pp_kernel<kStackNF32, kStackRJ, true><<<g0, 512, StackL0::BYTES, h->stream>>>(a, h->wsplit.p, kt16, st);
+    RNNWF_HIP(h, hipGetLastError());
+    for (int l = 1; l < NL; ++l) {
+        st.xin = (const float*)h->xrec[(l - 1) & 1].p;
+        st.xout = l < NL - 1 ? (float*)h->xrec[l & 1].p : nullptr;
+        st.koff = l * kt16;
+        if (l < NL - 1) prnn_flip_pp_upper_kernel<kStackNF32, kStackRJ, false><<<gu, 512, StackU1::LDS_BYTES, h->stream>>>(a, h->wsplit_up[l - 1].p, kt16, st);
+        else prnn_flip_pp_upper_kernel<kStackNF32, kStackRJ, true><<<gl, 512, StackU1::LDS_BYTES, h->stream>>>(a, h->wsplit_up[l - 1].p, kt16, st);
+        RNNWF_HIP(h, hipGetLastError());
+    }
+    return 0;
 }
 
 int rnnwf::prnn_split_flip(rnnwf_handle* h, const PrnnArgs& a) {

@@ -96,6 +96,50 @@ struct SplitLayout {
     }
 };
 
+// Stacked GRU layers above the first on the bf16x3 engine (tf.nn.rnn_cell.MultiRNNCell, 1DTFIM/RNNwavefunction.py:32; the complex
+// wave function's default is two layers, J1J2/ComplexRNNwavefunction.py:16,40), K-packed layout MODE 2 (37..50 units).
+// The input x of layer l is the new state of layer l - 1: an h-wide f32 vector instead of a one-hot, so a step is TWO blocks of
+// products, each shaped exactly like the first layer's image (SplitLayout<.., 2>: NT = 5 tiles, 19 k-steps, 50 KB):
+//     X block (K over x):  rows r, u, y = x Wci + bci         H block (K over h):  rows r, u, q = h Wch + bch
+// into SEVEN accumulator tiles
+//     0: r   1: u   2: y   3: q        (units 0..31; r and u take both blocks)
+//     4: mixed tile 0 = r[0..8], u[0..6] of the remainder units (both blocks)
+//     5: mixed tile 1 of the X block = u[7..8] (x part), y[0..8]
+//     6: mixed tile 1 of the H block = u[7..8] (h part), q[0..8], head rows of the state that entered the step
+// (the two u halves of remainder units 7, 8 meet in one VALU add each).  c = tanh(y + r q).  190 MFMAs per 32-chain wave-step.
+// Biases: the special k-step of MODE 2 uses six of its eight K entries per lane half; entries 6, 7 of both halves carry the constant
+// 1.0 on the B side and the three bf16 parts of the row's bias on the A side (X block: b_r, b_u, b_ci; H block: b_ch, head biases),
+// so every accumulator starts from the MFMA's inline zero: no preload, no table, no registers held across the VALU segment.
+// One layer per kernel: the layers of a stack run as a PIPELINE of kernels over the same flip / swap tiles, layer l - 1 writing its
+// new state of every step to a record buffer in HBM that layer l reads one step ahead of its use (split_kernels.h) - the images
+// of two such layers (50 + 100 KB) would fill LDS, and a wave at two per SIMD cannot hold two layers' accumulators and states.
+template <int NF32_, int RJ_, int NOUT_ = 1>
+struct SplitUpperLayout {
+    using L0 = SplitLayout<NF32_, RJ_, NOUT_, 2>;
+    static_assert(NF32_ == 1 && L0::NMIX == 2, "upper-layer layout: one 32-unit block + two mixed tiles (37..50 units)");
+    static constexpr int NOUT = NOUT_, NF32 = NF32_, RJ = RJ_;
+    static constexpr int NTB = L0::NT;                          // tiles per block
+    static constexpr int NTA = 7;                               // accumulator tiles
+    static constexpr int NU = L0::NU, NUP = L0::NUP;
+    static constexpr size_t SZ_BLOCK = L0::SZ_A;                // one block's A fragments, laid out as SplitLayout<.., 2>'s
+    static constexpr size_t OFF_AX = 0;
+    static constexpr size_t OFF_AH = SZ_BLOCK;
+    static constexpr size_t OFF_WD = 2 * SZ_BLOCK;              // [2 hh][NUP][NOUT] f32 head weights (top layer)
+    static constexpr size_t OFF_BD = OFF_WD + (size_t)2 * NUP * NOUT * 4;   // [4] f32 head biases (padded)
+    static constexpr size_t BYTES = OFF_BD + 16;
+    static_assert(BYTES <= 160 * 1024, "the upper-layer image must fit LDS");
+    // accumulator tile of block tile t
+    static constexpr int acc_of(bool xblock, int t) { return t < 2 ? t : t == 2 ? (xblock ? 2 : 3) : t == 3 ? 4 : (xblock ? 5 : 6); }
+    // one wave-step's state record: [NG groups of 4 entries][64 lanes][4] f32 - a lane's entries 4 g .. 4 g + 3 are 16 contiguous bytes,
+    // a group 1 KB: written with dwordx4 stores, read by LDS-DMA into a lane-linear staging slot (split_kernels.h)
+    static constexpr int NG = (NU + 3) / 4;
+    static constexpr int RECORD_FLOATS = NG * 64 * 4;
+    static constexpr size_t SLOT_BYTES = (size_t)RECORD_FLOATS * 4;       // per-wave LDS staging slot (also holds a checkpoint: [NU][64] f32)
+    static constexpr size_t LDS_BYTES = ((BYTES + 15) / 16) * 16 + 8 * SLOT_BYTES;
+    static_assert(LDS_BYTES + 64 <= 160 * 1024, "image + eight staging slots must fit LDS");
+    static constexpr unsigned B_ONES = 0x3F803F80u;             // register 3 of the special quad: K entries 6, 7 = bf16 1.0
+};
+
 // x -> packed (bf16(x0), bf16(x1)) with round-to-nearest-even: ONE v_cvt_pk_bf16_f32, emitted by the compiler from the
 // vector conversion.  It must NOT be inline asm: hipcc's hazard recognizer does not count an asm block as a VALU
 // instruction, so an MFMA reading the packed register right behind it got no wait states and multiplied STALE

@@ -212,4 +212,144 @@ struct SplitPP {
     }
 };
 
+
+// ---- stacked layers: one GRU layer ABOVE the first, in the two segments of the ping-pong kernels (split_core.h: SplitUpperLayout) ----
+// The layer's state travels only as its three bf16 parts (the B quads of the H block): a wave at two per SIMD has 256 registers,
+// and seven accumulator tiles (112) + the fragment ring of the MFMA segment (40) + the quads of x and h (80) leave no room for a
+// second, f32 copy of the state.  The gate arithmetic rebuilds h = h1 + h2 + h3 from the parts - exact, smallest first: the split
+// was exact - which costs ~5 VALU instructions per unit in a segment that has room for them (190 MFMAs = 6 080 matrix-pipe cycles
+// against ~4 000 issue cycles of vector work).
+template <int NF32, int RJ, int NOUT>
+struct SplitPPUpper {
+    using P0 = SplitPP<NF32, RJ, NOUT>;
+    using U = SplitUpperLayout<NF32, RJ, NOUT>;
+    using L = typename U::L0;
+    static constexpr int NU = P0::NU, NUA = P0::NUA, NQ = P0::NQ, NB = P0::NB, NP = P0::NP, NTA = U::NTA;
+    using Asm = MfmaSegAsm<U::NTB, NQ>;
+    static_assert(Asm::kAvailable, "no hand-scheduled MFMA segment generated for this layout (tools/gen_split_mfma_asm.py)");
+    static_assert(RJ <= 16 && 2 * RJ >= 16 && 3 * RJ + NOUT <= 32, "upper layer: r slots in mixed tile 0, candidate slots and head rows in mixed tile 1");
+
+    static __device__ __forceinline__ void stage(char* lds, const void* wup) {
+        const uint4* src = reinterpret_cast<const uint4*>(wup);
+        uint4* dst = reinterpret_cast<uint4*>(lds);
+        for (int i = threadIdx.x; i < (int)(U::BYTES / 16); i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+    }
+
+    // X block (r, u, y, mixed 0, mixed 1 X), every tile from zero, then H block (r, u, mixed 0 continued; q, mixed 1 H from zero): the
+    // generated block of the one-layer step, twice.  The biases ride in the special k-step (ones(): the B side of their K entries).
+    static __device__ __forceinline__ void mfma_seg(const char* lds, const u32x4 (&BX)[NB], const u32x4 (&BH)[NB], f32x16 (&acc)[NTA], int lane) {
+        Asm::run_tiles_from_zero(P0::lds_address(lds + U::OFF_AX) + (unsigned)lane * 16u, BX, acc[0], acc[1], acc[2], acc[4], acc[5]);
+        Asm::run_tiles_zero_2_4(P0::lds_address(lds + U::OFF_AH) + (unsigned)lane * 16u, BH, acc[0], acc[1], acc[3], acc[4], acc[6]);
+    }
+    // h -> quads, with the bias entries' ones
+    static __device__ __forceinline__ void split(const float (&h)[NU], u32x4 (&B)[NB]) {
+        P0::split(h, B);
+        B[3 * NQ][3] = U::B_ONES;
+    }
+
+    // head rows of the state that ENTERED the step: H block, mixed tile 1
+    static __device__ __forceinline__ void head_lagged(const f32x16 (&acc)[NTA], float (&z)[NOUT]) {
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) z[o] = acc[6][L::HEAD_SLOT - 16 + o];
+    }
+
+    // gate arithmetic of units [E0, E1), stage by stage (see SplitPP::gate_batch): the candidate's input term comes out of the y
+    // accumulators, the old state out of the quads B - unpacked and summed beside the candidate's exp / rcp chain, whose latencies
+    // it fills (and only then: three more live values per unit any earlier would not fit the register file)
+    template <int E0, int E1>
+    static __device__ __forceinline__ void gate_batch(const f32x16 (&acc)[NTA], const u32x4 (&B)[NB], float (&h)[NU]) {
+        constexpr int n = E1 - E0;
+        float ar[n], au[n], aq[n], ay[n], p1[n], p2[n], p3[n];
+#pragma unroll
+        for (int j = 0; j < n; ++j) {
+            const int e = E0 + j;
+            if (e < 16 * NF32) {
+                ar[j] = acc[0][e]; au[j] = acc[1][e]; ay[j] = acc[2][e]; aq[j] = acc[3][e];
+            } else {
+                const int r = e - 16 * NF32, su = RJ + r, sc = 2 * RJ + r;
+                ar[j] = acc[4][r];
+                au[j] = su < 16 ? acc[4][su] : acc[5][su - 16] + acc[6][su - 16];      // the u halves of the two blocks
+                ay[j] = acc[5][sc - 16];
+                aq[j] = acc[6][sc - 16];
+            }
+        }
+        RNNWF_STAGE();
+#pragma unroll
+        for (int j = 0; j < n; ++j) { ar[j] = __builtin_amdgcn_exp2f(ar[j]); au[j] = __builtin_amdgcn_exp2f(au[j]); }
+        RNNWF_STAGE();
+#pragma unroll
+        for (int j = 0; j < n; ++j) { ar[j] = 1.0f + ar[j]; au[j] = 1.0f + au[j]; }
+        RNNWF_STAGE();
+#pragma unroll
+        for (int j = 0; j < n; ++j) { ar[j] = __builtin_amdgcn_rcpf(ar[j]); au[j] = __builtin_amdgcn_rcpf(au[j]); }
+        RNNWF_STAGE();
+#pragma unroll
+        for (int j = 0; j < n; ++j) aq[j] = fmaf(ar[j], aq[j], ay[j]);
+        RNNWF_STAGE();
+        // the three parts of the old state as f32 (a bf16 is the upper half of an f32)
+        auto part = [&](int e, int k) -> float {
+            if (e < NUA) {
+                const int i = e >> 1;
+                const unsigned w = B[k * NQ + i / 4][i % 4];
+                return __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
+            }
+            // the special unit: quad 3 NQ = {h1 | h2 << 16, h3 | h1 << 16, h2 | h1 << 16, 0}
+            return __uint_as_float(k == 0 ? (B[3 * NQ][0] << 16) : k == 1 ? (B[3 * NQ][0] & 0xffff0000u) : (B[3 * NQ][1] << 16));
+        };
+#pragma unroll
+        for (int j = 0; j < n; ++j) { aq[j] = __builtin_amdgcn_exp2f(aq[j]); p3[j] = part(E0 + j, 2); p2[j] = part(E0 + j, 1); }
+        RNNWF_STAGE();
+#pragma unroll
+        for (int j = 0; j < n; ++j) { aq[j] = 1.0f + aq[j]; p2[j] = p3[j] + p2[j]; p1[j] = part(E0 + j, 0); }
+        RNNWF_STAGE();
+#pragma unroll
+        for (int j = 0; j < n; ++j) { aq[j] = __builtin_amdgcn_rcpf(aq[j]); p1[j] = p2[j] + p1[j]; }      // p1 = the old state, exactly
+        RNNWF_STAGE();
+#pragma unroll
+        for (int j = 0; j < n; ++j) aq[j] = fmaf(2.0f, aq[j], -1.0f);
+        RNNWF_STAGE();
+#pragma unroll
+        for (int j = 0; j < n; ++j) ar[j] = p1[j] - aq[j];
+        RNNWF_STAGE();
+#pragma unroll
+        for (int j = 0; j < n; ++j) h[E0 + j] = fmaf(au[j], ar[j], aq[j]);
+        RNNWF_STAGE();
+    }
+
+    // new state (f32) of this lane's units from the accumulators and the old state's quads, in two calls: the remainder units -
+    // which release the three mixed tiles' registers - and the 16 units of the full tiles; the kernels request the next step's
+    // input between the two, into the registers just released
+    static __device__ __forceinline__ void gates_rem(const f32x16 (&acc)[NTA], const u32x4 (&B)[NB], float (&h)[NU]) {
+        gate_batch<16 * NF32, NU>(acc, B, h);
+    }
+    static __device__ __forceinline__ void gates_full(const f32x16 (&acc)[NTA], const u32x4 (&B)[NB], float (&h)[NU]) {
+        gate_batch<0, 8 * NF32>(acc, B, h);
+        gate_batch<8 * NF32, 16 * NF32>(acc, B, h);
+    }
+
+    // head rows on the new state (top layer only): as SplitPP::head, on this image's tables
+    static __device__ __forceinline__ void head(const char* lds, const float (&h)[NU], int lane, float (&z)[NOUT]) {
+        const float* wd = reinterpret_cast<const float*>(lds + U::OFF_WD) + (lane >> 5) * L::NUP * NOUT;
+        float part[NOUT][4];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) part[o][c] = 0.0f;
+#pragma unroll
+        for (int e = 0; e < NU; ++e)
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) part[o][e & 3] = fmaf(h[e], wd[e * NOUT + o], part[o][e & 3]);
+        const float* bd = reinterpret_cast<const float*>(lds + U::OFF_BD);
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            const float s = (part[o][0] + part[o][1]) + (part[o][2] + part[o][3]);
+            const unsigned u = __float_as_uint(s);
+            const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            z[o] = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) + bd[o];
+        }
+        RNNWF_STAGE();
+    }
+};
+
 }  // namespace rnnwf

@@ -98,17 +98,19 @@ class ShardComm:
         """RCCL through the handle's communicator.  The moments of a `vmc_step` are summed over the ranks inside the step
         (rnnwf_comm_reduce_in_step: in-stream all-reduce before the step's one host synchronisation), so `reduce_moments`
         passes them through; `allreduce` / `allreduce_grads` of anything else go through rnnwf_allreduce_f64."""
+        comm = cls(rank, world, None, native=native)
         if int(world) > 1:                # a single process never opened a communicator (init_rccl_from_env): nothing to reduce
             native.comm_reduce_in_step(True)
-        return cls(rank, world, None, native=native)
+            comm._moments_in_step = True
+        return comm
 
     def reduce_moments(self, m):
         """The four moments of a vmc_step summed over the ranks.  With the RCCL transport the step itself has already
         summed them on the stream (rnnwf_comm_reduce_in_step), so they pass through; every other array goes through
         `allreduce`, which never passes anything through un-reduced."""
-        if self.native is not None:
+        if self.native is not None and getattr(self, "_moments_in_step", False):
             return np.asarray(m, dtype=np.float64)
-        return self.allreduce(m)
+        return self.allreduce(m)          # (world 1: the identity; a native comm built without from_rccl: rnnwf_allreduce_f64)
 
     def allreduce(self, a):
         """Sum of a float64 array over the ranks."""

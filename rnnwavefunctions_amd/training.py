@@ -45,18 +45,20 @@ class Adam:
 
     # -- what tf.train.Saver() keeps of the optimizer (TrainingRNN_1DTFIM.py:163-166): slots <var>/Adam, <var>/Adam_1,
     #    beta1_power / beta2_power (beta^(t+1) after t steps, float32 scalars) and the un-named global step `Variable`.
-    #    NAMES ARE UNPINNED (no TF-written checkpoint exists here).  The reference calls apply_gradients INSIDE
-    #    `tf.variable_scope(wf.scope)` (:149-163), where TF-1's slot creator nests the slot under the current variable
-    #    scope again - "<scope>/<scope>/.../kernel/Adam" - and the non-slot beta powers take the NAME scope, which is the
-    #    third entry of that scope (sample :104, log_probability :112, the training block :149): "<scope>_2/beta1_power".
-    #    The writer emits those names; the reader (load_state) accepts any prefix.
+    #    NAMES ARE UNPINNED (no TF-written checkpoint exists here).  The reference enters `tf.variable_scope(wf.scope)`
+    #    (:149) BEFORE `with wf.graph.as_default()` (:150): the scope therefore binds to the process default graph, not to
+    #    wf.graph (a separate tf.Graph(), RNNwavefunction.py:20), and TF-1 keeps the variable-scope store and the name stack
+    #    per graph.  Inside wf.graph both are at root when apply_gradients runs - the same reason the global step is the
+    #    bare `Variable` - so the slot creator names the slots after the variable alone, "<var>/Adam" / "<var>/Adam_1", and
+    #    the beta powers carry no prefix.  The reader (load_state) accepts any scope prefix, so files written with the
+    #    nested names of round 3 ("<scope>/<scope>/.../Adam", "<scope>_2/beta1_power") still load.
     def state_tensors(self, params, scope):
         out = {}
         for k, v in params.items():
-            out[scope + "/" + k + "/Adam"] = self.m.get(k, np.zeros(v.shape)).astype(v.dtype)
-            out[scope + "/" + k + "/Adam_1"] = self.v.get(k, np.zeros(v.shape)).astype(v.dtype)
-        out[scope + "_2/beta1_power"] = np.array(self.b1 ** (self.t + 1), dtype=np.float32)
-        out[scope + "_2/beta2_power"] = np.array(self.b2 ** (self.t + 1), dtype=np.float32)
+            out[k + "/Adam"] = self.m.get(k, np.zeros(v.shape)).astype(v.dtype)
+            out[k + "/Adam_1"] = self.v.get(k, np.zeros(v.shape)).astype(v.dtype)
+        out["beta1_power"] = np.array(self.b1 ** (self.t + 1), dtype=np.float32)
+        out["beta2_power"] = np.array(self.b2 ** (self.t + 1), dtype=np.float32)
         out["Variable"] = np.array(self.t, dtype=np.int32)
         return out
 

@@ -34,6 +34,10 @@ def test_single_gpu_line_has_the_contract_fields():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["one_thread"]["value"] > 0
     assert d["value"] > 10 * c["value"]                          # north_star: >= 10 x the CPU path
+    # config 1's oracle comparison: all 500 samples of the last timed step, scored by the C restatement
+    p = d["parity"]
+    assert p["pass"] and p["reproduces_timed_step"] and p["samples"] == 500 and p["of"] == 500
+    assert p["max_abs_dE_per_site"] < 1e-4 and d["exit_code"] == 0
 
 
 def test_two_rank_control_flow_over_gloo_on_one_device():

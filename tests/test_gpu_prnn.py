@@ -510,6 +510,62 @@ def test_stacked_layers_sampling_vmc_step_and_parity_model():
     assert np.allclose(wfp.log_prob(sp), ref, rtol=0, atol=4e-6 * N + 2e-6)
 
 
+@pytest.mark.parametrize("N,H,L,B", [(20, 50, 2, 70), (12, 37, 2, 33), (9, 44, 3, 40), (7, 50, 4, 20), (16, 50, 3, 97), (33, 49, 2, 64), (2, 50, 2, 5)])
+def test_stacked_layers_on_both_engines(N, H, L, B, monkeypatch):
+    """Stacked layers of 37..50 units on the bf16x3 engine (a pipeline of one ping-pong kernel per layer, csrc/split_kernels.h:
+    prnn_flip_pp_kernel<.., STACK> -> prnn_flip_pp_upper_kernel) and on the f32-input MFMA: log-probability queue and local
+    energies of both against the float64 oracle, same tolerances; the two engines agree far inside them."""
+    from rnnwavefunctions_amd import _lib
+    prm = stacked_like(H, L, seed=H + L)
+    prm64 = {k: v.astype(np.float64) for k, v in prm.items()}
+    rng = np.random.RandomState(N + H)
+    s = rng.randint(0, 2, (B, N)).astype(np.int32)
+    Jz = 1.0 + 0.1 * rng.standard_normal(N)
+    e_ref, lp_ref = E.ising_local_energies(Jz, 0.9, s, lambda x: M.prnn_log_probability(prm64, x, dtype=np.float64), return_log_probs=True)
+    got = {}
+    for engine in ("bf16x3", "f32"):
+        monkeypatch.setenv("RNNWF_ENGINE", engine)
+        wf = make_stacked(_lib.MODEL_GRU1D, N, H, L, prm)
+        lp = np.zeros((N + 1) * B)
+        e = wf.tfim_eloc(s, Jz, 0.9, log_probs=lp)
+        assert wf.engine_name() == ("bf16x3" if engine == "bf16x3" else "f32mfma")
+        print("L=%d N=%d H=%d %s: max |lp - oracle64| = %.2e, max rel dE = %.2e" %
+              (L, N, H, engine, np.abs(lp - lp_ref.ravel()).max(), np.abs(e / e_ref - 1).max()))
+        assert np.allclose(lp, lp_ref.ravel(), rtol=0, atol=2e-6 * N * L + 2e-6)
+        assert np.allclose(e, e_ref, rtol=3e-5)
+        got[engine] = (lp, e)
+    assert np.allclose(got["bf16x3"][0], got["f32"][0], rtol=0, atol=2e-6 * N * L + 2e-6)
+    # the parity-symmetric class on the same stack: both directions through the pipeline
+    monkeypatch.setenv("RNNWF_ENGINE", "bf16x3")
+    wfp = make_stacked(_lib.MODEL_GRU1D_PARITY, N, H, L, prm)
+    ep = wfp.tfim_eloc(s, Jz, 0.9)
+    ep_ref = E.ising_local_energies(Jz, 0.9, s, lambda x: M.prnn_paritysym_log_probability(prm64, x, dtype=np.float64))
+    assert wfp.engine_name() == "bf16x3" and np.allclose(ep, ep_ref, rtol=3e-5)
+
+
+def test_stacked_layers_bf16x3_vmc_step_at_speed_size():
+    """The layer pipeline at a batch large enough to be chosen by default (no RNNWF_ENGINE): N=40, units=[50,50], 4 096 samples;
+    256 of them against the float64 oracle, shard invariance bit for bit, copies of one configuration get identical values."""
+    from rnnwavefunctions_amd import _lib
+    N, H, L, ns = 40, 50, 2, 4096
+    prm = stacked_like(H, L, seed=7)
+    prm64 = {k: v.astype(np.float64) for k, v in prm.items()}
+    wf = make_stacked(_lib.MODEL_GRU1D, N, H, L, prm)
+    c = np.append(np.ones(N), 1.0)
+    out = wf.vmc_step(ns, seed=5, step=1, couplings=c, want_samples=True, want_eloc=True)
+    assert wf.engine_name() == "bf16x3"
+    s, e = out["samples"], out["eloc"]
+    sub = np.arange(0, ns, 16)
+    e_ref = E.ising_local_energies(np.ones(N), 1.0, s[sub], lambda x: M.prnn_log_probability(prm64, x, dtype=np.float64))
+    assert np.allclose(e[sub], e_ref, rtol=3e-5)
+    lo = wf.vmc_step(ns // 2, seed=5, step=1, couplings=c, want_eloc=True)
+    hi = wf.vmc_step(ns // 2, seed=5, step=1, couplings=c, sample_offset=ns // 2, want_eloc=True)
+    assert np.array_equal(np.concatenate([lo["eloc"], hi["eloc"]]), e)
+    rep = np.repeat(s[:3], 100, axis=0).astype(np.int32)
+    er = wf.tfim_eloc(rep, np.ones(N), 1.0)
+    assert all(len(set(er[k * 100:(k + 1) * 100].tolist())) == 1 for k in range(3))
+
+
 @pytest.mark.parametrize("N,units,B", [(12, (20, 10), 40), (10, (10, 20), 33), (9, (36, 50, 20), 24), (8, (50, 7, 33), 17), (7, (64, 20), 20),
                                         (6, (30, 100), 16), (9, (20, 10, 36, 12), 24)])
 def test_stacked_layers_of_unequal_width(N, units, B):

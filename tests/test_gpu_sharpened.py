@@ -1,0 +1,142 @@
+"""Full-size oracle comparisons on SHARPENED weights.
+
+Every full-size oracle test elsewhere runs glorot-initialised weights, where each conditional is ~0.5 and every ratio
+exp(1/2 [log P(flipped) - log P]) is ~1.  Here the kernels are scaled by 3 and every bias is randomised (SURVEY.md 8d's
+"trained-like" weights), so that the conditionals are sharp, the flip ratios span orders of magnitude and the f32 /
+bf16x3 arithmetic of the long chains is stressed at the sizes BASELINE.json names.  The oracle scores the very sample
+matrix the HIP path drew.
+
+Tolerance: the absolute per-site bound of the glorot tests (1e-5 f32 models, 1e-10 f64) cannot be the criterion alone here -
+a local energy of sharpened weights is a sum of N ratios, single ones reaching 1e3..1e5, and an f32 log-probability difference of
+2e-6 N moves such a ratio by a RELATIVE 1e-4.  The bound is therefore stated per sample as
+    |E_loc - E_oracle| <= tol_abs * N + tol_rel * sum_i ratio_i,     sum_i ratio_i = (diag - E_loc) / Bx  (TFIM),
+with tol_abs the glorot tests' per-site bound and tol_rel = 3e-6 * N (f32; the log-probability tolerance of test_gpu_prnn.py)
+or 1e-10 (f64), and the batch mean <E>/N is held to north_star's 1e-4 (f32) outright.
+"""
+import numpy as np
+import pytest
+
+from oracle import estimators as E
+from oracle import models as M
+from rnnwavefunctions_amd import params as P
+
+pytestmark = pytest.mark.gpu
+SCOPE = "RNNwavefunction"
+HEADS = ("wf_dense_ampl", "wf_dense_phase")
+
+
+def sharpened(prm, seed):
+    return P.randomize_biases(P.scale_kernels(prm, 3.0), seed)
+
+
+def tfim_diag_1d(s, Jz):
+    sz = 2.0 * s - 1.0
+    return -(sz[:, :-1] * sz[:, 1:] * Jz[:-1]).sum(axis=1)
+
+
+def check_tfim(name, e, e_ref, diag, Bx, N, tol_abs, tol_rel, tol_mean):
+    ratios = (diag - e_ref) / Bx                      # sum_i exp(1/2 [log P(flip i) - log P]) >= 0
+    bound = tol_abs * N + tol_rel * np.abs(ratios)
+    d = np.abs(e - e_ref)
+    worst = int(np.argmax(d / bound))
+    d_mean = abs(e.mean() - e_ref.mean()) / N
+    print("%s sharpened: %d samples, ratio sums %.3g .. %.3g (median %.3g); max |dE|/N = %.2e; worst |dE|/bound = %.3f; "
+          "|d<E>|/N = %.2e" % (name, len(e), ratios.min(), ratios.max(), np.median(ratios), d.max() / N, (d / bound)[worst], d_mean))
+    assert np.all(np.isfinite(e))
+    assert np.all(d <= bound), "sample %d: |dE| %.3e > bound %.3e" % (worst, d[worst], bound[worst])
+    assert d_mean < tol_mean
+    assert ratios.max() > 3 * max(np.median(ratios), 1e-300)      # the weights ARE sharp: the ratio sums spread out (glorot: within 20 %)
+
+
+def test_config2_sharpened_all_samples():
+    """BASELINE config 2 (N=80, 50 units, 10 000 samples), all 10 000 samples against the C restatement of the reference formulation."""
+    from oracle import cport
+    from rnnwavefunctions_amd import _lib
+    N, H, ns = 80, 50, 10000
+    prm = sharpened(P.init_gru_params([H], seed=111), 112)
+    wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D, N, 1, (H,))
+    wf.set_params(prm, scope=SCOPE)
+    Jz = np.ones(N)
+    out = wf.vmc_step(ns, seed=111, step=0, couplings=np.append(Jz, 1.0), want_samples=True, want_eloc=True)
+    assert wf.engine_name() == "bf16x3"
+    s, e = out["samples"], out["eloc"]
+    e_ref = cport.ising_local_energies(prm, Jz, 1.0, s)
+    check_tfim("cfg2", e, e_ref, tfim_diag_1d(s, Jz), 1.0, N, 1e-5, 3e-6 * N, 1e-4)
+    m = out["moments"]
+    assert abs(m[0] / m[2] - e.mean()) <= 1e-12 * abs(e.mean()) + 1e-9
+
+
+def test_config5_shard_sharpened():
+    """BASELINE config 5, one GPU's shard (N=200, 100 units, 32 768 samples): 256 samples spread over the shard against the C oracle."""
+    from oracle import cport
+    from rnnwavefunctions_amd import _lib
+    N, H, ns = 200, 100, 32768
+    prm = sharpened(P.init_gru_params([H], seed=111), 113)
+    wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D, N, 1, (H,))
+    wf.set_params(prm, scope=SCOPE)
+    Jz = np.ones(N)
+    out = wf.vmc_step(ns, seed=111, step=1, couplings=np.append(Jz, 1.0), want_samples=True, want_eloc=True)
+    assert wf.engine_name() == "bf16x3"
+    s, e = out["samples"], out["eloc"]
+    sub = np.arange(0, ns, ns // 256)[:256]
+    e_ref = cport.ising_local_energies(prm, Jz, 1.0, s[sub])
+    check_tfim("cfg5 shard", e[sub], e_ref, tfim_diag_1d(s[sub], Jz), 1.0, N, 2e-5, 3e-6 * N, 1e-4)
+
+
+def test_config3_sharpened():
+    """BASELINE config 3 (J1-J2, N=40, J2=0.5, 50 units, 10 000 samples): 2 048 samples (~80 000 connected configurations) against
+    the NumPy oracle.  E_loc = sum_s H_s exp(log psi_s - log psi_0): the bound scales with sum_s |H_s| |ratio_s|."""
+    from rnnwavefunctions_amd import _lib
+    N, H, ns = 40, 50, 10000
+    prm = sharpened(P.init_gru_params([H], seed=111, heads=HEADS), 114)
+    wf = _lib.NativeWavefunction(_lib.MODEL_CRNN_U1, N, 1, (H,))
+    wf.set_params(prm, scope=SCOPE)
+    J1, J2, Bz = np.ones(N), 0.5 * np.ones(N), np.zeros(N)
+    out = wf.vmc_step(ns, seed=111, step=0, couplings=np.concatenate([J1, J2, Bz, [0.0, 0.0]]), want_samples=True, want_eloc=True)
+    assert wf.engine_name() == "bf16x3"
+    s, e = out["samples"], out["eloc"]
+    assert np.all(s.sum(axis=1) == N // 2)
+    sub = np.arange(0, ns, 4)[:2048]
+    e_ref = np.concatenate([E.j1j2_local_energies(J1, J2, Bz, s[sub[k:k + 256]], lambda x: M.crnn_log_amplitude(prm, x))
+                            for k in range(0, 2048, 256)])
+    # magnitude of the off-diagonal sum per sample, from the oracle in float64 arithmetic on the same configurations
+    mag = np.zeros(len(sub))
+    for k0 in range(0, len(sub), 256):
+        blk = s[sub[k0:k0 + 256]]
+        sig = np.zeros((2 * N * len(blk), N), np.int32)
+        Hm = np.zeros(2 * N * len(blk), np.float32)
+        sH = np.zeros((2 * N, N), np.int32)
+        me = np.zeros(2 * N, np.float32)
+        from rnnwavefunctions_amd.estimators import J1J2Slices
+        slices, total = J1J2Slices(J1, J2, Bz, blk, sig, Hm, sH, me, False)
+        la = M.crnn_log_amplitude(prm, sig[:total]).astype(np.complex128)
+        for j, sl in enumerate(slices):
+            mag[k0 + j] = np.sum(np.abs(Hm[sl]) * np.abs(np.exp(la[sl] - la[sl][0])))
+    d = np.abs(e[sub].astype(np.complex128) - e_ref.astype(np.complex128))
+    bound = 1e-5 * N + 3e-6 * N * mag
+    worst = int(np.argmax(d / bound))
+    d_mean = abs(e[sub].astype(np.complex128).mean() - e_ref.astype(np.complex128).mean()) / N
+    print("cfg3 sharpened: 2048 samples, sum |H||ratio| %.3g .. %.3g (median %.3g); max |dE|/N = %.2e; worst |dE|/bound = %.3f; "
+          "|d<E>|/N = %.2e" % (mag.min(), mag.max(), np.median(mag), d.max() / N, (d / bound)[worst], d_mean))
+    assert np.all(np.isfinite(e.real)) and np.all(np.isfinite(e.imag))
+    assert np.all(d <= bound), "sample %d: |dE| %.3e > bound %.3e" % (worst, d[worst], bound[worst])
+    assert d_mean < 1e-4
+
+
+def test_config4_sharpened():
+    """BASELINE config 4 (2DTFIM_2DRNN 12x12, 50 units, 10 000 samples, float64): 256 samples against the float64 oracle."""
+    from rnnwavefunctions_amd import _lib
+    Nx = Ny = 12
+    N, H, ns = Nx * Ny, 50, 10000
+    prm = sharpened(P.init_mdrnn_params(H, seed=111), 115)
+    wf = _lib.NativeWavefunction(_lib.MODEL_MDRNN2D, Nx, Ny, (H,))
+    wf.set_params(prm, scope=SCOPE)
+    Jz = np.ones((Nx, Ny))
+    out = wf.vmc_step(ns, seed=111, step=0, couplings=np.append(Jz.ravel(), 3.0), want_samples=True, want_eloc=True)
+    s, e = out["samples"], out["eloc"]
+    sub = np.arange(0, ns, ns // 256)[:256]
+    e_ref = np.concatenate([E.ising2d_local_energies(Jz, 3.0, Nx, Ny, s[sub[k:k + 64]], lambda x: M.mdrnn_log_probability(prm, x))
+                            for k in range(0, 256, 64)])
+    sz = 2.0 * s[sub] - 1.0
+    diag = -((sz[:, :-1, :] * sz[:, 1:, :]).sum(axis=(1, 2)) + (sz[:, :, :-1] * sz[:, :, 1:]).sum(axis=(1, 2)))
+    check_tfim("cfg4", e[sub], e_ref, diag, 3.0, N, 1e-10, 1e-10, 1e-9)

@@ -327,6 +327,9 @@ def test_rccl_shardcomm_never_returns_unreduced_arrays():
     assert np.array_equal(g["w"], 2 * np.ones((2, 2))) and np.array_equal(g["b"], 2 * np.arange(3.0))
     with pytest.raises(RuntimeError, match="no transport"):
         D.ShardComm(0, 2).allreduce(m)
+    # a native communicator built through the constructor never switched the in-step reduce on: its moments must be reduced
+    bare = D.ShardComm(1, 2, None, native=nat)
+    assert np.array_equal(bare.reduce_moments(m), 2 * m) and nat.calls[-1] == ("allreduce_f64", 4)
 
 
 _SANITIZED_CASES = r"""
@@ -375,3 +378,70 @@ def test_c_oracle_under_address_and_undefined_behaviour_sanitizers():
                UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1", OMP_NUM_THREADS="4", PYTHONDONTWRITEBYTECODE="1")
     r = subprocess.run([sys.executable, "-c", _SANITIZED_CASES, root], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "sanitized oracle ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def _synthetic_bench_inputs(world, fallback=None, transport="rccl"):
+    import argparse
+    import bench
+    wl = dict(bench.WORKLOADS["cfg2"], weights="init")
+    ns, N = wl["ns"], wl["N"]
+    args = argparse.Namespace(workload="cfg2", steps=20, warmup=3, transport=transport, weights="init")
+    infos = [{"pid_rank": r, "rank": r, "nranks": world, "device": r} for r in range(world)]
+    per_rank = [2.5 + 0.01 * r for r in range(world)]
+    dt = max(per_rank) * 1e-3 * args.steps
+    cell_evals = ns * N * (N - 1) / 2.0
+    flip = {"launches": 20, "total_ms": 20 * 2.36, "cell_evals": 20 * cell_evals, "mfma_flops": 20 * 3.08e12 / 6}
+    cfg5 = None
+    if world > 1:
+        w5 = bench.WORKLOADS["cfg5"]
+        cfg5 = {"workload": w5["desc"], "steps": 2, "warmup": 1, "ms_per_step": 171.0, "value": world * w5["ns"] * w5["N"] / 0.171,
+                "unit": "samples*sites/s", "global_numsamples": world * w5["ns"], "mean_E": -250.0, "note": "synthetic"}
+    return dict(args=args, wl=wl, world=world, dt=dt, step_ms=[2.5] * args.steps, per_rank_ms=per_rank, infos=infos,
+                moments=[-1.0e6, 1.1e8, float(world * ns), 0.0], flip=flip, base={"launches": 3, "total_ms": 0.6},
+                asm={"launches": 3, "total_ms": 0.03}, engine="bf16x3", transport_fallback=fallback, cfg5=cfg5,
+                traffic={"hbm_bytes_per_launch": 1.0e8, "held_clock_ghz": 1.72, "held_clock_source": "synthetic", "build": "test"},
+                last_step=22)
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_bench_rank0_record_assembles_for_every_rank_count(world):
+    """rank 0's JSON assembly driven with synthetic per-rank records, so that a first 8-GPU run cannot die
+    in it: every contract field present, whole-job value, json-serialisable, exit code 0."""
+    import json
+    import bench
+    kw = _synthetic_bench_inputs(world)
+    rec = bench.assemble_record(**kw)
+    rec["parity"] = None
+    rec["cpu_baseline"] = None
+    d = json.loads(json.dumps(rec))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    ns, N = kw["wl"]["ns"], kw["wl"]["N"]
+    assert d["n_gpus"] == world and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["value"] == pytest.approx(world * ns * N / (d["ms_per_step"] * 1e-3))
+    assert d["ms_per_step"] == pytest.approx(max(kw["per_rank_ms"]))          # the slowest rank sets the job's time
+    assert len(d["ms_per_step_per_rank"]) == world and len(d["ranks"]) == world
+    assert d["rccl_nranks"] == world and d["transport_fallback"] is None
+    assert d["config"]["global_numsamples"] == world * ns
+    r = d["roofline"]
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0.3 < r["frac"] < 0.7
+    assert ("cfg5_sharded" in d) == (world > 1)
+    assert bench.exit_status(d) == (0, None)
+
+
+def test_bench_exit_status_is_nonzero_on_red_parity_or_silent_fallback():
+    """a red parity leg or a gloo fallback must not hand the driver an rc-0 number."""
+    import bench
+    rec = bench.assemble_record(**_synthetic_bench_inputs(1))
+    good = {"pass": True, "reproduces_timed_step": True, "max_abs_dE_per_site": 1e-7, "d_meanE_per_site": 1e-9, "tolerance_per_site": 1e-4}
+    assert bench.exit_status(dict(rec, parity=good))[0] == 0
+    assert bench.exit_status(dict(rec, parity=dict(good, **{"pass": False})))[0] == 2
+    assert bench.exit_status(dict(rec, parity=dict(good, reproduces_timed_step=False)))[0] == 2
+    fb = bench.assemble_record(**_synthetic_bench_inputs(8, fallback="RCCL communicator could not be created (rank 3: x)"))
+    assert fb["rccl_nranks"] is None
+    assert bench.exit_status(fb)[0] == 3 and bench.exit_status(fb, allow_fallback=True)[0] == 0
+    # a communicator that spans fewer ranks than the job (N x dp1 passing for dp-N)
+    short = bench.assemble_record(**_synthetic_bench_inputs(8))
+    short["rccl_nranks"] = 1
+    assert bench.exit_status(short)[0] == 3

@@ -18,7 +18,9 @@ import sys
 ORD = [(2, 0), (1, 1), (0, 2), (1, 0), (0, 1), (0, 0)]       # (weight part, state part), smallest products first
 
 
-def gen(NT, NQ):
+def gen_body(NT, NQ, zero=()):
+    """(declarations, asm body, outputs, inputs) of one block; tiles in `zero` start from 0 (first MFMA with the inline constant
+    as C, early-clobber output) instead of accumulating on their incoming value."""
     KS = 6 * NQ + 1
     NB = 3 * NQ + 1
 
@@ -45,7 +47,10 @@ def gen(NT, NQ):
     for m in range(total):
         k, t = divmod(m, NT)
         lines.append("s_waitcnt lgkmcnt(%d)" % (issued - m - 1))
-        lines.append("v_mfma_f32_32x32x16_bf16 %%[c%d], %%[f%d_%d], %%[b%d], %%[c%d]" % (t, k % RING, t, b_idx(k), t))
+        if k == 0 and t in zero:
+            lines.append("v_mfma_f32_32x32x16_bf16 %%[c%d], %%[f%d_%d], %%[b%d], 0" % (t, k % RING, t, b_idx(k)))
+        else:
+            lines.append("v_mfma_f32_32x32x16_bf16 %%[c%d], %%[f%d_%d], %%[b%d], %%[c%d]" % (t, k % RING, t, b_idx(k), t))
         # the register set of fragment m - 1 is free once MFMA m has issued (MFMA m - 1 started >= 32 cycles ago and
         # has long read its operands): refill it with the fragment RING k-steps further on
         r = m - 1 + RING * NT
@@ -58,23 +63,42 @@ def gen(NT, NQ):
     # result needs >= 10 wait states before a VALU read, and the assembler inserts none inside inline asm
     lines += ["s_nop 7", "s_nop 7"]
     body = "\\n\\t".join(lines).replace("%%", "%")
-    outs = ", ".join(['[c%d] "+v"(acc[%d])' % (t, t) for t in range(NT)] +
-                     ['[f%d_%d] "=&v"(f%d_%d)' % (r, t, r, t) for r in range(RING) for t in range(NT)])
     ins = ", ".join(['[b%d] "v"(B[%d])' % (i, i) for i in range(NB)] + ['[aa] "v"(a_addr)'])
     decl = "u32x4 " + ", ".join("f%d_%d" % (r, t) for r in range(RING) for t in range(NT)) + ";"
-    return '''template <> struct MfmaSegAsm<%d, %d> {
-    static constexpr bool kAvailable = true;
-    // a_addr: LDS byte address of this lane's 16 bytes in fragment 0 of the A image; B: the %d state quads
-    // (3 parts x %d k-steps, then the special k-step); acc: in = bias / one-hot rows, out = pre-activations.
-    static __device__ __forceinline__ void run(unsigned a_addr, const u32x4 (&B)[%d], f32x16 (&acc)[%d]) {
+    outs = ", ".join(['[c%d] "%s"(c%d)' % (t, "=&v" if t in zero else "+v", t) for t in range(NT)] +
+                     ['[f%d_%d] "=&v"(f%d_%d)' % (r, t, r, t) for r in range(RING) for t in range(NT)])
+    return decl, body, outs, ins
+
+
+def gen(NT, NQ):
+    NB = 3 * NQ + 1
+    cargs = ", ".join("f32x16& c%d" % t for t in range(NT))
+    ccall = ", ".join("acc[%d]" % t for t in range(NT))
+    fn = '''    static __device__ __forceinline__ void %s(unsigned a_addr, const u32x4 (&B)[%d], %s) {
         %s
         asm volatile("%s"
                      : %s
                      : %s
                      : "memory");
     }
+'''
+    variants = ""
+    for name, zero in (("run_tiles", ()), ("run_tiles_from_zero", tuple(range(NT))), ("run_tiles_zero_2_4", (2, 4))):
+        decl, body, outs, ins = gen_body(NT, NQ, zero)
+        variants += fn % (name, NB, cargs, decl, body, outs, ins)
+    return '''template <> struct MfmaSegAsm<%d, %d> {
+    static constexpr bool kAvailable = true;
+    // a_addr: LDS byte address of this lane's 16 bytes in fragment 0 of the A image; B: the %d state quads
+    // (3 parts x %d k-steps, then the special k-step); c0..: in = bias / one-hot rows (or the sums so far), out = pre-activations.
+    // Separate accumulator references: the stacked-layer kernels run the block twice per step - X block, H block - on
+    // different subsets of their seven accumulator tiles (split_pp.h: SplitPPUpper); their biases travel in two spare K entries of
+    // the special k-step, so run_tiles_from_zero starts every tile from 0 (no accumulator preload, no registers held for it) and
+    // run_tiles_zero_2_4 continues tiles 0, 1, 3 (r, u, mixed 0) while tiles 2, 4 (q, mixed 1 of the H block) start from 0.
+%s    static __device__ __forceinline__ void run(unsigned a_addr, const u32x4 (&B)[%d], f32x16 (&acc)[%d]) {
+        run_tiles(a_addr, B, %s);
+    }
 };
-''' % (NT, NQ, NB, NQ, NB, NT, decl, body, outs, ins)
+''' % (NT, NQ, NB, NQ, variants, NB, NT, ccall)
 
 
 HEADER = '''// GENERATED by tools/gen_split_mfma_asm.py - do not edit (edit the generator).
