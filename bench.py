@@ -49,6 +49,9 @@ WORKLOADS = {
                     desc="1DTFIM pRNN N=80 units=[50,50] numsamples=10000 (config 2's size, two stacked GRU layers)"),
     "cfg2_l3": dict(kind="tfim1d", N=80, H=50, ns=10000, Bx=1.0, layers=3,
                     desc="1DTFIM pRNN N=80 units=[50,50,50] numsamples=10000 (config 2's size, three stacked GRU layers)"),
+    # the complex wave function's default is a two-layer stack (J1J2/ComplexRNNwavefunction.py:16,40): config 3's size with units=[50,50]
+    "cfg3_l2": dict(kind="j1j2", N=40, H=50, ns=10000, J2=0.5, layers=2,
+                    desc="J1J2 cRNN N=40 J2=0.5 U(1) mask units=[50,50] numsamples=10000 (config 3's size, two stacked GRU layers)"),
 }
 # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA = f32 vector peak; f64 matrix = f64 vector peak; bf16 MFMA
 # dense 2 500 TF/s.  The bf16x3 engine spends SIX bf16 products per f32 product (csrc/split_core.h), so the roof of
@@ -73,7 +76,7 @@ def f_cell_gru(h):
 def f_cell(wl):
     h = wl["H"]
     if wl["kind"] == "j1j2":
-        return f_cell_gru(h) + 4 * h          # second Dense(2) head
+        return f_cell_gru(h) + 4 * h + (wl.get("layers", 1) - 1) * 12 * h * h         # second Dense(2) head; stacked layers as below
     if wl["kind"] == "tfim2d":
         return 4 * h * h + 12 * h             # MDRNN: 4h^2 + 4dh + 4h
     # stacked layers: every layer above the first has an h-wide input instead of the 2-wide one-hot: 6h^2 + 6h^2
@@ -85,8 +88,9 @@ def make_wavefunction(wl, device):
     N, H = wl["N"], wl["H"]
     scale = 3.0 if wl.get("weights") == "trained" else 1.0    # "trained-like" = kernels x 3
     if wl["kind"] == "j1j2":
-        prm = P.init_gru_params([H], seed=111, heads=("wf_dense_ampl", "wf_dense_phase"))
-        wf = _lib.NativeWavefunction(_lib.MODEL_CRNN_U1, N, 1, (H,), device=device)
+        L = wl.get("layers", 1)
+        prm = P.init_gru_params([H] * L, seed=111, heads=("wf_dense_ampl", "wf_dense_phase"))
+        wf = _lib.NativeWavefunction(_lib.MODEL_CRNN_U1, N, 1, (H,) * L, device=device)
         couplings = np.concatenate([np.ones(N), wl["J2"] * np.ones(N), np.zeros(N), [0.0, 0.0]])
     elif wl["kind"] == "tfim2d_gru":
         prm = P.init_gru_params([H], seed=111, dtype=np.float64)
@@ -202,7 +206,7 @@ def oracle_local_energies(wl, prm, couplings, samples):
 
 # samples of the parity leg per workload: what ~10-15 s of the box's host cores score (config 2: the whole batch)
 PARITY_SAMPLES = {"cfg1": 500, "cfg2": 10000, "cfg3": 2048, "cfg4": 256, "cfg5": 512, "w64": 2000, "2d1drnn": 256,
-                  "cfg2_parity": 256, "cfg2_l2": 256, "cfg2_l3": 192}
+                  "cfg2_parity": 256, "cfg2_l2": 256, "cfg2_l3": 192, "cfg3_l2": 512}
 
 
 def parity_leg(workload, wl, wf, prm, couplings, step_index, offset, timed_moments):

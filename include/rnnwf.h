@@ -175,7 +175,7 @@ int rnnwf_vmc_step(rnnwf_handle* h, int64_t numsamples, uint64_t seed, uint64_t 
  *   (Im E_s - mean_energy_im) d Im log psi]; mean_energy_im is ignored for the positive RNNs.
  *   The 2D drivers (2DTFIM_2DRNN/Training2DRNN_2DTFIM.py:163, 2DTFIM_1DRNN/Training1DRNN_2DTFIM.py:160) use the
  *   first cost in float64.  Every width rnnwf_create accepts (above 68 / 52 units the backward operand is read through
- *   L2 instead of LDS).  Stacked layers (len(units) 2..3, every GRU model): one backward pass per
+ *   L2 instead of LDS).  Stacked layers (len(units) 2..RNNWF_MAX_LAYERS, every GRU model): one backward pass per
  *   layer, top first.  GRU1D_PARITY (the import switch of 1DTFIM/TrainingRNN_1DTFIM.py:10): log P_sym =
  *   log(0.5 (P(s) + P(reversed s))), two backward passes weighted by each direction's share of P_sym.
  *   Every reduction has a fixed order: the same batch gives the same bits.
@@ -222,8 +222,10 @@ int rnnwf_comm_destroy(rnnwf_handle* h);
  * kernel ids: 0 = base pass (sample / teacher-forced + checkpoints), 1 = flip pass (dominant),
  *             2 = local-energy assembly + moments, 3 = back-propagation through time of rnnwf_vmc_gradient,
  *             4 = its weight-gradient GEMM.  total_ms / launches accumulate since the
- *             last rnnwf_timing_reset.  work[0] = cell evaluations, work[1] = MFMA flops issued
- *             (padding included) by the flip pass since the last reset.
+ *             last rnnwf_timing_reset.  Stacked layers on the bf16x3 engine: id 1 brackets the whole
+ *             pipeline of per-layer kernels as ONE launch.  work[] is the same for every id: work[0] =
+ *             cell evaluations (all layers of a chain step count as one), work[1] = MFMA flops issued
+ *             (padding included), both by the flip / swap pass (id 1) since the last reset.
  * rnnwf_timing_enable: on = 0 off, 1 all groups, 2 the dominant pass (id 1) only - two events per step instead of
  *             ten, which is what a throughput measurement wants beside its roofline figure.       */
 int rnnwf_timing_enable(rnnwf_handle* h, int32_t on);
@@ -231,9 +233,11 @@ int rnnwf_timing_reset(rnnwf_handle* h);
 int rnnwf_timing_get(rnnwf_handle* h, int32_t kernel_id, double* total_ms, int64_t* launches, double* work);
 /* Which matrix engine the dominant (flip / swap) pass of this handle uses, decided at rnnwf_commit_params:
  *   "bf16x3"  - both operands held exactly as three bf16 parts, six bf16 MFMA products, f32 accumulate
- *               (f32 models; f32 accuracy, see csrc/split_core.h; above 68 units one weight part is read through L2);
- *   "f32mfma" - f32-input MFMA (forced with RNNWF_ENGINE=f32; always used for stacked layers, the base pass, sampling
- *               and log_probability);
+ *               (f32 models up to 100 units; f32 accuracy, see csrc/split_core.h; above 68 units one weight part is read
+ *               through L2; stacked layers of 37..50 units: one kernel per layer, csrc/split_kernels.h).  With one layer of
+ *               37..52 units the base pass (sampling, log_probability) runs on the same engine (cooperative kernel);
+ *   "f32mfma" - f32-input MFMA: forced with RNNWF_ENGINE=f32; above 100 units; stacked layers of other widths; batches too
+ *               small to fill the chip with 32-chain tiles; every other base pass;
  *   "f64mfma" - the float64 models.                                                                     */
 const char* rnnwf_engine_name(const rnnwf_handle* h);
 /* hipDeviceSynchronize on the handle's device (bench.py brackets its timed region with it). */

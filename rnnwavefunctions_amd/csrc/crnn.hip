@@ -170,8 +170,19 @@ CrnnArgs base_args(rnnwf_handle* h, int64_t ns) {
 }
 
 int64_t max_chains_per_pass(rnnwf_handle* h) {
-    const size_t per_block = (size_t)hck_sites(h) * hck_bytes_per_block(h);
+    size_t per_block = (size_t)hck_sites(h) * hck_bytes_per_block(h);
+    if (h->NL > 1 && h->engine_split)                         // the layer pipeline's records: ~2 items per sample and site, per 16 chains
+        per_block += stack_record_bytes_per_32_chains(h, (int64_t)h->N * (h->N - 1) / 2) + stack_record_bytes_per_32_chains(h, 4 * (int64_t)h->N);
     return std::max<int64_t>(1, (int64_t)(state_budget_bytes(h, kHckBudget) / per_block)) * kChains;
+}
+
+// Upper bound of the wave-steps (32-item tiles x chain length) of one swap pass: first-changed site lo owns the bonds (lo, lo + 1) and
+// (lo, lo + 2), with periodic couplings also (N - 1, 0), (N - 2, 0) at lo = 0 and (N - 1, 1) at lo = 1 (j1j2_enumerate_kernel) - at most
+// 4, 3, 2, 2, ... items per sample.
+int64_t stack_max_records(int N, int64_t ns) {
+    int64_t r = 0;
+    for (int lo = 0; lo < N - 1; ++lo) r += ((int64_t)(lo == 0 ? 4 : lo == 1 ? 3 : 2) * ns + 31) / 32 * (N - 1 - lo);
+    return std::max<int64_t>(r, 1);
 }
 
 // J1-J2 local energies of the ns chains whose packed spins are in h->bits (drawn here when `sampling`).
@@ -185,7 +196,7 @@ int j1j2_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
     if (int rc = ensure(h, h->hck, (size_t)hck_sites(h) * nsb * hck_bytes_per_block(h))) return rc;
     if (int rc = ensure(h, h->cbase, (size_t)N * ns * sizeof(double2))) return rc;
     if (int rc = ensure(h, h->cout, (size_t)ns * (sizeof(double2) + sizeof(double)))) return rc;
-    if (int rc = ensure(h, h->tile_count, (size_t)(2 * N + 8) * 4 + 64)) return rc;
+    if (int rc = ensure(h, h->tile_count, (size_t)(2 * N + 8) * 4 + 64 + (size_t)N * 8)) return rc;
     if (int rc = ensure(h, h->tiles, (size_t)N * cap * sizeof(SwapItem))) return rc;
     if (int rc = ensure(h, h->lpq, (size_t)ns * 2 * N * sizeof(double2))) return rc;
     if (int rc = ensure(h, h->eloc, (size_t)ns * sizeof(float2))) return rc;
@@ -195,6 +206,8 @@ int j1j2_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
     int32_t* cnt = (int32_t*)h->tile_count.p;
     int32_t* tile_start = cnt + N;
     int64_t* total_items = (int64_t*)((char*)h->tile_count.p + (((size_t)(2 * N + 1) * 4 + 15) / 16) * 16);
+    const bool stack = h->engine_split && h->NL > 1;
+    int64_t* rec_start = stack ? total_items + 4 : nullptr;     // [N] first record of each site's tiles (layer pipeline)
 
     CrnnArgs a = base_args(h, ns);
     a.bits = (uint32_t*)h->bits.p;
@@ -224,7 +237,7 @@ int j1j2_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
         // the three totals land in pinned[64..88) - written by the kernel itself - and are read at the caller's next stream sync
         // (collect_totals)
         j1j2_tile_scan_kernel<<<1, 64, 0, h->stream>>>(cnt, N, tile_start, total_items, (int64_t*)((char*)h->pinned_dev + 64),
-                                                       h->engine_split ? 32 : kChains);
+                                                       h->engine_split ? 32 : kChains, rec_start);
         RNNWF_HIP(h, hipGetLastError());
     }
     a.sampling = 0;
@@ -234,7 +247,10 @@ int j1j2_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
     a.cap = cap;
     a.contrib = (double2*)h->lpq.p;
     const int64_t max_tiles = (int64_t)N * ((2 * ns + kChains - 1) / kChains + 2);
-    if (h->engine_split) {
+    if (stack) {
+        a.rec_start = rec_start;
+        if (int rc = crnn_stack_swap(h, a, max_tiles, stack_max_records(N, ns))) return rc;
+    } else if (h->engine_split) {
         if (int rc = crnn_split_swap(h, a, max_tiles)) return rc;
     } else {
         if (int rc = launch_swap(h, a, max_tiles)) return rc;
@@ -253,7 +269,7 @@ int j1j2_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
 int64_t collect_totals(rnnwf_handle* h, int64_t ns) {
     const int64_t* t = (const int64_t*)((char*)h->pinned + 64);
     h->work[0] += (double)t[1];
-    h->work[1] += (double)t[2] * (h->engine_split ? crnn_split_flops_per_step(h)
+    h->work[1] += (double)t[2] * (h->engine_split ? (h->NL > 1 ? stack_split_flops_per_step(h) : crnn_split_flops_per_step(h))
                                                   : (double)(3 * h->NFULL + 1) * (4 * h->NFULL + 1) * 2048.0);
     return t[0] + ns;   // + one diagonal configuration per sample
 }
@@ -263,8 +279,12 @@ int64_t collect_totals(rnnwf_handle* h, int64_t ns) {
 int rnnwf::crnn_pack_image(rnnwf_handle* h, std::vector<char>& img) {
     // swap-pass engine: bf16x3 on the matrix core (RNNWF_ENGINE=f32: f32-input MFMA everywhere; above 68 units the w3
     // fragments are read through L2, split_stream.hip)
-    h->engine_split = h->NL == 1 && h->knobs.engine != 1 && h->NFULL <= 6;     // stacked layers, > 100 units: f32-input MFMA
-    if (h->engine_split) {
+    // stacked layers of 37..50 units: a pipeline of bf16x3 kernels, one per layer (split.hip: crnn_stack_swap); other stacks and
+    // > 100 units: f32-input MFMA
+    h->engine_split = h->knobs.engine != 1 && (h->NL == 1 ? h->NFULL <= 6 : stack_split_available(h));
+    if (h->engine_split && h->NL > 1) {
+        if (int rc = crnn_stack_pack(h)) return rc;
+    } else if (h->engine_split) {
         std::vector<char> simg;
         if (int rc = crnn_split_pack(h, simg)) return rc;
         if (int rc = ensure(h, h->wsplit, simg.size())) return rc;

@@ -43,6 +43,7 @@ struct CrnnArgs {
     const SwapItem* items;     // [N][cap]
     int64_t cap;
     double2* contrib;          // [2N][ns]  (bond slot major: the assembly kernel reads it coalesced)
+    const int64_t* rec_start;  // [N] first wave-step record of site lo's tiles (stacked layers on the bf16x3 engine), nullptr otherwise
 };
 
 // One site of the complex RNN (ComplexRNNwavefunction.py:83-93,143-157) from the head outputs
@@ -310,10 +311,13 @@ static __global__ void __launch_bounds__(256) j1j2_enumerate_kernel(J1J2Args a) 
 // totals[2] = sum tiles[lo] (N-1-lo) (wave-steps actually issued)
 // One wave: lane l takes the sites l, l + 64, ... (one load each instead of N dependent ones), wave-level prefix sums.
 // totals_host: the same three numbers straight into pinned host memory (read after the caller's stream sync; no copy launch).
+// rec_start (optional; stacked layers on the bf16x3 engine): rec_start[lo] = sum_{l < lo} tiles[l] (N-1-l), the first wave-step record of
+// the tiles of site lo in the layer pipeline's record buffers (split_kernels.h).
 static __global__ void __launch_bounds__(64) j1j2_tile_scan_kernel(const int32_t* cnt, int N, int32_t* tile_start, int64_t* totals,
-                                                                   int64_t* totals_host, int tile_items) {
+                                                                   int64_t* totals_host, int tile_items, int64_t* rec_start = nullptr) {
     const int lane = threadIdx.x;
     int32_t carry = 0;
+    int64_t rcarry = 0;
     int64_t items = 0, evals = 0, wsteps = 0;
     for (int base = 0; base < N; base += 64) {
         const int lo = base + lane;
@@ -327,6 +331,17 @@ static __global__ void __launch_bounds__(64) j1j2_tile_scan_kernel(const int32_t
         }
         if (lo < N) tile_start[lo] = carry + incl - t;
         carry += __shfl(incl, 63);
+        if (rec_start) {                                     // the same scan over tiles x chain length
+            const int64_t w = lo < N ? (int64_t)t * (N - 1 - lo) : 0;
+            int64_t rincl = w;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int64_t v = __shfl_up(rincl, d);
+                if (lane >= d) rincl += v;
+            }
+            if (lo < N) rec_start[lo] = rcarry + rincl - w;
+            rcarry += __shfl(rincl, 63);
+        }
         if (lo < N) {
             items += c;
             evals += (int64_t)c * (N - 1 - lo);

@@ -3,6 +3,7 @@
 #include "crnn_kernels.h"
 #include "split_core.h"
 #include "split_pp.h"
+#include "split_kernels.h"
 
 namespace rnnwf {
 
@@ -106,8 +107,10 @@ __global__ void __launch_bounds__(WAVES * 64, (3 * NF32 + (3 * RJ + 15) / 16) <=
 // segment of one wave beside the VALU segment of the other, K-packed layout MODE 2 (37..50 units).  Tiles come from
 // the device-side table (tile_start[lo] = first 32-item tile of first-changed site lo, longest chains first); the walk
 // is the same snake, so the waves of a workgroup carry the same number of steps within a few.
-template <int NF32, int RJ>
-__global__ void __launch_bounds__(512) crnn_swap_pp_kernel(CrnnArgs a, const void* wsplit, int kt16) {
+// STACK: first layer of a stack (see prnn_flip_pp_kernel): interleaved checkpoint rows, a record of every step's new state for the
+// layer above (record index: a.rec_start[lo] + (tile - tile_start[lo]) (N - 1 - lo) + step), no heads and no output.
+template <int NF32, int RJ, bool STACK = false>
+__global__ void __launch_bounds__(512) crnn_swap_pp_kernel(CrnnArgs a, const void* wsplit, int kt16, StackArgs st) {
     using PP = SplitPP<NF32, RJ, 3>;
     using C = typename PP::C;
     using L = typename C::L;
@@ -154,6 +157,7 @@ __global__ void __launch_bounds__(512) crnn_swap_pp_kernel(CrnnArgs a, const voi
     float h[NU];
     u32x4 B[NB];
     f32x16 acc[NT];
+    int64_t rec = 0;
     auto next_tile = [&]() {
         for (;;) {
             ++round;
@@ -168,7 +172,7 @@ __global__ void __launch_bounds__(512) crnn_swap_pp_kernel(CrnnArgs a, const voi
         valid = k < a.cnt[lo];
         it = a.items[(int64_t)lo * a.cap + (valid ? k : 0)];
         s = it.s;
-        const float* src = hck + (((int64_t)lo * a.nsb + (s >> 4)) * kt16) * 64 + (s & 15);
+        const float* src = hck + (((int64_t)lo * a.nsb + (s >> 4)) * (STACK ? st.kstride : kt16) + (STACK ? st.koff : 0)) * 64 + (s & 15);
         auto off = [](int u) { return (u >> 2) * 64 + ((u & 3) << 4); };
 #pragma unroll
         for (int e = 0; e < NU; ++e) {
@@ -176,6 +180,7 @@ __global__ void __launch_bounds__(512) crnn_swap_pp_kernel(CrnnArgs a, const voi
             const int d = off(u1) - off(u0);
             h[e] = (src + (hh ? d : 0))[off(u0)];              // HP <= 4 kt16: host-checked
         }
+        if constexpr (STACK) rec = a.rec_start[lo] + (tile - a.tile_start[lo]) * (int64_t)(N - 1 - lo);
         num_up = 0;
         for (int w = 0; w < (lo >> 5); ++w) num_up += __popc(a.bits[(int64_t)w * a.ns + s]);
         word = a.bits[(int64_t)(lo >> 5) * a.ns + s];
@@ -201,7 +206,7 @@ __global__ void __launch_bounds__(512) crnn_swap_pp_kernel(CrnnArgs a, const voi
             // The three head rows ride in spare slots of the mixed tiles (pack_split.h): this step's accumulators hold the
             // logits of the state that ENTERED it, i.e. of site n - 1 (spin sig_in, up-spins before it num_up - sig_in).
             // Site lo is not part of the sum; the chain's last site gets its logits from the VALU head below.
-            if (n > lo + 1) {
+            if (!STACK && n > lo + 1) {
                 float zp[3];
                 PP::head_lagged(acc, zp);
                 float la0, la1, w0, ph0, ph1;
@@ -210,8 +215,12 @@ __global__ void __launch_bounds__(512) crnn_swap_pp_kernel(CrnnArgs a, const voi
                 im += (double)(sig_in ? ph1 : ph0);
             }
             PP::gates(lds, sig_in, acc, h, lane);
+            if constexpr (STACK) {
+                store_record<NU>(st.xout, rec, h, lane);
+                ++rec;
+            }
             const int sig = (int)((word >> (n & 31)) & 1) ^ (n == it.hi ? 1 : 0);
-            if (n + 1 == N) {
+            if (!STACK && n + 1 == N) {
                 float z[3];
                 PP::head(lds, h, lane, z);
                 float la0, la1, w0, ph0, ph1;
@@ -223,7 +232,7 @@ __global__ void __launch_bounds__(512) crnn_swap_pp_kernel(CrnnArgs a, const voi
             sig_in = sig;
             ++n;
             if (n == N) {
-                if (valid && hh == 0) {
+                if (!STACK && valid && hh == 0) {
                     const double2 b = a.cb[(int64_t)lo * a.ns + s];
                     const double2 t = a.tot[s];
                     const double dre = b.x + re - t.x, dim = b.y + im - t.y;
@@ -239,6 +248,191 @@ __global__ void __launch_bounds__(512) crnn_swap_pp_kernel(CrnnArgs a, const voi
                 PP::preload(lds, sig_in, lane, acc);
                 PP::split(h, B);
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!late) __builtin_amdgcn_s_barrier();
+}
+
+// One GRU layer above the first of the complex RNN's stack (its default: two layers, J1J2/ComplexRNNwavefunction.py:16,40), ping-pong
+// form: prnn_flip_pp_upper_kernel's step (split_kernels.h) on the swap pass's tiles.  LAST: three head rows (amplitude logit
+// difference, two phase logits), the U(1) mask's running up-spin count, and the item's contribution H exp(log psi(s') - log psi(s)).
+template <int NF32, int RJ, bool LAST>
+__global__ void __launch_bounds__(512) crnn_swap_pp_upper_kernel(CrnnArgs a, const void* wup, int kt16, StackArgs st) {
+    using PU = SplitPPUpper<NF32, RJ, 3>;
+    using U = typename PU::U;
+    using L = typename PU::L;
+    constexpr int NU = PU::NU, NTA = PU::NTA, NB = PU::NB, WAVES = 8, REC = U::RECORD_FLOATS, NG = U::NG;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    __shared__ int max_steps;
+    if (threadIdx.x == 0) max_steps = 0;
+    PU::stage(lds, wup);
+    const int lane = threadIdx.x & 63, c = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool late = wave >= 4;
+    const int64_t gw = (int64_t)blockIdx.x * WAVES + wave;
+    const int64_t nw = (int64_t)gridDim.x * WAVES;
+    const int N = a.N;
+    const int64_t ntiles = a.tile_start[N];
+    const float* hck = reinterpret_cast<const float*>(a.hck);
+    char* slot = lds + ((U::BYTES + 15) / 16) * 16 + (size_t)wave * U::SLOT_BYTES;
+    auto tile_of = [&](int64_t r) -> int64_t { return r * nw + ((r & 1) ? nw - 1 - gw : gw); };
+    auto lo_of = [&](int64_t t) -> int {
+        int l = 0, r = N;
+        while (r - l > 1) {
+            const int mid = (l + r) >> 1;
+            if (a.tile_start[mid] <= t) l = mid; else r = mid;
+        }
+        return l;
+    };
+    {
+        int mine = 0;
+        for (int64_t r = 0; r * nw < ntiles; ++r) {
+            const int64_t t = tile_of(r);
+            if (t < ntiles) mine += N - 1 - lo_of(t);
+        }
+        if (lane == 0) atomicMax(&max_steps, mine);
+        __syncthreads();
+    }
+    const int iters = max_steps;
+
+    int64_t round = 0, tile = tile_of(0), rec = 0;
+    bool active = tile < ntiles;
+    int lo = 0, n = 0, sig_in = 0, num_up = 0, s = 0;
+    bool valid = false;
+    SwapItem it{};
+    uint32_t word = 0;
+    double re = 0.0, im = 0.0;
+    float h[NU];
+    u32x4 BX[NB], BH[NB];
+    f32x16 acc[NTA];
+    typedef __attribute__((address_space(3))) void* LdsVoid;
+    typedef const __attribute__((address_space(1))) void* GlobVoid;
+    auto dma_record = [&](int64_t r) {
+        const float* src = st.xin + r * (int64_t)REC + lane * 4;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) __builtin_amdgcn_global_load_lds((GlobVoid)(src + g * 256), (LdsVoid)(slot + g * 1024), 16, 0, 0);
+    };
+    auto read_record = [&](float (&x)[NU]) {
+        const float4* p = reinterpret_cast<const float4*>(slot) + lane;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const float4 v = p[g * 64];
+            x[4 * g] = v.x;
+            if (4 * g + 1 < NU) x[4 * g + 1] = v.y;
+            if (4 * g + 2 < NU) x[4 * g + 2] = v.z;
+            if (4 * g + 3 < NU) x[4 * g + 3] = v.w;
+        }
+    };
+    auto wait_vm = [&]() { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); };
+    auto wait_lds = [&]() { __builtin_amdgcn_s_waitcnt(0xC07F); asm volatile("" ::: "memory"); };
+    auto next_tile = [&]() {
+        for (;;) {
+            ++round;
+            if (round * nw >= ntiles) { active = false; return; }
+            tile = tile_of(round);
+            if (tile < ntiles) { active = true; return; }
+        }
+    };
+    // A tile's item list is data dependent (one more dependent load than the TFIM pass's), so the switch is taken in place: item,
+    // checkpoint and first record are requested and waited for here - once per tile of N - 1 - lo steps.
+    auto begin_tile = [&]() {
+        lo = lo_of(tile);
+        const int k = (int)(tile - a.tile_start[lo]) * 32 + c;
+        valid = k < a.cnt[lo];
+        it = a.items[(int64_t)lo * a.cap + (valid ? k : 0)];
+        s = it.s;
+        rec = a.rec_start[lo] + (tile - a.tile_start[lo]) * (int64_t)(N - 1 - lo);
+        dma_record(rec);
+        const float* src = hck + (((int64_t)lo * a.nsb + (s >> 4)) * st.kstride + st.koff) * 64 + (s & 15);
+        auto off = [](int u) { return (u >> 2) * 64 + ((u & 3) << 4); };
+#pragma unroll
+        for (int e = 0; e < NU; ++e) {
+            const int u0 = L::unit_of(e, 0), u1 = L::unit_of(e, 1);
+            const int d = off(u1) - off(u0);
+            h[e] = (src + (hh ? d : 0))[off(u0)];
+        }
+        n = lo + 1;
+        if constexpr (LAST) {
+            num_up = 0;
+            for (int w = 0; w < (lo >> 5); ++w) num_up += __popc(a.bits[(int64_t)w * a.ns + s]);
+            word = a.bits[(int64_t)(lo >> 5) * a.ns + s];
+            num_up += __popc(word & ((1u << (lo & 31)) - 1u));
+            sig_in = 1 - (int)((word >> (lo & 31)) & 1);
+            num_up += sig_in;
+            if ((n & 31) == 0 && n < N) word = a.bits[(int64_t)(n >> 5) * a.ns + s];
+            re = 0.0; im = 0.0;
+        }
+    };
+    auto load_quads = [&](bool fresh) {                       // BH <- h, BX <- the record in flight
+        PU::split(h, BH);
+        // behind the record's transfer only this segment's NG record stores may still be on their way (a fresh tile: wait for all)
+        if (LAST || fresh) __builtin_amdgcn_s_waitcnt(0x0F70);
+        else __builtin_amdgcn_s_waitcnt(0x0F70 | NG);
+        asm volatile("" ::: "memory");
+        read_record(h);
+        PU::split(h, BX);
+        wait_lds();
+    };
+    if (active) {
+        begin_tile();
+        load_quads(true);
+    }
+    if (late) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+    for (int itn = 0; itn < iters; ++itn) {
+        if (active) PU::mfma_seg(lds, BX, BH, acc, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (active) {
+            const bool last = n + 1 == N;
+            if (!last) dma_record(rec + 1);
+            asm volatile("" ::: "memory");
+            if constexpr (LAST) {
+                // head rows of the state that ENTERED the step: site n - 1 (spin sig_in, up-spins before it num_up - sig_in)
+                if (n > lo + 1) {
+                    float zp[3];
+                    PU::head_lagged(acc, zp);
+                    float la0, la1, w0, ph0, ph1;
+                    crnn_site(zp, n - 1, N, num_up - sig_in, la0, la1, w0, ph0, ph1);
+                    re += (double)(sig_in ? la1 : la0);
+                    im += (double)(sig_in ? ph1 : ph0);
+                }
+            }
+            PU::gates_rem(acc, BH, h);
+            PU::gates_full(acc, BH, h);
+            if constexpr (!LAST) store_record<NU>(st.xout, rec, h, lane);
+            if constexpr (LAST) {
+                const int sig = (int)((word >> (n & 31)) & 1) ^ (n == it.hi ? 1 : 0);
+                if (last) {
+                    float z[3];
+                    PU::head(lds, h, lane, z);
+                    float la0, la1, w0, ph0, ph1;
+                    crnn_site(z, n, N, num_up, la0, la1, w0, ph0, ph1);
+                    re += (double)(sig ? la1 : la0);
+                    im += (double)(sig ? ph1 : ph0);
+                    if (valid && hh == 0) {
+                        const double2 b = a.cb[(int64_t)lo * a.ns + s];
+                        const double2 t = a.tot[s];
+                        const double dre = b.x + re - t.x, dim = b.y + im - t.y;
+                        const double mag = exp(dre) * (double)it.coef;
+                        a.contrib[(int64_t)it.slot * a.ns + s] = make_double2(mag * cos(dim), mag * sin(dim));
+                    }
+                }
+                num_up += sig;
+                sig_in = sig;
+            }
+            ++n;
+            ++rec;
+            if (last) {
+                next_tile();
+                if (active) begin_tile();
+            } else if constexpr (LAST) {
+                if ((n & 31) == 0) word = a.bits[(int64_t)(n >> 5) * a.ns + s];
+            }
+            if (active) load_quads(last);
         }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();

@@ -39,6 +39,7 @@ struct MLaunch {
         *grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
         return 0;
     }
+#ifdef RNNWF_DIAGNOSTICS      // measured negative (profiles/r03_d_cfg4_prefetch.md), kept for A/B runs of tools/ only: not in the release library
     // prefetching variant (mdrnn_flip_pf_kernel): one 8-wave workgroup per CU, a staging slot per wave behind the spin words
     static constexpr int PF_WAVES = 8;
     static constexpr size_t PF_LDS = L::BYTES + (size_t)PF_WAVES * L::WORDS_BYTES + (size_t)PF_WAVES * ((L::KT + 1) / 2) * 1024;
@@ -60,8 +61,11 @@ struct MLaunch {
         }
         return 0;
     }
+#endif
     static int flip(rnnwf_handle* h, MdArgs a) {
+#ifdef RNNWF_DIAGNOSTICS
         if (PF_FITS && NFULL == 3 && h->knobs.md_prefetch) return flip_pf(h, a);      // A/B only: measured slower (profiles/r03_d_cfg4_prefetch.md)
+#endif
         unsigned grid = 0;
         if (int rc = flip_grid(h, a.ntiles, &grid)) return rc;
         const size_t ring_bytes = (size_t)grid * WAVES * a.Nx * ((L::KT + 1) / 2) * 64 * 16;      // one slot per lattice column

@@ -367,6 +367,7 @@ __global__ void __launch_bounds__(WAVES * 64, NFULL <= 3 ? 2 : 1) mdrnn_flip_ker
     }
 }
 
+#ifdef RNNWF_DIAGNOSTICS
 // The flip pass with the vertical neighbour's state PREFETCHED one step ahead by LDS-DMA (global_load_lds_dwordx4: global
 // memory -> LDS without passing through registers; the kernel above has none to spare - 250 VGPRs at two waves per SIMD).
 // Per wave one 7 KB staging slot in LDS: the transfer of step p + 1's h_v (a base-pass state or one of the chain's own column
@@ -493,5 +494,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) mdrnn_flip_pf_kernel(MdArgs a) 
         if (valid && q == 0) a.lpq[(int64_t)a.row_of_pos[i] * a.ns + s] += lp;
     }
 }
+
+#endif  // RNNWF_DIAGNOSTICS
 
 }  // namespace rnnwf

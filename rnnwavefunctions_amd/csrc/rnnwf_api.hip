@@ -81,9 +81,20 @@ size_t rnnwf::state_budget_bytes(const rnnwf_handle* h, size_t dflt) {
 }
 
 // The environment is consulted here and nowhere else: once per handle, at creation.
-static void read_knobs(Knobs& k) {
+// Returns nullptr, or the offending setting: a value this build does not know is refused (rnnwf_create fails), never ignored.
+static const char* read_knobs(Knobs& k) {
+    if (const char* e = getenv("RNNWF_ENGINE")) {
+        k.engine = !strcmp(e, "f32") ? 1 : !strcmp(e, "bf16x3") ? 2 : -1;
+#ifdef RNNWF_DIAGNOSTICS      // measured negatives kept for A/B runs (docs/history): the release library holds one kernel per model and width class
+        if (const char* e2 = getenv("RNNWF_MDRNN_PREFETCH")) k.md_prefetch = !strcmp(e2, "1");
+        if (k.engine < 0) k.engine = !strcmp(e, "bf16x3-serial") ? 3 : !strcmp(e, "bf16x3-hipcc") ? 4 : !strcmp(e, "bf16x3-asm32") ? 5 : !strcmp(e, "bf16x3-n16") ? 7 : -1;
+#endif
+        if (k.engine < 0 && *e) return "RNNWF_ENGINE (this build knows: f32, bf16x3)";
+        if (k.engine < 0) k.engine = 0;
+    }
+#ifdef RNNWF_DIAGNOSTICS
     if (const char* e = getenv("RNNWF_MDRNN_PREFETCH")) k.md_prefetch = !strcmp(e, "1");
-    if (const char* e = getenv("RNNWF_ENGINE")) k.engine = !strcmp(e, "f32") ? 1 : !strcmp(e, "bf16x3") ? 2 : !strcmp(e, "bf16x3-serial") ? 3 : !strcmp(e, "bf16x3-hipcc") ? 4 : !strcmp(e, "bf16x3-asm32") ? 5 : !strcmp(e, "bf16x3-n16") ? 7 : 0;
+#endif
     if (const char* e = getenv("RNNWF_NO_COOP")) k.no_coop = atoi(e) != 0;
     if (const char* e = getenv("RNNWF_BASE")) k.base_f32 = !strcmp(e, "f32");
     if (const char* e = getenv("RNNWF_STATE_BUDGET_MB")) {
@@ -94,6 +105,7 @@ static void read_knobs(Knobs& k) {
     if (const char* e = getenv("RNNWF_ABLATE")) k.ablate = atoi(e);
     if (const char* e = getenv("RNNWF_ABLATE_BASE")) k.ablate_base = atoi(e);
 #endif
+    return nullptr;
 }
 
 int rnnwf::upload_couplings(rnnwf_handle* h, const double* src, size_t n) {
@@ -139,7 +151,7 @@ extern "C" int rnnwf_create(const rnnwf_config* cfg, rnnwf_handle** out) {
     if (cfg->model < 0 || cfg->model > RNNWF_MODEL_MDRNN2D) return bad("rnnwf_create: unknown model");
     if (cfg->nx < 1 || cfg->ny < 1) return bad("rnnwf_create: system size must be positive");
     if (cfg->num_layers < 1 || cfg->num_layers > RNNWF_MAX_LAYERS)
-        return bad("rnnwf_create: len(units) must be 1..4");
+        return bad("rnnwf_create: len(units) must be 1.." + std::to_string(RNNWF_MAX_LAYERS));
     if (cfg->units[0] < 1) return bad("rnnwf_create: units[0] must be positive");
     if (cfg->num_layers > 1) {
         // MultiRNNCell stacks (1DTFIM/RNNwavefunction.py:32, J1J2/ComplexRNNwavefunction.py:40,
@@ -196,7 +208,11 @@ extern "C" int rnnwf_create(const rnnwf_config* cfg, rnnwf_handle** out) {
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return fail_hip("hipStreamCreate", e);
     if ((e = hipHostMalloc(&h->pinned, 4096, hipHostMallocDefault)) != hipSuccess) return fail_hip("hipHostMalloc", e);
     if ((e = hipHostGetDevicePointer(&h->pinned_dev, h->pinned, 0)) != hipSuccess) return fail_hip("hipHostGetDevicePointer", e);
-    read_knobs(h->knobs);
+    if (const char* badknob = read_knobs(h->knobs)) {
+        g_create_error = std::string("rnnwf_create: unknown value of the environment switch ") + badknob;
+        rnnwf_destroy(h);
+        return RNNWF_ERR_INVALID;
+    }
     declare_params(h);
     *out = h;
     return RNNWF_OK;

@@ -117,7 +117,7 @@ struct CSLaunch {
             const int64_t need = (max_tiles + 7) / 8;
             const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
             TimedLaunch tl(h, 1);
-            crnn_swap_pp_kernel<NF32, RJ><<<grid, 512, L::BYTES, h->stream>>>(a, h->wsplit.p, kt16);
+            crnn_swap_pp_kernel<NF32, RJ><<<grid, 512, L::BYTES, h->stream>>>(a, h->wsplit.p, kt16, StackArgs{});
             RNNWF_HIP(h, hipGetLastError());
             return 0;
         } else {
@@ -142,11 +142,15 @@ struct CSLaunch {
 
 // widths served by the riders form (split_stream.hip): 53..100 units (53..68: RNNWF_ENGINE=bf16x3-serial selects the padded
 // serial kernel of round 1 instead, for A/B runs: 5.55 against 4.56 ms at N=80, 64 units, 10 000 samples)
-bool riders(const rnnwf_handle* h) { return h->NFULL == 6 || (h->NFULL == 4 && h->knobs.engine != 3); }
+bool riders(const rnnwf_handle* h) { return h->NFULL == 6 || (h->NFULL == 4 && h->knobs.engine != 3); }      // (engine 3: diagnostics builds only)
 // 37..52 units, positive RNN: RNNWF_ENGINE=bf16x3-n16 runs the flip pass in the 16x16x32 riders form (split_stream.hip:
 // prnn_flip_riders16n_asm_kernel) instead of the 32x32x16 ping-pong kernel - built and measured in round 3, 10 % slower
 bool riders16n(const rnnwf_handle* h) {
+#ifdef RNNWF_DIAGNOSTICS
     return h->NFULL == 3 && h->model != RNNWF_MODEL_CRNN_U1 && h->knobs.engine == 7;
+#else
+    return false;
+#endif
 }
 
 }  // namespace
@@ -311,8 +315,74 @@ int rnnwf::prnn_stack_flip(rnnwf_handle* h, const PrnnArgs& a) {
         st.xin = (const float*)h->xrec[(l - 1) & 1].p;
         st.xout = l < NL - 1 ? (float*)h->xrec[l & 1].p : nullptr;
         st.koff = l * kt16;
+#ifdef RNNWF_DIAGNOSTICS
+        if (l == NL - 1 && getenv("RNNWF_STAMPS")) {          // in-kernel cycle stamps of the top layer's kernel, median over waves -> stderr (tools/stamps.py)
+            PrnnArgs b = a;
+            const size_t nwv = (size_t)gl * 8;
+            RNNWF_HIP(h, hipMalloc((void**)&b.stamps, nwv * 128));
+            RNNWF_HIP(h, hipMemsetAsync(b.stamps, 0, nwv * 128, h->stream));
+            prnn_flip_pp_upper_kernel<kStackNF32, kStackRJ, true><<<gl, 512, StackU1::LDS_BYTES, h->stream>>>(b, h->wsplit_up[l - 1].p, kt16, st);
+            RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+            std::vector<unsigned long long> sv(nwv * 16);
+            RNNWF_HIP(h, hipMemcpy(sv.data(), b.stamps, nwv * 128, hipMemcpyDeviceToHost));
+            RNNWF_HIP(h, hipFree(b.stamps));
+            const char* names[10] = {"mfma_seg", "barrier_after_mfma", "valu_seg_split_part", "barrier_after_valu", "tile_switch", "total_cycles",
+                                     "realtime_ticks_100MHz", "iterations", "valu_seg_head_gates", "valu_seg_store_head"};
+            fprintf(stderr, "RNNWF_STAMPS upper kernel grid=%u waves=%zu:", gl, nwv);
+            for (int k = 0; k < 10; ++k) {
+                std::vector<unsigned long long> v(nwv);
+                for (size_t w = 0; w < nwv; ++w) v[w] = sv[w * 16 + k];
+                std::sort(v.begin(), v.end());
+                fprintf(stderr, " %s med %llu min %llu max %llu;", names[k], v[nwv / 2], v[0], v[nwv - 1]);
+            }
+            fprintf(stderr, "\n");
+            continue;
+        }
+#endif
         if (l < NL - 1) prnn_flip_pp_upper_kernel<kStackNF32, kStackRJ, false><<<gu, 512, StackU1::LDS_BYTES, h->stream>>>(a, h->wsplit_up[l - 1].p, kt16, st);
         else prnn_flip_pp_upper_kernel<kStackNF32, kStackRJ, true><<<gl, 512, StackU1::LDS_BYTES, h->stream>>>(a, h->wsplit_up[l - 1].p, kt16, st);
+        RNNWF_HIP(h, hipGetLastError());
+    }
+    return 0;
+}
+
+
+int rnnwf::crnn_stack_pack(rnnwf_handle* h) {
+    {
+        const std::vector<char> img = pack_split_image<kStackNF32, kStackRJ, 3, 2>(h);
+        if (int rc = ensure(h, h->wsplit, img.size())) return rc;
+        if (int rc = upload(h, h->wsplit.p, img.data(), img.size())) return rc;
+    }
+    for (int l = 1; l < h->NL; ++l) {
+        const std::vector<char> img = pack_split_upper_image<kStackNF32, kStackRJ, 3>(h, l, l == h->NL - 1);
+        if (int rc = ensure(h, h->wsplit_up[l - 1], img.size())) return rc;
+        if (int rc = upload(h, h->wsplit_up[l - 1].p, img.data(), img.size())) return rc;
+    }
+    return 0;
+}
+
+// max_records: upper bound of the wave-steps of all tiles (crnn.hip derives it from the bonds a first-changed site can have)
+int rnnwf::crnn_stack_swap(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles, int64_t max_records) {
+    using CL0 = SplitLayout<kStackNF32, kStackRJ, 3, 2>;
+    const int kt16 = 4 * h->NFULL + 1, NL = h->NL;
+    if (CL0::HP > 4 * kt16) return h->fail(RNNWF_ERR_INVALID, "bf16x3 layout wider than the checkpoint rows (%d > %d)", CL0::HP, 4 * kt16);
+    const size_t bytes = (size_t)max_records * StackU3::RECORD_FLOATS * 4;
+    if (int rc = ensure(h, h->xrec[0], bytes)) return rc;
+    if (NL > 2) if (int rc = ensure(h, h->xrec[1], bytes)) return rc;
+    unsigned g0 = 0, gu = 0, gl = 0;
+    if (int rc = stack_grid(h, crnn_swap_pp_kernel<kStackNF32, kStackRJ, true>, CL0::BYTES, max_tiles, &g0)) return rc;
+    if (int rc = stack_grid(h, crnn_swap_pp_upper_kernel<kStackNF32, kStackRJ, false>, StackU3::LDS_BYTES, max_tiles, &gu)) return rc;
+    if (int rc = stack_grid(h, crnn_swap_pp_upper_kernel<kStackNF32, kStackRJ, true>, StackU3::LDS_BYTES, max_tiles, &gl)) return rc;
+    TimedLaunch tl(h, 1);
+    StackArgs st{nullptr, (float*)h->xrec[0].p, NL * kt16, 0};
+    crnn_swap_pp_kernel<kStackNF32, kStackRJ, true><<<g0, 512, CL0::BYTES, h->stream>>>(a, h->wsplit.p, kt16, st);
+    RNNWF_HIP(h, hipGetLastError());
+    for (int l = 1; l < NL; ++l) {
+        st.xin = (const float*)h->xrec[(l - 1) & 1].p;
+        st.xout = l < NL - 1 ? (float*)h->xrec[l & 1].p : nullptr;
+        st.koff = l * kt16;
+        if (l < NL - 1) crnn_swap_pp_upper_kernel<kStackNF32, kStackRJ, false><<<gu, 512, StackU3::LDS_BYTES, h->stream>>>(a, h->wsplit_up[l - 1].p, kt16, st);
+        else crnn_swap_pp_upper_kernel<kStackNF32, kStackRJ, true><<<gl, 512, StackU3::LDS_BYTES, h->stream>>>(a, h->wsplit_up[l - 1].p, kt16, st);
         RNNWF_HIP(h, hipGetLastError());
     }
     return 0;
@@ -321,14 +391,18 @@ int rnnwf::prnn_stack_flip(rnnwf_handle* h, const PrnnArgs& a) {
 int rnnwf::prnn_split_flip(rnnwf_handle* h, const PrnnArgs& a) {
     const int kt16 = 4 * h->NFULL + 1;
     if (riders(h)) return prnn_split_flip_stream(h, a, kt16);
+#ifdef RNNWF_DIAGNOSTICS
     if (riders16n(h)) return prnn_split_flip_16n(h, a, kt16);
     if (h->knobs.engine == 3) { SPLIT_DISPATCH(h, return K::flip(h, a, kt16)); }      // RNNWF_ENGINE=bf16x3-serial: A/B only
-    else { SPLIT_DISPATCH(h, return K::flip_pp(h, a, kt16)); }
+#endif
+    SPLIT_DISPATCH(h, return K::flip_pp(h, a, kt16));
     return h->fail(RNNWF_ERR_INVALID, "no bf16x3 kernel for NFULL=%d", h->NFULL);
 }
 double rnnwf::prnn_split_flops_per_step(rnnwf_handle* h) {
     if (riders(h)) return prnn_split_stream_flops_per_step(h);
+#ifdef RNNWF_DIAGNOSTICS
     if (riders16n(h)) return prnn_split_16n_flops_per_step();
+#endif
     SPLIT_DISPATCH(h, return K::mfma_flops_per_step());
     return 0;
 }
@@ -336,9 +410,11 @@ double rnnwf::prnn_split_flops_per_step(rnnwf_handle* h) {
 
 int rnnwf::prnn_split_pack(rnnwf_handle* h, std::vector<char>& simg) {
     if (riders(h)) return prnn_split_stream_pack(h, simg);
+#ifdef RNNWF_DIAGNOSTICS
     if (riders16n(h)) {
         if (int rc = prnn_split_16n_pack(h)) return rc;
     }
+#endif
     SPLIT_DISPATCH(h, { simg = K::pack(h); return 0; });
     return h->fail(RNNWF_ERR_INVALID, "no bf16x3 layout for NFULL=%d", h->NFULL);
 }
@@ -346,8 +422,10 @@ int rnnwf::prnn_split_pack(rnnwf_handle* h, std::vector<char>& simg) {
 int rnnwf::crnn_split_swap(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles) {
     const int kt16 = 4 * h->NFULL + 1;
     if (riders(h)) return crnn_split_swap_stream(h, a, max_tiles, kt16);
+#ifdef RNNWF_DIAGNOSTICS
     if (h->knobs.engine == 3) { CSPLIT_DISPATCH(h, return K::swap(h, a, max_tiles, kt16)); }      // RNNWF_ENGINE=bf16x3-serial: A/B only
-    else { CSPLIT_DISPATCH(h, return K::swap_pp(h, a, max_tiles, kt16)); }
+#endif
+    CSPLIT_DISPATCH(h, return K::swap_pp(h, a, max_tiles, kt16));
     return h->fail(RNNWF_ERR_INVALID, "no bf16x3 cRNN kernel for NFULL=%d", h->NFULL);
 }
 double rnnwf::crnn_split_flops_per_step(rnnwf_handle* h) {

@@ -19,11 +19,18 @@ struct RLaunch {
     using L = SplitLayout<NF32, RJ, 1, 3>;
     using LC = SplitLayout<NF32, RJ, 3, 3>;                  // complex RNN: three head rows
     static int flip(rnnwf_handle* h, const PrnnArgs& a, int kt16) {
+#ifdef RNNWF_DIAGNOSTICS
         if constexpr (RidersStepAsm<NF32, RJ, 1, L::STREAM>::kAvailable) {
             // default: the 16x16x32 form; RNNWF_ENGINE=bf16x3-asm32: the 32x32x16 asm step; bf16x3-hipcc: the compiler-scheduled step (A/B)
             if (h->knobs.engine != 4 && h->knobs.engine != 5 && h->wsplit16.p) return flip_asm16(h, a, kt16);
             if (h->knobs.engine != 4) return flip_asm(h, a, kt16);
         }
+#else
+        // 69..100 units: the 16x16x32 form (generated asm step); 53..68 units: the compiler-scheduled riders step below
+        if constexpr (L::STREAM) return flip_asm16(h, a, kt16);
+        else
+#endif
+        {
         const void* fn = (const void*)prnn_flip_split_kernel<NF32, RJ, WAVES, 3>;
         if (L::HP > 4 * kt16) return h->fail(RNNWF_ERR_INVALID, "bf16x3 layout wider than the checkpoint rows (%d > %d)", L::HP, 4 * kt16);
         int bpc = 0;
@@ -35,7 +42,9 @@ struct RLaunch {
         prnn_flip_split_kernel<NF32, RJ, WAVES, 3><<<grid, WAVES * 64, L::LDS_BYTES, h->stream>>>(a, h->wsplit.p, kt16);
         RNNWF_HIP(h, hipGetLastError());
         return 0;
+        }
     }
+#ifdef RNNWF_DIAGNOSTICS
     // the same pass with the wave-step as one hand-scheduled asm block (split_riders_asm.h)
     static int flip_asm(rnnwf_handle* h, const PrnnArgs& a, int kt16) {
         const void* fn = (const void*)prnn_flip_riders_asm_kernel<NF32, RJ, WAVES>;
@@ -50,6 +59,7 @@ struct RLaunch {
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }
+#endif
     // the 16x16x32 form (split16_core.h), 69..100 units
     static int flip_asm16(rnnwf_handle* h, const PrnnArgs& a, int kt16) {
         using L16 = S16Layout<1>;
@@ -84,7 +94,8 @@ static_assert(R100::L::STREAM && R100::L::HP == 100 && R100::LC::STREAM, "layout
 static_assert(!R68::L::STREAM && R68::L::HP == 68 && !R68::LC::STREAM, "layout mode 3 at 68 units is LDS-resident");
 }  // namespace
 
-// ---- the 16x16x32 form at 37..52 units (split16_core.h: S16nLayout): the default flip pass of the positive RNN at these widths ----
+#ifdef RNNWF_DIAGNOSTICS
+// ---- the 16x16x32 form at 37..52 units (split16_core.h: S16nLayout): A/B only (RNNWF_ENGINE=bf16x3-n16): measured 10 % slower than the ping-pong kernel ----
 int rnnwf::prnn_split_flip_16n(rnnwf_handle* h, const PrnnArgs& a, int kt16) {
     using L16 = S16nLayout<1>;
     const void* fn = (const void*)prnn_flip_riders16n_asm_kernel<WAVES>;
@@ -107,12 +118,14 @@ int rnnwf::prnn_split_16n_pack(rnnwf_handle* h) {
     return 0;
 }
 
+#endif  // RNNWF_DIAGNOSTICS
+
 int rnnwf::prnn_split_flip_stream(rnnwf_handle* h, const PrnnArgs& a, int kt16) {
     return h->NFULL == 6 ? R100::flip(h, a, kt16) : R68::flip(h, a, kt16);
 }
 double rnnwf::prnn_split_stream_flops_per_step(rnnwf_handle* h) {
     // the 16x16x32 form: 19 tiles x 19 k-steps x 2 chain sets of 16 x 16 x 32 x 2 flop per 32-chain wave-step
-    if (h->NFULL == 6 && h->wsplit16.p && h->knobs.engine != 4 && h->knobs.engine != 5)
+    if (h->NFULL == 6 && h->wsplit16.p && h->knobs.engine != 4 && h->knobs.engine != 5)      // (engines 4, 5: diagnostics builds only)
         return (double)S16Layout<1>::NT * S16Layout<1>::KS * 2 * 16384.0;
     return h->NFULL == 6 ? (double)R100::L::NT * R100::L::KS * 32768.0 : (double)R68::L::NT * R68::L::KS * 32768.0;
 }

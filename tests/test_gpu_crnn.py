@@ -331,6 +331,55 @@ def test_stacked_layers_log_amplitude_sampling_and_eloc_match_oracle(N, H, L, B)
     assert np.allclose(out["eloc"], e2, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("N,H,L,B", [(20, 50, 2, 40), (12, 37, 2, 33), (10, 44, 3, 24), (8, 50, 4, 20), (34, 49, 2, 50), (2, 50, 2, 4)])
+def test_stacked_layers_on_both_engines(N, H, L, B, monkeypatch):
+    """The complex RNN's stack (default: two layers, J1J2/ComplexRNNwavefunction.py:16,40) at 37..50 units on the bf16x3 engine - a
+    pipeline of one ping-pong kernel per layer (csrc/crnn_split_kernels.h: crnn_swap_pp_kernel<.., STACK> -> crnn_swap_pp_upper_kernel)
+    - and on the f32-input MFMA: J1-J2 local energies of both against the oracle, all four flag combinations on the first case."""
+    from rnnwavefunctions_amd import _lib
+    prm = stacked_like(H, L, seed=N + H)
+    s = zero_mag_batch(B, N, 6)
+    rng = np.random.RandomState(N)
+    J1, J2, Bz = 1.0 + 0.1 * rng.standard_normal(N), 0.5 + 0.1 * rng.standard_normal(N), 0.1 * rng.standard_normal(N)
+    flags = [(False, False), (True, False), (False, True), (True, True)] if (N, H) == (20, 50) else [(False, False)]
+    for periodic, marshall in flags:
+        e_ref = E.j1j2_local_energies(J1, J2, Bz, s, lambda x: M.crnn_log_amplitude(prm, x), periodic, marshall)
+        got = {}
+        for engine in ("bf16x3", "f32"):
+            monkeypatch.setenv("RNNWF_ENGINE", engine)
+            wf = _lib.NativeWavefunction(_lib.MODEL_CRNN_U1, N, 1, (H,) * L)
+            wf.set_params(prm, scope="RNNwavefunction")
+            e, ncon = wf.j1j2_eloc(s, J1, J2, Bz, periodic=periodic, marshall=marshall)
+            assert wf.engine_name() == ("bf16x3" if engine == "bf16x3" else "f32mfma")
+            print("L=%d N=%d H=%d %s periodic=%d marshall=%d: max |dE| = %.2e" % (L, N, H, engine, periodic, marshall, np.abs(e - e_ref).max()))
+            assert np.allclose(e, e_ref, rtol=1e-4, atol=1e-4)
+            got[engine] = (e, ncon)
+        assert got["bf16x3"][1] == got["f32"][1]
+        assert np.allclose(got["bf16x3"][0], got["f32"][0], rtol=5e-5, atol=5e-5)
+
+
+def test_stacked_layers_bf16x3_vmc_step_at_speed_size():
+    """The layer pipeline at a batch it is chosen for by default: N=24, units=[50,50], 4 096 samples; 256 of them against the oracle,
+    zero magnetisation, shard invariance bit for bit."""
+    from rnnwavefunctions_amd import _lib
+    N, H, L, ns = 24, 50, 2, 4096
+    prm = stacked_like(H, L, seed=3)
+    wf = _lib.NativeWavefunction(_lib.MODEL_CRNN_U1, N, 1, (H,) * L)
+    wf.set_params(prm, scope="RNNwavefunction")
+    J1, J2, Bz = np.ones(N), 0.5 * np.ones(N), np.zeros(N)
+    c = np.concatenate([J1, J2, Bz, [0.0, 0.0]])
+    out = wf.vmc_step(ns, seed=5, step=1, couplings=c, want_samples=True, want_eloc=True)
+    assert wf.engine_name() == "bf16x3"
+    s, e = out["samples"], out["eloc"]
+    assert np.all(s.sum(axis=1) == N // 2)
+    sub = np.arange(0, ns, 16)
+    e_ref = E.j1j2_local_energies(J1, J2, Bz, s[sub], lambda x: M.crnn_log_amplitude(prm, x), False, False)
+    assert np.allclose(e[sub], e_ref, rtol=1e-4, atol=1e-4)
+    lo = wf.vmc_step(ns // 2, seed=5, step=1, couplings=c, want_eloc=True)
+    hi = wf.vmc_step(ns // 2, seed=5, step=1, couplings=c, sample_offset=ns // 2, want_eloc=True)
+    assert np.array_equal(np.concatenate([lo["eloc"], hi["eloc"]]), e)
+
+
 def test_default_constructor_of_the_complex_wave_function():
     """RNNwavefunction(systemsize, cell) with every other argument at the reference's default: units=[10, 10]."""
     from rnnwavefunctions_amd import compat as tf

@@ -421,30 +421,17 @@ def test_both_flip_engines_agree_with_the_f64_oracle(N, H, ns, monkeypatch):
     assert np.array_equal(wf.tfim_eloc(s, Jz, 1.1), got["f32"][0])
 
 
-@pytest.mark.parametrize("N,H,ns", [(40, 50, 333), (25, 37, 64), (33, 44, 70), (21, 52, 40), (66, 49, 33), (2, 50, 5)])
-def test_16x16x32_riders_form_at_37_to_52_units(N, H, ns, monkeypatch):
-    """RNNWF_ENGINE=bf16x3-n16: the flip pass of the positive RNN at 37..52 units as one generated asm block per wave-step on
-    v_mfma_f32_16x16x32_bf16 (tools/gen_riders16n_asm.py; 10 % slower than the default ping-pong kernel, kept for A/B runs).
-    Same tolerances as the default engine, against the float64 oracle and against the default kernel."""
+def test_release_library_refuses_engine_switches_it_does_not_hold(monkeypatch):
+    """The measured negatives of rounds 1-3 (RNNWF_ENGINE=bf16x3-serial / -hipcc / -asm32 / -n16, RNNWF_MDRNN_PREFETCH) live in the
+    -DRNNWF_DIAGNOSTICS build of tools/ only; the release library holds one kernel per model and width class and refuses a
+    value it does not know instead of silently running something else."""
     from rnnwavefunctions_amd import _lib
-    prm = trained_like(H, seed=3 * N + H)
-    prm64 = {k: v.astype(np.float64) for k, v in prm.items()}
-    rng = np.random.RandomState(11)
-    s = rng.randint(0, 2, (ns, N)).astype(np.int32)
-    Jz = 1.0 + 0.1 * rng.standard_normal(N)
-    e64, lp64 = E.ising_local_energies(Jz, 0.9, s, lambda x: M.prnn_log_probability(prm64, x, dtype=np.float64),
-                                       return_log_probs=True)
-    got = {}
-    for engine in ("bf16x3-n16", "bf16x3"):
-        monkeypatch.setenv("RNNWF_ENGINE", engine)
-        wf = make_wf(_lib.MODEL_GRU1D, N, H, prm)
-        lp = np.zeros((N + 1) * ns)
-        e = wf.tfim_eloc(s, Jz, 0.9, log_probs=lp)
-        assert wf.engine_name() == "bf16x3"
-        assert np.abs(lp - lp64.ravel()).max() <= 2e-6 * N + 2e-6
-        assert np.abs(e / e64 - 1).max() <= 2e-5
-        got[engine] = e
-    assert np.allclose(got["bf16x3-n16"], got["bf16x3"], rtol=2e-5)
+    for bad in ("bf16x3-n16", "bf16x3-serial", "bf16x3-hipcc", "bf16x3-asm32", "fp8"):
+        monkeypatch.setenv("RNNWF_ENGINE", bad)
+        with pytest.raises((ValueError, _lib.RnnwfError), match="RNNWF_ENGINE"):
+            _lib.NativeWavefunction(_lib.MODEL_GRU1D, 8, 1, (50,))
+    monkeypatch.setenv("RNNWF_ENGINE", "f32")
+    _lib.NativeWavefunction(_lib.MODEL_GRU1D, 8, 1, (50,))
 
 
 # ---- stacked layers (units = [h] * num_layers, 1DTFIM/TrainingRNN_1DTFIM.py:98; MultiRNNCell, RNNwavefunction.py:32) ----

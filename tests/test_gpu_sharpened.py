@@ -6,12 +6,13 @@ exp(1/2 [log P(flipped) - log P]) is ~1.  Here the kernels are scaled by 3 and e
 bf16x3 arithmetic of the long chains is stressed at the sizes BASELINE.json names.  The oracle scores the very sample
 matrix the HIP path drew.
 
-Tolerance: the absolute per-site bound of the glorot tests (1e-5 f32 models, 1e-10 f64) cannot be the criterion alone here -
-a local energy of sharpened weights is a sum of N ratios, single ones reaching 1e3..1e5, and an f32 log-probability difference of
-2e-6 N moves such a ratio by a RELATIVE 1e-4.  The bound is therefore stated per sample as
-    |E_loc - E_oracle| <= tol_abs * N + tol_rel * sum_i ratio_i,     sum_i ratio_i = (diag - E_loc) / Bx  (TFIM),
-with tol_abs the glorot tests' per-site bound and tol_rel = 3e-6 * N (f32; the log-probability tolerance of test_gpu_prnn.py)
-or 1e-10 (f64), and the batch mean <E>/N is held to north_star's 1e-4 (f32) outright.
+Tolerances: those of the glorot full-size tests, unchanged - max |E_loc - E_oracle| / N < 1e-5 (configs 2, 3), 1e-10 (config 4,
+float64) per sample, and the batch mean inside them (measured on MI355X: 3.2e-6, 2.3e-6, 4e-16).  Config 5 (N = 200, 100 units) is
+the one exception, stated where it is made: 200 recurrent f32 steps through x3 kernels amplify rounding differences between ANY
+two f32 evaluations to ~1e-4 per site on single samples (measured 1.4e-4 HIP vs the C oracle), so its per-sample bound carries a
+term relative to the sum of ratios, 3e-6 N (the log-probability tolerance of test_gpu_prnn.py), and the test shows on a subset
+scored in float64 that the HIP path is as close to float64 as the f32 C restatement of the reference formulation is.  The batch
+mean <E>/N stays inside north_star's 1e-4 outright (measured 2e-6).
 """
 import numpy as np
 import pytest
@@ -45,7 +46,8 @@ def check_tfim(name, e, e_ref, diag, Bx, N, tol_abs, tol_rel, tol_mean):
     assert np.all(np.isfinite(e))
     assert np.all(d <= bound), "sample %d: |dE| %.3e > bound %.3e" % (worst, d[worst], bound[worst])
     assert d_mean < tol_mean
-    assert ratios.max() > 3 * max(np.median(ratios), 1e-300)      # the weights ARE sharp: the ratio sums spread out (glorot: within 20 %)
+    assert ratios.std() > 0.2 * ratios.mean()      # the weights ARE sharp: the ratio sums spread out (glorot: every ratio ~1, sums within a few %)
+    return d
 
 
 def test_config2_sharpened_all_samples():
@@ -61,7 +63,7 @@ def test_config2_sharpened_all_samples():
     assert wf.engine_name() == "bf16x3"
     s, e = out["samples"], out["eloc"]
     e_ref = cport.ising_local_energies(prm, Jz, 1.0, s)
-    check_tfim("cfg2", e, e_ref, tfim_diag_1d(s, Jz), 1.0, N, 1e-5, 3e-6 * N, 1e-4)
+    check_tfim("cfg2", e, e_ref, tfim_diag_1d(s, Jz), 1.0, N, 1e-5, 0.0, 1e-5)
     m = out["moments"]
     assert abs(m[0] / m[2] - e.mean()) <= 1e-12 * abs(e.mean()) + 1e-9
 
@@ -81,6 +83,14 @@ def test_config5_shard_sharpened():
     sub = np.arange(0, ns, ns // 256)[:256]
     e_ref = cport.ising_local_energies(prm, Jz, 1.0, s[sub])
     check_tfim("cfg5 shard", e[sub], e_ref, tfim_diag_1d(s[sub], Jz), 1.0, N, 2e-5, 3e-6 * N, 1e-4)
+    # 24 of them in float64 (NumPy oracle): the HIP path is as close to float64 as the f32 C restatement is
+    few = sub[::11][:24]
+    prm64 = {k: v.astype(np.float64) for k, v in prm.items()}
+    e64 = E.ising_local_energies(Jz, 1.0, s[few], lambda x: M.prnn_log_probability(prm64, x, dtype=np.float64))
+    idx = np.searchsorted(sub, few)
+    err_hip, err_c = np.abs(e[few] - e64).max() / N, np.abs(e_ref[idx] - e64).max() / N
+    print("cfg5 shard sharpened, 24 samples vs float64: HIP %.2e per site, f32 C oracle %.2e per site" % (err_hip, err_c))
+    assert err_hip <= 2.0 * err_c + 2e-5
 
 
 def test_config3_sharpened():
@@ -101,6 +111,7 @@ def test_config3_sharpened():
                             for k in range(0, 2048, 256)])
     # magnitude of the off-diagonal sum per sample, from the oracle in float64 arithmetic on the same configurations
     mag = np.zeros(len(sub))
+    rmax = 0.0
     for k0 in range(0, len(sub), 256):
         blk = s[sub[k0:k0 + 256]]
         sig = np.zeros((2 * N * len(blk), N), np.int32)
@@ -112,15 +123,17 @@ def test_config3_sharpened():
         la = M.crnn_log_amplitude(prm, sig[:total]).astype(np.complex128)
         for j, sl in enumerate(slices):
             mag[k0 + j] = np.sum(np.abs(Hm[sl]) * np.abs(np.exp(la[sl] - la[sl][0])))
+            rmax = max(rmax, float(np.abs(np.exp(la[sl] - la[sl][0])).max()))
     d = np.abs(e[sub].astype(np.complex128) - e_ref.astype(np.complex128))
-    bound = 1e-5 * N + 3e-6 * N * mag
+    bound = 1e-5 * N + 0.0 * mag                      # the glorot test's per-site bound, unchanged
     worst = int(np.argmax(d / bound))
     d_mean = abs(e[sub].astype(np.complex128).mean() - e_ref.astype(np.complex128).mean()) / N
     print("cfg3 sharpened: 2048 samples, sum |H||ratio| %.3g .. %.3g (median %.3g); max |dE|/N = %.2e; worst |dE|/bound = %.3f; "
           "|d<E>|/N = %.2e" % (mag.min(), mag.max(), np.median(mag), d.max() / N, (d / bound)[worst], d_mean))
     assert np.all(np.isfinite(e.real)) and np.all(np.isfinite(e.imag))
     assert np.all(d <= bound), "sample %d: |dE| %.3e > bound %.3e" % (worst, d[worst], bound[worst])
-    assert d_mean < 1e-4
+    print("cfg3 sharpened: largest amplitude ratio %.3g" % rmax)
+    assert d_mean < 1e-5 and rmax > 3.0                  # the weights ARE sharp (glorot: every ratio within ~20 % of 1)
 
 
 def test_config4_sharpened():
@@ -139,4 +152,4 @@ def test_config4_sharpened():
                             for k in range(0, 256, 64)])
     sz = 2.0 * s[sub] - 1.0
     diag = -((sz[:, :-1, :] * sz[:, 1:, :]).sum(axis=(1, 2)) + (sz[:, :, :-1] * sz[:, :, 1:]).sum(axis=(1, 2)))
-    check_tfim("cfg4", e[sub], e_ref, diag, 3.0, N, 1e-10, 1e-10, 1e-9)
+    check_tfim("cfg4", e[sub], e_ref, diag, 3.0, N, 1e-10, 0.0, 1e-10)
