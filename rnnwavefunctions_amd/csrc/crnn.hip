@@ -71,10 +71,13 @@ struct CMLaunch {
         const void* fn = (const void*)crnn_ml_base_kernel<NFULL, NL, WAVES>;
         int bpc = 0;
         if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, M::BYTES, &bpc)) return rc;
-        const int64_t need = (a.nsb + WAVES - 1) / WAVES;
-        const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
+        // as few waves per workgroup as still cover the batch with every resident workgroup busy (prnn.hip: MLaunchL::base)
+        const int64_t slots = (int64_t)bpc * h->cu_count;
+        const int wpb = (int)std::max<int64_t>(1, std::min<int64_t>(WAVES, (a.nsb + slots - 1) / slots));
+        const int64_t need = (a.nsb + wpb - 1) / wpb;
+        const unsigned grid = (unsigned)std::min<int64_t>(need, slots);
         TimedLaunch tl(h, 0);
-        crnn_ml_base_kernel<NFULL, NL, WAVES><<<grid, WAVES * 64, M::BYTES, h->stream>>>(a);
+        crnn_ml_base_kernel<NFULL, NL, WAVES><<<grid, wpb * 64, M::BYTES, h->stream>>>(a);
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }

@@ -311,20 +311,22 @@ __global__ void __launch_bounds__(512) crnn_swap_pp_upper_kernel(CrnnArgs a, con
     typedef __attribute__((address_space(3))) void* LdsVoid;
     typedef const __attribute__((address_space(1))) void* GlobVoid;
     auto dma_record = [&](int64_t r) {
-        const float* src = st.xin + r * (int64_t)REC + lane * 4;
+        const float* base = st.xin + r * (int64_t)REC;
 #pragma unroll
-        for (int g = 0; g < NG; ++g) __builtin_amdgcn_global_load_lds((GlobVoid)(src + g * 256), (LdsVoid)(slot + g * 1024), 16, 0, 0);
+        for (int g = 0; g < NG; ++g) __builtin_amdgcn_global_load_lds((GlobVoid)(base + g * 256 + lane * 4), (LdsVoid)(slot + g * 1024), 16, 0, RNNWF_RECORD_AUX);
+#pragma unroll
+        for (int t = 0; t < U::NTAIL; ++t)
+            __builtin_amdgcn_global_load_lds((GlobVoid)(base + NG * 256 + t * 64 + lane), (LdsVoid)(slot + NG * 1024 + t * 256), 4, 0, 0);
     };
     auto read_record = [&](float (&x)[NU]) {
         const float4* p = reinterpret_cast<const float4*>(slot) + lane;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const float4 v = p[g * 64];
-            x[4 * g] = v.x;
-            if (4 * g + 1 < NU) x[4 * g + 1] = v.y;
-            if (4 * g + 2 < NU) x[4 * g + 2] = v.z;
-            if (4 * g + 3 < NU) x[4 * g + 3] = v.w;
+            x[4 * g] = v.x; x[4 * g + 1] = v.y; x[4 * g + 2] = v.z; x[4 * g + 3] = v.w;
         }
+#pragma unroll
+        for (int t = 0; t < U::NTAIL; ++t) x[4 * NG + t] = reinterpret_cast<const float*>(slot + NG * 1024)[t * 64 + lane];
     };
     auto wait_vm = [&]() { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); };
     auto wait_lds = [&]() { __builtin_amdgcn_s_waitcnt(0xC07F); asm volatile("" ::: "memory"); };
@@ -370,7 +372,7 @@ __global__ void __launch_bounds__(512) crnn_swap_pp_upper_kernel(CrnnArgs a, con
         PU::split(h, BH);
         // behind the record's transfer only this segment's NG record stores may still be on their way (a fresh tile: wait for all)
         if (LAST || fresh) __builtin_amdgcn_s_waitcnt(0x0F70);
-        else __builtin_amdgcn_s_waitcnt(0x0F70 | NG);
+        else __builtin_amdgcn_s_waitcnt(0x0F70 | (NG + U::NTAIL));
         asm volatile("" ::: "memory");
         read_record(h);
         PU::split(h, BX);

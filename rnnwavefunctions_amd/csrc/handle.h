@@ -62,6 +62,8 @@ struct rnnwf_handle {
     std::string err;
     hipStream_t stream = nullptr;
     std::map<std::string, rnnwf::ParamSpec> params;
+    std::map<std::string, std::vector<int32_t>> param_flat;   // per tensor: padded index -> index in the flat parameter vector
+                                                              // (order of rnnwf_set_params_flat), -1 for padding (pack_value.h)
     bool committed = false;
 
     // device buffers (grown on demand, owned by the handle)

@@ -48,8 +48,11 @@ __global__ void __launch_bounds__(WAVES * 64) prnn_ml_base_kernel(PrnnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     M::stage(lds, a.wimg);
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
-    const int64_t gw = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
-    const int64_t nw = (int64_t)gridDim.x * WAVES;
+    // (launched with WAVES waves or fewer: a batch of fewer 16-chain blocks than the chip has SIMDs spreads over all CUs, one wave
+    //  per SIMD, instead of filling a third of them with eight - the pass is N dependent steps of MFMA latency per wave)
+    const int64_t wpb = blockDim.x >> 6;
+    const int64_t gw = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * wpb;
     const int N = a.N;
     for (int64_t sb = gw; sb < a.nsb; sb += nw) {
         const int64_t s = sb * kChains + c;

@@ -7,6 +7,7 @@
 
 #include "handle.h"
 #include "layout.h"
+#include "pack_value.h"
 
 namespace rnnwf {
 
@@ -14,6 +15,14 @@ static const char* kGruPre = "multi_rnn_cell/cell_0/cudnn_compatible_gru_cell/";
 
 inline const std::vector<double>& pv(const rnnwf_handle* h, const std::string& name) {
     return h->params.at(name).value;
+}
+// the same tensor for a packer written over the scalar type S (pack_value.h): values, or values with their provenance
+template <class S> inline ParamView<S> pvs(const rnnwf_handle* h, const std::string& name);
+template <> inline ParamView<double> pvs<double>(const rnnwf_handle* h, const std::string& name) {
+    return ParamView<double>{&h->params.at(name).value};
+}
+template <> inline ParamView<Lin> pvs<Lin>(const rnnwf_handle* h, const std::string& name) {
+    return ParamView<Lin>{&h->params.at(name).value, &h->param_flat.at(name)};
 }
 
 // Row scales that let the f32 kernels feed the accumulator straight into v_exp_f32 (see gru_core.h, Act<T>).
@@ -28,18 +37,20 @@ template <> struct PackScale<double> {
 // Packs the single-layer cuDNN-compatible GRU + Dense head(s).
 // NOUT = 1: positive RNN (head row = softmax logit difference z1 - z0);
 // NOUT = 3: complex RNN (amplitude logit difference, phase logit 0, phase logit 1).
-template <typename T, int NFULL, int NOUT>
+template <typename T, int NFULL, int NOUT, class S = double>
 std::vector<char> pack_gru_image(const rnnwf_handle* h) {
     using L = GruLayout<T, NFULL, NOUT>;
+    using Out = PackSink<S>;
     const int H = h->H;
     std::vector<char> img(L::BYTES, 0);
+    Out::begin(img);
     const std::string pre = kGruPre;
-    const auto& Wg = pv(h, pre + "gates/kernel");                         // [2+H, 2H], cols r | u
-    const auto& bg = pv(h, pre + "gates/bias");                           // [2H]
-    const auto& Wci = pv(h, pre + "candidate/input_projection/kernel");   // [2, H]
-    const auto& bci = pv(h, pre + "candidate/input_projection/bias");     // [H]
-    const auto& Wch = pv(h, pre + "candidate/hidden_projection/kernel");  // [H, H]
-    const auto& bch = pv(h, pre + "candidate/hidden_projection/bias");    // [H]
+    const auto Wg = pvs<S>(h, pre + "gates/kernel");                         // [2+H, 2H], cols r | u
+    const auto bg = pvs<S>(h, pre + "gates/bias");                           // [2H]
+    const auto Wci = pvs<S>(h, pre + "candidate/input_projection/kernel");   // [2, H]
+    const auto bci = pvs<S>(h, pre + "candidate/input_projection/bias");     // [H]
+    const auto Wch = pvs<S>(h, pre + "candidate/hidden_projection/kernel");  // [H, H]
+    const auto bch = pvs<S>(h, pre + "candidate/hidden_projection/bias");    // [H]
 
     auto decode = [&](int tile, int q, int r, int& gate, int& unit) -> bool {
         if (tile < 3 * NFULL) {
@@ -53,8 +64,8 @@ std::vector<char> pack_gru_image(const rnnwf_handle* h) {
         return unit < H;
     };
     const double sg = PackScale<T>::gate, sc = PackScale<T>::cand;
-    auto wt = [&](int gate, int unit, int k) -> double {  // (scaled) W^T[row(gate,unit)][k]
-        if (k >= H) return 0.0;
+    auto wt = [&](int gate, int unit, int k) -> S {  // (scaled) W^T[row(gate,unit)][k]
+        if (k >= H) return S(0.0);
         if (gate == 0) return sg * Wg[(size_t)(2 + k) * 2 * H + unit];
         if (gate == 1) return sg * Wg[(size_t)(2 + k) * 2 * H + H + unit];
         return sc * Wch[(size_t)k * H + unit];
@@ -70,9 +81,8 @@ std::vector<char> pack_gru_image(const rnnwf_handle* h) {
                 const int lane = (kq << 4) | row;
                 for (int g = 0; g < L::NG; ++g)
                     for (int j = 0; j < L::VW; ++j)
-                        avec[(((size_t)tile * L::NG + g) * 64 + lane) * L::VW + j] =
-                            (T)wt(gate, unit, 4 * (g * L::VW + j) + kq);
-                arem[(size_t)tile * 64 + lane] = (T)wt(gate, unit, 4 * (L::KT - 1) + kq);
+                        Out::put(&avec[(((size_t)tile * L::NG + g) * 64 + lane) * L::VW + j], wt(gate, unit, 4 * (g * L::VW + j) + kq));
+                Out::put(&arem[(size_t)tile * 64 + lane], wt(gate, unit, 4 * (L::KT - 1) + kq));
             }
         }
     for (int v = 0; v < 3; ++v) {  // v = 0: zero input; v = 1, 2: one-hot of spin 0, 1
@@ -83,11 +93,11 @@ std::vector<char> pack_gru_image(const rnnwf_handle* h) {
                 for (int r = 0; r < 4; ++r) {
                     int gate, unit;
                     if (!decode(tile, q, r, gate, unit)) continue;
-                    double b;
-                    if (gate == 0) b = sg * (bg[unit] + (v ? Wg[(size_t)(v - 1) * 2 * H + unit] : 0.0));
-                    else if (gate == 1) b = sg * (bg[H + unit] + (v ? Wg[(size_t)(v - 1) * 2 * H + H + unit] : 0.0));
+                    S b;
+                    if (gate == 0) b = sg * (bg[unit] + (v ? Wg[(size_t)(v - 1) * 2 * H + unit] : S(0.0)));
+                    else if (gate == 1) b = sg * (bg[H + unit] + (v ? Wg[(size_t)(v - 1) * 2 * H + H + unit] : S(0.0)));
                     else b = sc * bch[unit];
-                    binit[tile * 16 + q * 4 + r] = (T)b;
+                    Out::put(&binit[tile * 16 + q * 4 + r], b);
                 }
         for (int m = 0; m <= NFULL; ++m)
             for (int q = 0; q < 4; ++q)
@@ -95,29 +105,29 @@ std::vector<char> pack_gru_image(const rnnwf_handle* h) {
                     if (m == NFULL && r != 0) continue;
                     const int unit = m < NFULL ? 16 * m + 4 * r + q : 16 * NFULL + q;
                     if (unit >= H) continue;
-                    xc[m * 16 + q * 4 + r] = (T)(sc * (bci[unit] + (v ? Wci[(size_t)(v - 1) * H + unit] : 0.0)));
+                    Out::put(&xc[m * 16 + q * 4 + r], sc * (bci[unit] + (v ? Wci[(size_t)(v - 1) * H + unit] : S(0.0))));
                 }
     }
     T* wd = reinterpret_cast<T*>(img.data() + L::OFF_WD);
     T* bd = reinterpret_cast<T*>(img.data() + L::OFF_BD);
-    const auto& Wd = pv(h, std::string(NOUT == 1 ? "wf_dense" : "wf_dense_ampl") + "/kernel");   // [H, 2]
-    const auto& bdv = pv(h, std::string(NOUT == 1 ? "wf_dense" : "wf_dense_ampl") + "/bias");    // [2]
+    const auto Wd = pvs<S>(h, std::string(NOUT == 1 ? "wf_dense" : "wf_dense_ampl") + "/kernel");   // [H, 2]
+    const auto bdv = pvs<S>(h, std::string(NOUT == 1 ? "wf_dense" : "wf_dense_ampl") + "/bias");    // [2]
     for (int kt = 0; kt < L::KT; ++kt)
         for (int q = 0; q < 4; ++q) {
             const int unit = 4 * kt + q;
             if (unit >= H) continue;
-            wd[q * L::WD_Q + kt * NOUT] = (T)(Wd[(size_t)unit * 2 + 1] - Wd[(size_t)unit * 2]);
+            Out::put(&wd[q * L::WD_Q + kt * NOUT], Wd[(size_t)unit * 2 + 1] - Wd[(size_t)unit * 2]);
             if (NOUT == 3) {
-                const auto& Wp = pv(h, "wf_dense_phase/kernel");
-                wd[q * L::WD_Q + kt * NOUT + 1] = (T)Wp[(size_t)unit * 2];
-                wd[q * L::WD_Q + kt * NOUT + 2] = (T)Wp[(size_t)unit * 2 + 1];
+                const auto Wp = pvs<S>(h, "wf_dense_phase/kernel");
+                Out::put(&wd[q * L::WD_Q + kt * NOUT + 1], Wp[(size_t)unit * 2]);
+                Out::put(&wd[q * L::WD_Q + kt * NOUT + 2], Wp[(size_t)unit * 2 + 1]);
             }
         }
-    bd[0] = (T)(bdv[1] - bdv[0]);
+    Out::put(&bd[0], bdv[1] - bdv[0]);
     if (NOUT == 3) {
-        const auto& bp = pv(h, "wf_dense_phase/bias");
-        bd[1] = (T)bp[0];
-        bd[2] = (T)bp[1];
+        const auto bp = pvs<S>(h, "wf_dense_phase/bias");
+        Out::put(&bd[1], bp[0]);
+        Out::put(&bd[2], bp[1]);
     }
     return img;
 }

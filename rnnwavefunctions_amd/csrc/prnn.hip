@@ -75,10 +75,14 @@ struct MLaunchL {
         const void* fn = (const void*)prnn_ml_base_kernel<T, NFULL, NL, WAVES>;
         int bpc = 0;
         if (int rc = blocks_per_cu(h, fn, &bpc)) return rc;
-        const int64_t need = (a.nsb + WAVES - 1) / WAVES;
-        const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
+        // waves per workgroup: as few as still cover the batch with every resident workgroup busy (config 2 with two layers: 625
+        // blocks of 16 chains -> 3 waves on each of 209 CUs instead of 8 on 79; measured 1.26 -> see DESIGN.md)
+        const int64_t slots = (int64_t)bpc * h->cu_count;
+        const int wpb = (int)std::max<int64_t>(1, std::min<int64_t>(WAVES, (a.nsb + slots - 1) / slots));
+        const int64_t need = (a.nsb + wpb - 1) / wpb;
+        const unsigned grid = (unsigned)std::min<int64_t>(need, slots);
         TimedLaunch tl(h, 0);
-        prnn_ml_base_kernel<T, NFULL, NL, WAVES><<<grid, WAVES * 64, M::BYTES, h->stream>>>(a);
+        prnn_ml_base_kernel<T, NFULL, NL, WAVES><<<grid, wpb * 64, M::BYTES, h->stream>>>(a);
         RNNWF_HIP(h, hipGetLastError());
         return 0;
     }

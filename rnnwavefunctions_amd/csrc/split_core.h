@@ -131,9 +131,10 @@ struct SplitUpperLayout {
     // accumulator tile of block tile t
     static constexpr int acc_of(bool xblock, int t) { return t < 2 ? t : t == 2 ? (xblock ? 2 : 3) : t == 3 ? 4 : (xblock ? 5 : 6); }
     // one wave-step's state record: [NG groups of 4 entries][64 lanes][4] f32 - a lane's entries 4 g .. 4 g + 3 are 16 contiguous bytes,
-    // a group 1 KB: written with dwordx4 stores, read by LDS-DMA into a lane-linear staging slot (split_kernels.h)
-    static constexpr int NG = (NU + 3) / 4;
-    static constexpr int RECORD_FLOATS = NG * 64 * 4;
+    // a group 1 KB - then the NU % 4 last entries as [entry][64 lanes] f32: written with dwordx4 (dword) stores, read by LDS-DMA into a
+    // lane-linear staging slot (split_kernels.h).  NU floats per lane, nothing padded: the records are the pipeline's HBM traffic.
+    static constexpr int NG = NU / 4, NTAIL = NU % 4;
+    static constexpr int RECORD_FLOATS = NU * 64;
     static constexpr size_t SLOT_BYTES = (size_t)RECORD_FLOATS * 4;       // per-wave LDS staging slot (also holds a checkpoint: [NU][64] f32)
     static constexpr size_t LDS_BYTES = ((BYTES + 15) / 16) * 16 + 8 * SLOT_BYTES;
     static_assert(LDS_BYTES + 64 <= 160 * 1024, "image + eight staging slots must fit LDS");

@@ -345,6 +345,14 @@ def test_bench_launcher_flow_with_two_ranks():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--no-cpu-baseline", "--no-alt-engine", "--numsamples", "2000"] + ([] if two else ["--same-device"])
+    if not two:
+        # a scaling run that silently measured gloo is worse than none: without --allow-fallback the job exits 3 (every rank),
+        # the line - with the reason - is still printed
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
+        assert r.returncode != 0 and "RCCL communicator could not be created" in r.stderr, r.stderr[-2000:]
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert d["exit_code"] == 3 and "gloo" in d["transport_fallback"] and d["rccl_nranks"] is None
+        cmd.append("--allow-fallback")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
