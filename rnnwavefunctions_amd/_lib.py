@@ -61,6 +61,11 @@ PROTOTYPES = {
     "rnnwf_comm_info": (C.c_int, [_P, _P, _P, _P]),
     "rnnwf_comm_reduce_in_step": (C.c_int, [_P, _I32]),
     "rnnwf_comm_destroy": (C.c_int, [_P]),
+    "rnnwf_device_training_supported": (C.c_int, [_P]),
+    "rnnwf_adam_step": (C.c_int, [_P, _F64, _F64, _F64, _F64]),
+    "rnnwf_train_steps": (C.c_int, [_P, _I32, _I64, C.c_uint64, C.c_uint64, _I64, _F64P, _I64, _F64P, _F64, _F64, _F64, _F64P]),
+    "rnnwf_adam_get_state": (C.c_int, [_P, _F64P, _F64P, _I64, C.POINTER(_I64)]),
+    "rnnwf_adam_set_state": (C.c_int, [_P, _F64P, _F64P, _I64, _I64]),
     "rnnwf_timing_enable": (C.c_int, [_P, _I32]),
     "rnnwf_timing_reset": (C.c_int, [_P]),
     "rnnwf_timing_get": (C.c_int, [_P, _I32, _F64P, C.POINTER(_I64), _F64P]),
@@ -323,6 +328,48 @@ class NativeWavefunction:
             g = np.empty(shape, dtype=np.float64)
             self._check(self.lib.rnnwf_get_grad(self.h, name.encode(), g.ctypes.data_as(_P), g.size, F64))
             out[name] = g
+        return out
+
+    # -- device-resident training iteration (rnnwf_train_steps; single-layer float32 GRU models) ------------------
+    def device_training_supported(self):
+        return bool(self.lib.rnnwf_device_training_supported(self.h))
+
+    def train_steps(self, numsamples, seed, step0, couplings, learning_rates, beta1=0.9, beta2=0.999, epsilon=1e-8, sample_offset=0):
+        """len(learning_rates) whole iterations (sample, local energies, gradient, Adam update, re-pack of the weight images) on
+        the device with one host synchronisation; returns the (K, 4) moments of the K batches."""
+        c, cp = _f64(couplings)
+        lr, lrp = _f64(np.atleast_1d(learning_rates))
+        mom = np.empty((lr.size, 4), dtype=np.float64)
+        self._check(self.lib.rnnwf_train_steps(self.h, lr.size, numsamples, seed, step0, sample_offset, cp, c.size, lrp,
+                                               float(beta1), float(beta2), float(epsilon), mom.ctypes.data_as(_F64P)))
+        return mom
+
+    def adam_step(self, learning_rate, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        """One Adam update on the device from the gradient of the last vmc_gradient, then the images' re-pack."""
+        self._check(self.lib.rnnwf_adam_step(self.h, float(learning_rate), float(beta1), float(beta2), float(epsilon)))
+
+    def adam_get_state(self):
+        """(m_flat, v_flat, t): Adam's moments in the flat order of _layout() and the number of updates applied."""
+        n = self.num_params()
+        m, v, t = np.empty(n), np.empty(n), _I64(0)
+        self._check(self.lib.rnnwf_adam_get_state(self.h, m.ctypes.data_as(_F64P), v.ctypes.data_as(_F64P), n, C.byref(t)))
+        return m, v, int(t.value)
+
+    def adam_set_state(self, m_flat, v_flat, t):
+        if m_flat is None:
+            self._check(self.lib.rnnwf_adam_set_state(self.h, None, None, self.num_params(), int(t)))
+            return
+        m, mp = _f64(m_flat)
+        v, vp = _f64(v_flat)
+        self._check(self.lib.rnnwf_adam_set_state(self.h, mp, vp, m.size, int(t)))
+
+    def get_params_dict(self, like, scope=None):
+        """{name: array} with the names, shapes and dtypes of `like`, read back from the library (after device-resident updates)."""
+        pre = scope + "/" if scope else ""
+        out = type(like)()
+        for k, v in like.items():
+            nm = k[len(pre):] if pre and k.startswith(pre) else k
+            out[k] = self.get_param(nm, v.shape, v.dtype)
         return out
 
     # -- multi-GPU --------------------------------------------------------------------------------

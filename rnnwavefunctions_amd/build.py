@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "librnnwf_hip.so")
-SOURCES = ["rnnwf_api.hip", "prnn.hip", "crnn.hip", "split.hip", "split_stream.hip", "mdrnn.hip", "grad.hip", "comm.hip"]
+SOURCES = ["rnnwf_api.hip", "prnn.hip", "crnn.hip", "split.hip", "split_stream.hip", "mdrnn.hip", "grad.hip", "comm.hip", "train.hip"]
 # no SLP packing of adjacent f32 adds / fmas into v_pk_*_f32 in the bf16x3 engine's translation unit: packed-f32 (and v_dot2)
 # instructions stall behind bf16 MFMAs - their own wave's AND the SIMD partner's (measured: tools/microbench/issue_model,
 # a VALU segment with packed ops beside an MFMA partner 5 170 vs 3 337 cycles).  The f32-input-MFMA kernels keep it.

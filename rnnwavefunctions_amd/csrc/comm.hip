@@ -153,6 +153,12 @@ extern "C" int rnnwf_allreduce_grads(rnnwf_handle* h) {
         if (h->nranks == 1) return RNNWF_OK;
         return h->fail(RNNWF_ERR_STATE, "rnnwf_allreduce_grads: communicator not initialised");
     }
+    RNNWF_HIP(h, hipSetDevice(h->cfg.device));
+    {   // single-layer f32 GRU models: the gradient is flattened and summed on the device, in-stream (train.hip)
+        const int done = rnnwf::train_allreduce_grads_device(h);
+        if (done < 0) return done;
+        if (done == 1) return RNNWF_OK;
+    }
     size_t total = 0;
     for (auto& kv : h->grads) total += kv.second.size();      // std::map: same order on every rank
     if (int rc = rnnwf::ensure_staging(h, total * sizeof(double))) return rc;

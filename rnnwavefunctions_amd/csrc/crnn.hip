@@ -388,7 +388,7 @@ int rnnwf::crnn_vmc_step(rnnwf_handle* h, int64_t ns, uint64_t seed, uint64_t st
     if (out_eloc) RNNWF_HIP(h, hipMemcpyAsync(out_eloc, h->eloc.p, (size_t)ns * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
     h->last_ns = ns;                  // bits, hck and eloc stay resident for rnnwf_vmc_gradient
     h->last_has_ckpt = true;
-    if (int rc = run_moments(h, h->eloc.p, ns, true, moments)) return rc;   // syncs the stream
-    collect_totals(h, ns);
+    if (int rc = run_moments(h, h->eloc.p, ns, true, moments)) return rc;   // syncs the stream (moments == nullptr, device-resident training: it does not)
+    if (moments) collect_totals(h, ns);
     return RNNWF_OK;
 }

@@ -19,12 +19,15 @@ struct GLaunch {
     static constexpr bool STREAM = GradStream<T, NFULL, NOUT>::value;       // backward operand read through L2 (grad_kernels.h)
     static constexpr size_t LDS = L::LDS_BYTES + (STREAM ? 0 : G::BWD_BYTES);
 
+    template <class S = double>
     static std::vector<char> pack_bwd(const rnnwf_handle* h) {
+        using Out = PackSink<S>;
         const int H = h->H;
         std::vector<char> img(G::BWD_BYTES, 0);
+        Out::begin(img);
         const std::string pre = kGruPre;
-        const auto& Wg = pv(h, pre + "gates/kernel");                         // [2+H, 2H]
-        const auto& Wch = pv(h, pre + "candidate/hidden_projection/kernel");  // [H, H]
+        const auto Wg = pvs<S>(h, pre + "gates/kernel");                         // [2+H, 2H]
+        const auto Wch = pvs<S>(h, pre + "candidate/hidden_projection/kernel");  // [H, H]
         T* A = reinterpret_cast<T*>(img.data());
         for (int t = 0; t < G::NTO; ++t)
             for (int row = 0; row < 16; ++row) {
@@ -38,11 +41,11 @@ struct GLaunch {
                     for (int kk = 0; kk < G::KB; ++kk) {
                         const int g = kk / G::KT, kt = kk % G::KT, u = 4 * kt + kq;  // pre-activation (gate g, unit u)
                         if (u >= H) continue;
-                        double w;
+                        S w;
                         if (g == 0) w = Wg[(size_t)(2 + kout) * 2 * H + u];
                         else if (g == 1) w = Wg[(size_t)(2 + kout) * 2 * H + H + u];
                         else w = Wch[(size_t)kout * H + u];
-                        A[(((size_t)t * G::KBG + kk / G::VW) * 64 + lane) * G::VW + (kk % G::VW)] = (T)w;
+                        Out::put(&A[(((size_t)t * G::KBG + kk / G::VW) * 64 + lane) * G::VW + (kk % G::VW)], w);
                     }
                 }
             }
@@ -227,7 +230,7 @@ struct MLGrad {
     }
 
     static std::vector<char> pack_all(const rnnwf_handle* h) {
-        std::vector<char> img = G0::pack_bwd(h);
+        std::vector<char> img = G0::template pack_bwd<double>(h);
         for (int l = 1; l < NL; ++l) {
             const std::vector<char> up = pack_upper_bwd(h, l);
             img.insert(img.end(), up.begin(), up.end());
@@ -452,7 +455,6 @@ extern "C" int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double me
     if (!h) return RNNWF_ERR_INVALID;
     if (!h->committed) return h->fail(RNNWF_ERR_STATE, "parameters not committed");
     if (h->model == RNNWF_MODEL_MDRNN2D) return mdrnn_vmc_gradient(h, mean_energy, norm);
-    const bool parity = h->model == RNNWF_MODEL_GRU1D_PARITY;
     if (h->NL != 1) {
         if (h->last_ns <= 0 || !h->last_has_ckpt)
             return h->fail(RNNWF_ERR_STATE, "rnnwf_vmc_gradient: call rnnwf_vmc_step first (its samples, states and E_loc are reused)");
@@ -461,12 +463,30 @@ extern "C" int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double me
         MLGRAD_DISPATCH(h, return K::run(h, mean_energy, mean_energy_im, norm));
         return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: no stacked-layer kernel for this width");
     }
+    size_t dw_floats = 0;
+    if (int rc = grad_single_layer_device(h, mean_energy, mean_energy_im, norm, nullptr, &dw_floats)) return rc;
+    const size_t es = h->model == RNNWF_MODEL_GRU1D_F64 ? 8 : 4;
+    int pcols = 0, qcols = 0;
+    GRAD_DISPATCH(h, { pcols = K::G::PCOLS; qcols = K::G::QCOLS; break; });
+    if (int rc = ensure_staging(h, dw_floats * es)) return rc;        // pinned: the copy is a plain DMA, the one wait is ours
+    RNNWF_HIP(h, hipMemcpyAsync(h->staging, h->gradW.p, dw_floats * es, hipMemcpyDeviceToHost, h->stream));
+    RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+    GRAD_DISPATCH(h, { K::unpack(h, h->staging, (size_t)pcols * qcols); break; });
+    return RNNWF_OK;
+}
+
+// The single-layer gradient's kernels on the batch of the last rnnwf_vmc_step: back-propagation through time + weight-gradient GEMM,
+// result (the dW image and the head rows) left in h->gradW.  mom_dev != nullptr (device-resident training, train.hip): mean energy
+// and norm come from the step's moments on the device (mean_energy / norm arguments unused) and nothing visits the host.
+int rnnwf::grad_single_layer_device(rnnwf_handle* h, double mean_energy, double mean_energy_im, double norm, const double* mom_dev,
+                                    size_t* dw_count) {
+    const bool parity = h->model == RNNWF_MODEL_GRU1D_PARITY;
     const bool cplx = h->model == RNNWF_MODEL_CRNN_U1;
     const bool f64 = h->model == RNNWF_MODEL_GRU1D_F64;
     const size_t es = f64 ? 8 : 4;
     if (h->last_ns <= 0 || !h->last_has_ckpt)
         return h->fail(RNNWF_ERR_STATE, "rnnwf_vmc_gradient: call rnnwf_vmc_step first (its samples, states and E_loc are reused)");
-    if (!(norm > 0)) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: norm must be positive");
+    if (!mom_dev && !(norm > 0)) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: norm must be positive");
     RNNWF_HIP(h, hipSetDevice(h->cfg.device));
     const int N = h->N;
     const int64_t ns = h->last_ns, R = ns * N;
@@ -474,7 +494,7 @@ extern "C" int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double me
     GRAD_DISPATCH(h, { pcols = K::G::PCOLS; qcols = K::G::QCOLS; hgn = K::G::HEAD_ROW * (cplx ? 3 : 1); break; });
     if (!h->wbwd_valid) {
         std::vector<char> img;
-        GRAD_DISPATCH(h, { img = K::pack_bwd(h); break; });
+        GRAD_DISPATCH(h, { img = K::template pack_bwd<double>(h); break; });
         if (int rc = ensure(h, h->wbwd, img.size())) return rc;
         if (int rc = upload(h, h->wbwd.p, img.data(), img.size())) return rc;
         h->wbwd_valid = true;
@@ -482,6 +502,7 @@ extern "C" int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double me
     if (int rc = ensure(h, h->gradP, (size_t)R * pcols * es)) return rc;
     if (int rc = ensure(h, h->gradQ, (size_t)R * qcols * es)) return rc;
     const size_t dw_floats = (size_t)pcols * qcols + hgn;
+    if (dw_count) *dw_count = dw_floats;
     if (int rc = ensure(h, h->gradW, dw_floats * es)) return rc;
     RNNWF_HIP(h, hipMemsetAsync(h->gradW.p, 0, dw_floats * es, h->stream));
     GradArgs a{};
@@ -496,7 +517,8 @@ extern "C" int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double me
     a.eloc_c = (const float2*)h->eloc.p;
     a.mean_e = mean_energy;
     a.mean_im = mean_energy_im;
-    a.inv_norm = (cplx ? 2.0 : 1.0) / norm;      // the complex cost carries a factor 2 (TrainingRNN_J1J2.py:197)
+    a.mom = mom_dev;
+    a.inv_norm = mom_dev ? (cplx ? 2.0 : 1.0) : (cplx ? 2.0 : 1.0) / norm;      // the complex cost carries a factor 2 (TrainingRNN_J1J2.py:197)
     a.P = h->gradP.p;
     a.Q = h->gradQ.p;
     a.head_grad = (char*)h->gradW.p + (size_t)pcols * qcols * es;
@@ -519,11 +541,47 @@ extern "C" int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double me
         a.wfac = lpF;
     }
     GRAD_DISPATCH(h, { if (int rc = K::run(h, a, R, h->gradW.p)) return rc; break; });
-    if (int rc = ensure_staging(h, dw_floats * es)) return rc;        // pinned: the copy is a plain DMA, the one wait is ours
-    RNNWF_HIP(h, hipMemcpyAsync(h->staging, h->gradW.p, dw_floats * es, hipMemcpyDeviceToHost, h->stream));
-    RNNWF_HIP(h, hipStreamSynchronize(h->stream));
-    GRAD_DISPATCH(h, { K::unpack(h, h->staging, (size_t)pcols * qcols); break; });
     return RNNWF_OK;
+}
+
+// ---- what train.hip needs from this translation unit (the layouts live in its anonymous namespace) -------------------------
+// table of the backward image (pack_value.h) into the active PackTrace
+int rnnwf::grad_bwd_pack_table(rnnwf_handle* h) {
+    GRAD_DISPATCH(h, { K::template pack_bwd<Lin>(h); return 0; });
+    return h->fail(RNNWF_ERR_INVALID, "no gradient kernel for NFULL=%d", h->NFULL);
+}
+// Where every entry of the flat gradient (order and shapes of rnnwf_get_grads_flat) sits in the dW image: the host unpacker run on an
+// image whose element k holds k + 1 - sidx[j] = +-(k + 1), 0: no source (stays 0).  is_f64: element type of the image.
+int rnnwf::grad_flat_probe(rnnwf_handle* h, std::vector<int32_t>& sidx, size_t* dw_count, bool* is_f64) {
+    const bool cplx = h->model == RNNWF_MODEL_CRNN_U1;
+    const bool f64 = h->model == RNNWF_MODEL_GRU1D_F64;
+    int pcols = 0, qcols = 0, hgn = 0;
+    GRAD_DISPATCH(h, { pcols = K::G::PCOLS; qcols = K::G::QCOLS; hgn = K::G::HEAD_ROW * (cplx ? 3 : 1); break; });
+    const size_t n = (size_t)pcols * qcols + hgn;
+    if (n == 0 || n >= ((size_t)1 << 24)) return h->fail(RNNWF_ERR_INVALID, "gradient image of %zu elements cannot be probed", n);
+    const auto saved = h->grads;
+    if (f64) {
+        std::vector<double> img(n);
+        for (size_t k = 0; k < n; ++k) img[k] = (double)(k + 1);
+        GRAD_DISPATCH(h, { K::unpack(h, img.data(), (size_t)pcols * qcols); break; });
+    } else {
+        std::vector<float> img(n);
+        for (size_t k = 0; k < n; ++k) img[k] = (float)(k + 1);
+        GRAD_DISPATCH(h, { K::unpack(h, img.data(), (size_t)pcols * qcols); break; });
+    }
+    sidx.clear();
+    for (auto& kv : h->params) {
+        auto it = h->grads.find(kv.first);
+        if (it == h->grads.end() || it->second.size() != kv.second.value.size()) {
+            h->grads = saved;
+            return h->fail(RNNWF_ERR_STATE, "grad_flat_probe: no gradient for '%s'", kv.first.c_str());
+        }
+        for (size_t i = 0; i < kv.second.slot.size(); ++i) sidx.push_back((int32_t)std::llround(it->second[(size_t)kv.second.slot[i]]));
+    }
+    h->grads = saved;
+    if (dw_count) *dw_count = n;
+    if (is_f64) *is_f64 = f64;
+    return 0;
 }
 
 extern "C" int rnnwf_get_grad(rnnwf_handle* h, const char* name, void* data, int64_t count, int32_t dtype) {

@@ -48,6 +48,9 @@ struct GradArgs {
     const double* eloc;        // [ns] f64 (positive RNN) ...
     const float2* eloc_c;      // ... or [ns] complex64 (complex RNN)
     double mean_e, mean_im, inv_norm;   // w_s = (E_s - mean) * inv_norm  (real and imaginary part separately)
+    const double* mom;         // device-resident training (train.hip): the step's moments {sum Re E, sum (Re E)^2, n, sum Im E} still on the
+                               // device - then mean_e = mom[0] / mom[2], mean_im = mom[3] / mom[2] and inv_norm (the cost's factor 1 or 2) is
+                               // divided by mom[2]: the divisions the host path does in Python, in the same arithmetic; nullptr: the three fields above
     const double* wfac;        // [ns] extra factor of w_s or nullptr (parity-symmetric model: the direction's share of P_sym)
     void* P;                   // [N*ns][PCOLS] T
     void* Q;                   // [N*ns][QCOLS] T
@@ -146,12 +149,14 @@ __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
         const int64_t sc = valid ? s : a.ns - 1;
         T w = T(0), w_im = T(0);
         if (valid) {
+            const double mean_e = a.mom ? a.mom[0] / a.mom[2] : a.mean_e, mean_im = a.mom ? a.mom[3] / a.mom[2] : a.mean_im;
+            const double inv_norm = a.mom ? a.inv_norm / a.mom[2] : a.inv_norm;
             if constexpr (NOUT == 1) {
-                w = (T)((a.eloc[sc] - a.mean_e) * a.inv_norm * (a.wfac ? a.wfac[sc] : 1.0));
+                w = (T)((a.eloc[sc] - mean_e) * inv_norm * (a.wfac ? a.wfac[sc] : 1.0));
             } else {
                 const float2 e = a.eloc_c[sc];
-                w = (T)(((double)e.x - a.mean_e) * a.inv_norm);
-                w_im = (T)(((double)e.y - a.mean_im) * a.inv_norm);
+                w = (T)(((double)e.x - mean_e) * inv_norm);
+                w_im = (T)(((double)e.y - mean_im) * inv_norm);
             }
         }
         auto word = [&](int wi) { return a.bits[(int64_t)wi * a.ns + sc]; };

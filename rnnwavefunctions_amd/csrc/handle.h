@@ -38,6 +38,29 @@ struct Knobs {
     int ablate = 0, ablate_base = 0;   // RNNWF_ABLATE / RNNWF_ABLATE_BASE: only in -DRNNWF_DIAGNOSTICS builds (tools/)
 };
 
+// Device-resident training (train.hip): the parameters, Adam's moments and the flat gradient live on the device; after every update
+// the kernels' weight images are rebuilt there by replaying the host packers' recorded element tables (pack_value.h).
+struct TrainImage {
+    DevBuf table;                 // PackEntry[n]
+    int64_t n = 0;
+    DevBuf* target = nullptr;     // the image it rebuilds (h->wimg, h->wsplit, ...)
+};
+struct TrainState {
+    bool built = false, supported = false;
+    std::string why;              // why not supported
+    DevBuf P, M, V, G;            // flat f64: parameters (order of rnnwf_set_params_flat), Adam's m and v, gradient
+    DevBuf gidx;                  // int32[nparams]: +-(k + 1) = element k of the dW image (sign: the head's logit difference), 0: none
+    int64_t nparams = 0;
+    size_t dw_count = 0;
+    bool dw_f64 = false;
+    TrainImage img[5];
+    int nimg = 0;
+    int64_t adam_t = 0;           // updates applied so far (tf.train.AdamOptimizer's beta powers are beta^(t+1))
+    bool host_newer = true;       // the host copy of the parameters changed since the device copy was made
+    bool dev_newer = false;       // the device copy was updated by an optimizer step the host copy has not seen
+    void* mom_host = nullptr;     // pinned [kMaxSteps][4] doubles: the moments of the K steps of one rnnwf_train_steps call
+};
+
 struct ParamSpec {
     std::vector<int64_t> shape; // as the caller sees it (the reference's TF variable)
     std::vector<double> value;  // stored in f64, converted to the model type when packed.  Layers of unequal width are held PADDED
@@ -84,6 +107,7 @@ struct rnnwf_handle {
     rnnwf::DevBuf wbasebf;        // bf16x3 A fragments of the cooperative base pass (layout.h: BaseBfLayout); valid iff base_bf
     rnnwf::DevBuf wsplit_up[RNNWF_MAX_LAYERS - 1];   // stacked layers on the bf16x3 engine: image of layer l in [l - 1] (split_core.h: SplitUpperLayout)
     rnnwf::DevBuf xrec[2];        // their layer pipeline: per-step state records of one layer, read by the kernel of the layer above
+    rnnwf::TrainState train;      // device-resident training (train.hip)
     bool base_bf = false;
     bool engine_split = false;
     bool engine_forced = false;   // RNNWF_ENGINE=bf16x3: no small-batch fallback to the f32-input MFMA

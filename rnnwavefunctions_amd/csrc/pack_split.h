@@ -9,27 +9,6 @@
 
 namespace rnnwf {
 
-inline uint16_t bf16_rne(float x) {
-    uint32_t u;
-    std::memcpy(&u, &x, 4);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-inline float bf16_to_float(uint16_t b) {
-    const uint32_t u = (uint32_t)b << 16;
-    float f;
-    std::memcpy(&f, &u, 4);
-    return f;
-}
-// w -> three bf16 numbers whose sum is exactly (float)w
-inline void split3(double w, uint16_t (&p)[3]) {
-    float r = (float)w;
-    for (int i = 0; i < 3; ++i) {
-        p[i] = bf16_rne(r);
-        r -= bf16_to_float(p[i]);
-    }
-}
-
 // Image of the 16x16x32 form of the flip pass at 37..52 units (split16_core.h: S16nLayout).
 template <int NOUT>
 std::vector<char> pack_split16n_image(const rnnwf_handle* h) {
@@ -112,21 +91,23 @@ std::vector<char> pack_split16n_image(const rnnwf_handle* h) {
 }
 
 // Image of the 16x16x32 form of the flip pass at 69..100 units (split16_core.h: S16Layout).
-template <int NOUT>
+template <int NOUT, class S = double>
 std::vector<char> pack_split16_image(const rnnwf_handle* h) {
     using L = S16Layout<NOUT>;
+    using Out = PackSink<S>;
     static_assert(NOUT == 1, "the 16x16x32 form carries one head row (positive RNN)");
     const int H = h->H;
     std::vector<char> img(L::BYTES, 0);
+    Out::begin(img);
     const std::string pre = kGruPre;
-    const auto& Wg = pv(h, pre + "gates/kernel");
-    const auto& bg = pv(h, pre + "gates/bias");
-    const auto& Wci = pv(h, pre + "candidate/input_projection/kernel");
-    const auto& bci = pv(h, pre + "candidate/input_projection/bias");
-    const auto& Wch = pv(h, pre + "candidate/hidden_projection/kernel");
-    const auto& bch = pv(h, pre + "candidate/hidden_projection/bias");
-    const auto& Wd = pv(h, "wf_dense/kernel");
-    const auto& bd = pv(h, "wf_dense/bias");
+    const auto Wg = pvs<S>(h, pre + "gates/kernel");
+    const auto bg = pvs<S>(h, pre + "gates/bias");
+    const auto Wci = pvs<S>(h, pre + "candidate/input_projection/kernel");
+    const auto bci = pvs<S>(h, pre + "candidate/input_projection/bias");
+    const auto Wch = pvs<S>(h, pre + "candidate/hidden_projection/kernel");
+    const auto bch = pvs<S>(h, pre + "candidate/hidden_projection/bias");
+    const auto Wd = pvs<S>(h, "wf_dense/kernel");
+    const auto bd = pvs<S>(h, "wf_dense/bias");
     const double sg = PackScale<float>::gate, sc = PackScale<float>::cand;
     // row (tile t, row i = 4 g + r) -> (gate, unit): gate 0 r, 1 u, 2 candidate, 3 head; unit -1: unused row
     auto decode = [&](int t, int g, int r, int& gate, int& unit) {
@@ -143,12 +124,12 @@ std::vector<char> pack_split16_image(const rnnwf_handle* h) {
         }
         if (gate < 3 && unit >= H) unit = -1;
     };
-    auto weight = [&](int gate, int uo, int ui) -> double {
-        if (ui >= H) return 0.0;
-        return gate == 0 ? sg * Wg[(size_t)(2 + ui) * 2 * H + uo]
-             : gate == 1 ? sg * Wg[(size_t)(2 + ui) * 2 * H + H + uo]
-             : gate == 2 ? sc * Wch[(size_t)ui * H + uo]
-                         : Wd[(size_t)ui * 2 + 1] - Wd[(size_t)ui * 2];
+    auto weight = [&](int gate, int uo, int ui) -> S {
+        if (ui >= H) return S(0.0);
+        if (gate == 0) return sg * Wg[(size_t)(2 + ui) * 2 * H + uo];
+        if (gate == 1) return sg * Wg[(size_t)(2 + ui) * 2 * H + H + uo];
+        if (gate == 2) return sc * Wch[(size_t)ui * H + uo];
+        return Wd[(size_t)ui * 2 + 1] - Wd[(size_t)ui * 2];
     };
     uint16_t* A = reinterpret_cast<uint16_t*>(img.data() + L::OFF_A);
     uint16_t* ASP = reinterpret_cast<uint16_t*>(img.data() + L::OFF_ASP);
@@ -160,23 +141,23 @@ std::vector<char> pack_split16_image(const rnnwf_handle* h) {
             decode(t, go, r, gate, uo);
             if (uo < 0) continue;
             for (int sgm = 0; sgm < 2; ++sgm) {                  // accumulator start value: bias + one-hot input row
-                const double v = gate == 0 ? sg * (bg[uo] + Wg[(size_t)sgm * 2 * H + uo])
-                               : gate == 1 ? sg * (bg[H + uo] + Wg[(size_t)sgm * 2 * H + H + uo])
-                               : gate == 2 ? sc * bch[uo] : bd[1] - bd[0];
-                CI[(((size_t)sgm * L::NT + t) * 4 + go) * 4 + r] = (float)v;
+                S v;
+                if (gate == 0) v = sg * (bg[uo] + Wg[(size_t)sgm * 2 * H + uo]);
+                else if (gate == 1) v = sg * (bg[H + uo] + Wg[(size_t)sgm * 2 * H + H + uo]);
+                else if (gate == 2) v = sc * bch[uo];
+                else v = bd[1] - bd[0];
+                Out::put(&CI[(((size_t)sgm * L::NT + t) * 4 + go) * 4 + r], v);
             }
             for (int g = 0; g < 4; ++g) {                        // K side: lane group g supplies its units 4 j + g
                 const int lane = (g << 4) | i;
                 for (int o = 0; o < L::NOCT; ++o)
                     for (int e = 0; e < 8; ++e) {
-                        uint16_t p[3];
-                        split3(weight(gate, uo, 4 * (8 * o + e) + g), p);
-                        for (int a = 0; a < 3; ++a) A[((((size_t)t * 3 + a) * L::NOCT + o) * 64 + lane) * 8 + e] = p[a];
+                        auto at = [&](int a) { return &A[((((size_t)t * 3 + a) * L::NOCT + o) * 64 + lane) * 8 + e]; };
+                        Out::put_parts(at(0), at(1), at(2), weight(gate, uo, 4 * (8 * o + e) + g));
                     }
-                uint16_t p[3];
-                split3(weight(gate, uo, 4 * L::NJA + g), p);
+                const S ws = weight(gate, uo, 4 * L::NJA + g);
                 const int part[6] = {0, 0, 0, 1, 1, 2};          // against the B entries {h1, h2, h3, h1, h2, h1}
-                for (int e = 0; e < 6; ++e) ASP[((size_t)t * 64 + lane) * 8 + e] = p[part[e]];
+                for (int e = 0; e < 6; ++e) Out::put_part(&ASP[((size_t)t * 64 + lane) * 8 + e], ws, part[e]);
             }
         }
     float* XC = reinterpret_cast<float*>(img.data() + L::OFF_XC);
@@ -186,26 +167,28 @@ std::vector<char> pack_split16_image(const rnnwf_handle* h) {
         for (int j = 0; j < L::NJ; ++j) {
             const int u = 4 * j + g;
             if (u >= H) continue;
-            for (int sgm = 0; sgm < 2; ++sgm) XC[((size_t)sgm * 4 + g) * L::XCP + j] = (float)(sc * (bci[u] + Wci[(size_t)sgm * H + u]));
-            WD[(size_t)g * L::XCP + j] = (float)(Wd[(size_t)u * 2 + 1] - Wd[(size_t)u * 2]);
+            for (int sgm = 0; sgm < 2; ++sgm) Out::put(&XC[((size_t)sgm * 4 + g) * L::XCP + j], sc * (bci[u] + Wci[(size_t)sgm * H + u]));
+            Out::put(&WD[(size_t)g * L::XCP + j], Wd[(size_t)u * 2 + 1] - Wd[(size_t)u * 2]);
         }
-    BD[0] = (float)(bd[1] - bd[0]);
+    Out::put(&BD[0], bd[1] - bd[0]);
     return img;
 }
 
 // bf16x3 A fragments of the cooperative base pass (layout.h: BaseBfLayout): the rows of pack_gru_image (same scaled f32
 // weights), each split exactly into three bf16 parts.
-template <int NFULL>
+template <int NFULL, class S = double>
 std::vector<char> pack_base_bf_image(const rnnwf_handle* h) {
     using B = BaseBfLayout<NFULL>;
+    using Out = PackSink<S>;
     const int H = h->H;
     std::vector<char> img(B::BYTES, 0);
+    Out::begin(img);
     const std::string pre = kGruPre;
-    const auto& Wg = pv(h, pre + "gates/kernel");
-    const auto& Wch = pv(h, pre + "candidate/hidden_projection/kernel");
+    const auto Wg = pvs<S>(h, pre + "gates/kernel");
+    const auto Wch = pvs<S>(h, pre + "candidate/hidden_projection/kernel");
     const double sg = PackScale<float>::gate, sc = PackScale<float>::cand;
-    auto wt = [&](int gate, int unit, int k) -> double {
-        if (k >= H) return 0.0;
+    auto wt = [&](int gate, int unit, int k) -> S {
+        if (k >= H) return S(0.0);
         if (gate == 0) return sg * Wg[(size_t)(2 + k) * 2 * H + unit];
         if (gate == 1) return sg * Wg[(size_t)(2 + k) * 2 * H + H + unit];
         return sc * Wch[(size_t)k * H + unit];
@@ -226,31 +209,40 @@ std::vector<char> pack_base_bf_image(const rnnwf_handle* h) {
                         if (grp < NFULL) ku = 16 * grp + 4 * kr + kq;
                         else if (grp == NFULL && kr == 0) ku = 16 * NFULL + kq;
                         if (ku < 0 || ku >= H) continue;
-                        uint16_t p[3];
-                        split3((double)(float)wt(gate, unit, ku), p);
                         const int lane = (g << 4) | row;
-                        for (int a = 0; a < 3; ++a) A[((((size_t)tile * 3 + a) * B::NKS + t) * 64 + lane) * 8 + e] = p[a];
+                        auto at = [&](int a) { return &A[((((size_t)tile * 3 + a) * B::NKS + t) * 64 + lane) * 8 + e]; };
+                        Out::put_parts(at(0), at(1), at(2), wt(gate, unit, ku));      // (the split starts from the value as f32)
                     }
         }
     return img;
 }
 
-template <int NF32, int RJ, int NOUT = 1, int MODE = 0>
+template <int NF32, int RJ, int NOUT = 1, int MODE = 0, class S = double>
 std::vector<char> pack_split_image(const rnnwf_handle* h) {
     using L = SplitLayout<NF32, RJ, NOUT, MODE>;
+    using Out = PackSink<S>;
     const int H = h->H;
     std::vector<char> img(L::BYTES, 0);
+    Out::begin(img);
     const std::string pre = kGruPre;
-    const auto& Wg = pv(h, pre + "gates/kernel");
-    const auto& bg = pv(h, pre + "gates/bias");
-    const auto& Wci = pv(h, pre + "candidate/input_projection/kernel");
-    const auto& bci = pv(h, pre + "candidate/input_projection/bias");
-    const auto& Wch = pv(h, pre + "candidate/hidden_projection/kernel");
-    const auto& bch = pv(h, pre + "candidate/hidden_projection/bias");
-    const auto& Wd = pv(h, NOUT == 1 ? "wf_dense/kernel" : "wf_dense_ampl/kernel");
-    const auto& bd = pv(h, NOUT == 1 ? "wf_dense/bias" : "wf_dense_ampl/bias");
+    const auto Wg = pvs<S>(h, pre + "gates/kernel");
+    const auto bg = pvs<S>(h, pre + "gates/bias");
+    const auto Wci = pvs<S>(h, pre + "candidate/input_projection/kernel");
+    const auto bci = pvs<S>(h, pre + "candidate/input_projection/bias");
+    const auto Wch = pvs<S>(h, pre + "candidate/hidden_projection/kernel");
+    const auto bch = pvs<S>(h, pre + "candidate/hidden_projection/bias");
+    const auto Wd = pvs<S>(h, NOUT == 1 ? "wf_dense/kernel" : "wf_dense_ampl/kernel");
+    const auto bd = pvs<S>(h, NOUT == 1 ? "wf_dense/bias" : "wf_dense_ampl/bias");
     const double sg = PackScale<float>::gate, sc = PackScale<float>::cand;
     uint16_t* A = reinterpret_cast<uint16_t*>(img.data() + L::OFF_A);
+    auto head_w = [&](int o, int ui) -> S {
+        if (o == 0) return Wd[(size_t)ui * 2 + 1] - Wd[(size_t)ui * 2];
+        return pvs<S>(h, "wf_dense_phase/kernel")[(size_t)ui * 2 + (o - 1)];
+    };
+    auto head_b = [&](int o) -> S {
+        if (o == 0) return bd[1] - bd[0];
+        return pvs<S>(h, "wf_dense_phase/bias")[o - 1];
+    };
     for (int T = 0; T < L::NT; ++T)
         for (int lane = 0; lane < 64; ++lane) {
             const int r32 = lane & 31, hhk = lane >> 5;
@@ -268,29 +260,24 @@ std::vector<char> pack_split_image(const rnnwf_handle* h) {
                 else if ((MODE == 2 || MODE == 3) && s < L::HEAD_SLOT + NOUT) { g = 3 + (s - L::HEAD_SLOT); uo = 0; }
             }
             if (g < 0 || uo >= H) continue;
-            auto head_w = [&](int o, int ui) -> double {
-                if (o == 0) return Wd[(size_t)ui * 2 + 1] - Wd[(size_t)ui * 2];
-                const auto& Wp = pv(h, "wf_dense_phase/kernel");
-                return Wp[(size_t)ui * 2 + (o - 1)];
-            };
-            auto weight = [&](int ui) -> double {          // (scaled) recurrent weight from unit ui into row (g, uo)
-                if (ui >= H) return 0.0;
-                return g == 0 ? sg * Wg[(size_t)(2 + ui) * 2 * H + uo]
-                     : g == 1 ? sg * Wg[(size_t)(2 + ui) * 2 * H + H + uo]
-                     : g == 2 ? sc * Wch[(size_t)ui * H + uo]
-                              : head_w(g - 3, ui);
+            auto weight = [&](int ui) -> S {               // (scaled) recurrent weight from unit ui into row (g, uo)
+                if (ui >= H) return S(0.0);
+                if (g == 0) return sg * Wg[(size_t)(2 + ui) * 2 * H + uo];
+                if (g == 1) return sg * Wg[(size_t)(2 + ui) * 2 * H + H + uo];
+                if (g == 2) return sc * Wch[(size_t)ui * H + uo];
+                return head_w(g - 3, ui);
             };
             if constexpr (MODE != 0) {
                 // accumulator start value of this row: bias + one-hot input row (the same for both K halves)
                 if (hhk == 0) {
                     float* CI = reinterpret_cast<float*>(img.data() + L::OFF_CI);
                     for (int sgm = 0; sgm < 2; ++sgm) {
-                        double hb = 0.0;
-                        if (g >= 3) hb = g == 3 ? bd[1] - bd[0] : pv(h, "wf_dense_phase/bias")[g - 4];
-                        const double v = g == 0 ? sg * (bg[uo] + Wg[(size_t)sgm * 2 * H + uo])
-                                       : g == 1 ? sg * (bg[H + uo] + Wg[(size_t)sgm * 2 * H + H + uo])
-                                       : g == 2 ? sc * bch[uo] : hb;
-                        CI[(((size_t)sgm * L::NT + T) * 2 + hh_row) * 16 + rho] = (float)v;
+                        S v;
+                        if (g == 0) v = sg * (bg[uo] + Wg[(size_t)sgm * 2 * H + uo]);
+                        else if (g == 1) v = sg * (bg[H + uo] + Wg[(size_t)sgm * 2 * H + H + uo]);
+                        else if (g == 2) v = sc * bch[uo];
+                        else v = head_b(g - 3);
+                        Out::put(&CI[(((size_t)sgm * L::NT + T) * 2 + hh_row) * 16 + rho], v);
                     }
                 }
             }
@@ -302,19 +289,16 @@ std::vector<char> pack_split_image(const rnnwf_handle* h) {
                         const int fe = 8 * ks + jj, f = fe / 2;
                         if (f >= 6 * L::NRM) continue;
                         const int o = f / L::NRM, e = 2 * (f % L::NRM) + (fe & 1);
-                        uint16_t p[3];
-                        split3(weight(L::unit_of(e, hhk)), p);
-                        A[(((size_t)ks * L::NT + T) * 64 + lane) * 8 + jj] = p[ORD[o][0]];
+                        Out::put_part(&A[(((size_t)ks * L::NT + T) * 64 + lane) * 8 + jj], weight(L::unit_of(e, hhk)), ORD[o][0]);
                     }
                 continue;
             }
             if constexpr (MODE == 2) {
                 // special unit of K half hhk: parts {w1, w1, w1, w2, w2, w3} against the B entries {h1, h2, h3, h1, h2, h1}
-                uint16_t p[3];
-                split3(weight(L::unit_of(L::NU - 1, hhk)), p);
+                const S ws = weight(L::unit_of(L::NU - 1, hhk));
                 uint16_t* ASP = reinterpret_cast<uint16_t*>(img.data() + L::OFF_ASP);
                 const int part[6] = {0, 0, 0, 1, 1, 2};
-                for (int jj = 0; jj < 6; ++jj) ASP[((size_t)T * 64 + lane) * 8 + jj] = p[part[jj]];
+                for (int jj = 0; jj < 6; ++jj) Out::put_part(&ASP[((size_t)T * 64 + lane) * 8 + jj], ws, part[jj]);
             }
             if constexpr (MODE == 3) {
                 // NS special units per K half: entry 6 s + i of the special k-steps = product i of special unit s,
@@ -322,32 +306,32 @@ std::vector<char> pack_split_image(const rnnwf_handle* h) {
                 uint16_t* ASP = reinterpret_cast<uint16_t*>(img.data() + L::OFF_ASP);
                 const int part[6] = {0, 0, 0, 1, 1, 2};
                 for (int sp = 0; sp < L::NS; ++sp) {
-                    uint16_t p[3];
-                    split3(weight(L::unit_of(L::NUA + sp, hhk)), p);
+                    const S ws = weight(L::unit_of(L::NUA + sp, hhk));
                     for (int i = 0; i < 6; ++i) {
                         const int idx = 6 * sp + i;
-                        ASP[(((size_t)T * L::KSP + idx / 8) * 64 + lane) * 8 + idx % 8] = p[part[i]];
+                        Out::put_part(&ASP[(((size_t)T * L::KSP + idx / 8) * 64 + lane) * 8 + idx % 8], ws, part[i]);
                     }
                 }
             }
             for (int x = 0; x < L::NQ; ++x)
                 for (int jj = 0; jj < 8; ++jj) {
                     const int e = 8 * x + jj;
-                    double w = 0.0;
+                    S w = S(0.0);
                     if (e < L::NUA) {
                         w = weight(L::unit_of(e, hhk));
                     } else if (MODE != 0) {
-                        w = 0.0;
+                        w = S(0.0);
                     } else if (e == L::NU && hhk == 0) {                    // bias (+ input row of spin 0)
-                        w = g == 0 ? sg * (bg[uo] + Wg[uo]) : g == 1 ? sg * (bg[H + uo] + Wg[H + uo]) : g == 2 ? sc * bch[uo]
-                          : g == 3 ? bd[1] - bd[0] : pv(h, "wf_dense_phase/bias")[g - 4];
+                        if (g == 0) w = sg * (bg[uo] + Wg[uo]);
+                        else if (g == 1) w = sg * (bg[H + uo] + Wg[H + uo]);
+                        else if (g == 2) w = sc * bch[uo];
+                        else w = head_b(g - 3);
                     } else if (e == L::NU + 1 && hhk == 0) {                // input row difference, times sigma
-                        w = g == 0 ? sg * (Wg[(size_t)2 * H + uo] - Wg[uo])
-                          : g == 1 ? sg * (Wg[(size_t)2 * H + H + uo] - Wg[H + uo]) : 0.0;
+                        if (g == 0) w = sg * (Wg[(size_t)2 * H + uo] - Wg[uo]);
+                        else if (g == 1) w = sg * (Wg[(size_t)2 * H + H + uo] - Wg[H + uo]);
                     }
-                    uint16_t p[3];
-                    split3(w, p);
-                    for (int a = 0; a < 3; ++a) A[((((size_t)T * 3 + a) * L::NQ + x) * 64 + lane) * 8 + jj] = p[a];
+                    auto at = [&](int a) { return &A[((((size_t)T * 3 + a) * L::NQ + x) * 64 + lane) * 8 + jj]; };
+                    Out::put_parts(at(0), at(1), at(2), w);
                 }
         }
     float* XC = reinterpret_cast<float*>(img.data() + L::OFF_XC);
@@ -358,23 +342,12 @@ std::vector<char> pack_split_image(const rnnwf_handle* h) {
             const int u = L::unit_of(e, hh);
             if (u >= H) continue;
             for (int sgm = 0; sgm < 2; ++sgm)
-                XC[(size_t)(sgm * 2 + hh) * L::NUP + e] = (float)(sc * (bci[u] + Wci[(size_t)sgm * H + u]));
-            WD[((size_t)hh * L::NUP + e) * NOUT] = (float)(Wd[(size_t)u * 2 + 1] - Wd[(size_t)u * 2]);
-            if (NOUT == 3) {
-                const auto& Wp = pv(h, "wf_dense_phase/kernel");
-                WD[((size_t)hh * L::NUP + e) * NOUT + 1] = (float)Wp[(size_t)u * 2];
-                WD[((size_t)hh * L::NUP + e) * NOUT + 2] = (float)Wp[(size_t)u * 2 + 1];
-            }
+                Out::put(&XC[(size_t)(sgm * 2 + hh) * L::NUP + e], sc * (bci[u] + Wci[(size_t)sgm * H + u]));
+            for (int o = 0; o < NOUT; ++o) Out::put(&WD[((size_t)hh * L::NUP + e) * NOUT + o], head_w(o, u));
         }
-    BD[0] = (float)(bd[1] - bd[0]);
-    if (NOUT == 3) {
-        const auto& bp = pv(h, "wf_dense_phase/bias");
-        BD[1] = (float)bp[0];
-        BD[2] = (float)bp[1];
-    }
+    for (int o = 0; o < NOUT; ++o) Out::put(&BD[o], head_b(o));
     return img;
 }
-
 
 // Image of GRU layer `layer` >= 1 on the bf16x3 engine (split_core.h: SplitUpperLayout): the X block (input = state of the layer
 // below) and the H block, each laid out as the MODE 2 image of the first layer, the biases as accumulator start values, and - for

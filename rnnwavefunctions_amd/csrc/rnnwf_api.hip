@@ -214,6 +214,15 @@ extern "C" int rnnwf_create(const rnnwf_config* cfg, rnnwf_handle** out) {
         return RNNWF_ERR_INVALID;
     }
     declare_params(h);
+    {   // padded index -> flat parameter index (the order of rnnwf_set_params_flat: tensors by name, each in the caller's shape)
+        int32_t off = 0;
+        for (auto& kv : h->params) {
+            std::vector<int32_t>& f = h->param_flat[kv.first];
+            f.assign(kv.second.value.size(), -1);
+            for (size_t i = 0; i < kv.second.slot.size(); ++i) f[(size_t)kv.second.slot[i]] = off + (int32_t)i;
+            off += (int32_t)kv.second.slot.size();
+        }
+    }
     *out = h;
     return RNNWF_OK;
 }
@@ -232,7 +241,9 @@ extern "C" int rnnwf_destroy(rnnwf_handle* h) {
     DevBuf* bufs[] = {&h->wimg, &h->samples_i32, &h->bits, &h->bits2, &h->hck, &h->lpq, &h->lpq2, &h->out_lp,
                       &h->out_lp2, &h->eloc, &h->moments, &h->coupl, &h->maps, &h->camp, &h->tiles,
                       &h->tile_count, &h->cbase, &h->cout, &h->rowbuf, &h->wbwd, &h->gradP, &h->gradQ, &h->gradW, &h->gradPart, &h->gradHeadPart, &h->wsplit, &h->wsplit16, &h->wbasebf, &h->gradDX[0], &h->gradDX[1], &h->reduce_scratch,
-                      &h->xrec[0], &h->xrec[1], &h->wsplit_up[0], &h->wsplit_up[1], &h->wsplit_up[2]};
+                      &h->xrec[0], &h->xrec[1], &h->wsplit_up[0], &h->wsplit_up[1], &h->wsplit_up[2],
+                      &h->train.P, &h->train.M, &h->train.V, &h->train.G, &h->train.gidx, &h->train.img[0].table, &h->train.img[1].table,
+                      &h->train.img[2].table, &h->train.img[3].table, &h->train.img[4].table};
     static_assert(RNNWF_MAX_LAYERS == 4, "wsplit_up has RNNWF_MAX_LAYERS - 1 entries");
     for (DevBuf* b : bufs) free_buf(*b);
     for (auto& t : h->timers) {
@@ -240,6 +251,7 @@ extern "C" int rnnwf_destroy(rnnwf_handle* h) {
         for (auto& ev : t.pool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     }
     if (h->pinned) hipHostFree(h->pinned);
+    if (h->train.mom_host) hipHostFree(h->train.mom_host);
     if (h->staging) hipHostFree(h->staging);
     if (h->upbuf) hipHostFree(h->upbuf);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -263,6 +275,8 @@ static int find_param(rnnwf_handle* h, const char* name, int64_t count, ParamSpe
 
 extern "C" int rnnwf_set_param(rnnwf_handle* h, const char* name, const void* data, int64_t count, int32_t dtype) {
     if (!h || !data) return RNNWF_ERR_INVALID;
+    if (int rc = train_sync_params_to_host(h)) return rc;         // (the other tensors must be current before this one is replaced)
+    train_params_changed_on_host(h);
     ParamSpec* p;
     if (int rc = find_param(h, name, count, &p)) return rc;
     if (dtype == RNNWF_F32) for (int64_t i = 0; i < count; ++i) p->value[p->slot[i]] = ((const float*)data)[i];
@@ -275,6 +289,7 @@ extern "C" int rnnwf_set_param(rnnwf_handle* h, const char* name, const void* da
 
 extern "C" int rnnwf_get_param(rnnwf_handle* h, const char* name, void* data, int64_t count, int32_t dtype) {
     if (!h || !data) return RNNWF_ERR_INVALID;
+    if (int rc = train_sync_params_to_host(h)) return rc;         // device-resident optimizer steps the host copy has not seen
     ParamSpec* p;
     if (int rc = find_param(h, name, count, &p)) return rc;
     if (dtype == RNNWF_F32) for (int64_t i = 0; i < count; ++i) ((float*)data)[i] = (float)p->value[p->slot[i]];
@@ -298,6 +313,7 @@ extern "C" int rnnwf_set_params_flat(rnnwf_handle* h, const double* flat, int64_
         off += (int64_t)p.slot.size();
         p.set = true;
     }
+    train_params_changed_on_host(h);
     h->committed = false;
     return rnnwf_commit_params(h);
 }
@@ -320,6 +336,7 @@ extern "C" int64_t rnnwf_num_params(const rnnwf_handle* h) {
 
 extern "C" int rnnwf_init_params(rnnwf_handle* h, uint64_t seed) {
     if (!h) return RNNWF_ERR_INVALID;
+    train_params_changed_on_host(h);
     if (seed > 0xffffffffull) return h->fail(RNNWF_ERR_INVALID, "rnnwf_init_params: seed must fit 32 bits (numpy.random.RandomState)");
     NumpyRandomState rng((uint32_t)seed);
     const int64_t H = h->H;
@@ -373,6 +390,7 @@ extern "C" int rnnwf_init_params(rnnwf_handle* h, uint64_t seed) {
 
 extern "C" int rnnwf_commit_params(rnnwf_handle* h) {
     if (!h) return RNNWF_ERR_INVALID;
+    if (int rc = train_sync_params_to_host(h)) return rc;
     for (auto& kv : h->params)
         if (!kv.second.set) return h->fail(RNNWF_ERR_STATE, "parameter '%s' was never set", kv.first.c_str());
     RNNWF_HIP(h, hipSetDevice(h->cfg.device));

@@ -99,6 +99,36 @@ class Adam:
         raise T.CheckpointError("the checkpoint holds Adam slots but neither a global step nor a usable beta power")
 
 
+    # -- the optimizer state as the device-resident path keeps it (rnnwf_adam_get_state / rnnwf_adam_set_state): flat, in the
+    #    library's tensor order
+    def to_flat(self, native, params, scope):
+        lay = native._layout()
+        n = sum(cnt for _, cnt in lay)
+        m, v, off = np.zeros(n), np.zeros(n), 0
+        for nm, cnt in lay:
+            k = scope + "/" + nm
+            if k in self.m:
+                m[off:off + cnt] = np.asarray(self.m[k], dtype=np.float64).ravel()
+                v[off:off + cnt] = np.asarray(self.v[k], dtype=np.float64).ravel()
+            off += cnt
+        return m, v
+
+    def from_flat(self, native, params, scope, m, v, t):
+        off = 0
+        for nm, cnt in native._layout():
+            k = scope + "/" + nm
+            self.m[k] = m[off:off + cnt].reshape(params[k].shape).copy()
+            self.v[k] = v[off:off + cnt].reshape(params[k].shape).copy()
+            off += cnt
+        self.t = int(t)
+
+
+# Device-resident iterations (rnnwf_train_steps): on by default where the library supports them (single-layer float32 GRU models);
+# DEVICE_TRAINING = False (or RNNWF_HOST_ADAM=1) keeps the optimizer on the host for every model - the two give the same trajectory
+# bit for bit (tests/test_gpu_training.py).
+DEVICE_TRAINING = os.environ.get("RNNWF_HOST_ADAM", "0") != "1"
+
+
 def cost_gradient(native, params, scope, mean_energy, norm, allreduce=False):
     """{scoped tf name: gradient} of the reference cost on the batch of the last vmc_step."""
     shapes = {k[len(scope) + 1:]: v.shape for k, v in params.items()}
@@ -117,6 +147,11 @@ def _train(wf, params, scope, couplings, numsteps, numsamples, seed, lr, lr_of_i
     comm = comm or D.ShardComm()
     offset, count = D.shard_range(numsamples, comm.rank, comm.world)
     meanEnergy, varEnergy = history if history is not None else ([], [])
+    # the whole iteration on the device, ten at a time (the reference prints and saves every 10 steps, :213-227): single process,
+    # or RCCL with the in-step all-reduce of the moments (the gradient then takes one in-stream all-reduce too)
+    if DEVICE_TRAINING and (comm.world == 1 or getattr(comm, "_moments_in_step", False)) and wf.device_training_supported():
+        return _train_on_device(wf, params, scope, couplings, numsteps, numsamples, seed, lr, lr_of_it, opt, complex_energy, comm,
+                                verbose, on_step, meanEnergy, varEnergy, offset, count)
     for it in range(len(meanEnergy), numsteps + 1):       # `for it in range(len(meanEnergy),numsteps+1)` (:199): a restored run resumes
         m = wf.vmc_step(count, seed=seed, step=it, couplings=couplings, sample_offset=offset)["moments"]
         s1, s2, n, si = comm.reduce_moments(m)
@@ -134,6 +169,36 @@ def _train(wf, params, scope, couplings, numsteps, numsamples, seed, lr, lr_of_i
             grads = comm.allreduce_grads(grads)
         params = opt.step(params, grads, lr_of_it(lr, it))
         wf.set_params(params, scope=scope)
+    return meanEnergy, varEnergy, params
+
+
+def _train_on_device(wf, params, scope, couplings, numsteps, numsamples, seed, lr, lr_of_it, opt, complex_energy, comm, verbose,
+                     on_step, meanEnergy, varEnergy, offset, count):
+    """_train's loop with rnnwf_train_steps: chunks that end where the reference prints / saves (every 10 steps), one host
+    synchronisation per chunk.  What the loop shows the outside - prints, the histories handed to on_step, the parameters and
+    optimizer state a checkpoint holds - is what the per-iteration loop shows at the same iteration."""
+    m0, v0 = opt.to_flat(wf, params, scope)
+    wf.adam_set_state(m0 if opt.t else None, v0 if opt.t else None, opt.t)
+    it = len(meanEnergy)
+    while it <= numsteps:
+        K = min(10 - it % 10, numsteps + 1 - it)
+        if on_step is not None and comm.rank == 0 and it % 500 == 0:      # the checkpoint of iteration `it` holds the state BEFORE its update
+            params = wf.get_params_dict(params, scope)
+            opt.from_flat(wf, params, scope, *wf.adam_get_state())
+        mom = wf.train_steps(count, seed, it, couplings, [float(lr_of_it(lr, j)) for j in range(it, it + K)], opt.b1, opt.b2, opt.eps,
+                             sample_offset=offset)
+        for j in range(K):
+            s1, s2, n, si = mom[j]
+            meanE = complex(s1 / n, si / n) if complex_energy else s1 / n
+            meanEnergy.append(np.complex64(meanE) if complex_energy else meanE)
+            varEnergy.append(s2 / n - (s1 / n) ** 2)
+            if verbose and comm.rank == 0 and (it + j) % 10 == 0:
+                print("mean(E): {0}, var(E): {1}, #samples {2}, #Step {3} \n\n".format(meanEnergy[-1], varEnergy[-1], numsamples, it + j))
+            if on_step is not None and comm.rank == 0:
+                on_step(it + j, meanEnergy, varEnergy, params, opt)
+        it += K
+    params = wf.get_params_dict(params, scope)
+    opt.from_flat(wf, params, scope, *wf.adam_get_state())
     return meanEnergy, varEnergy, params
 
 
