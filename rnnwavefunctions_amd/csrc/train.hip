@@ -30,8 +30,8 @@ __global__ void repack_kernel(const PackEntry* __restrict__ e, int64_t n, const 
     if (i >= n) return;
     const PackEntry t = e[i];
     double v = P[t.a];
-    if (t.b >= 0) v = (t.kind & PACK_MINUS) ? v - P[t.b] : v + P[t.b];
-    if (t.c != 1.0) v = t.c * v;
+    if (t.b >= 0) v = (t.kind & PACK_MINUS) ? __dsub_rn(v, P[t.b]) : __dadd_rn(v, P[t.b]);
+    if (t.c != 1.0) v = __dmul_rn(t.c, v);
     const int kind = t.kind & 255;
     if (kind == PACK_F32) {
         *reinterpret_cast<float*>(img + t.off) = (float)v;
@@ -64,12 +64,14 @@ __global__ void adam_kernel(double* __restrict__ P, double* __restrict__ M, doub
 #pragma clang fp contract(off)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    // every operation rounded on its own, as NumPy evaluates the host optimizer's expressions (no fused multiply-add: the
+    // translation unit is compiled with -ffp-contract=fast)
     const double g = G[i];
-    const double m = b1 * M[i] + (1.0 - b1) * g;
-    const double v = b2 * V[i] + ((1.0 - b2) * g) * g;
+    const double m = __dadd_rn(__dmul_rn(b1, M[i]), __dmul_rn(__dsub_rn(1.0, b1), g));
+    const double v = __dadd_rn(__dmul_rn(b2, V[i]), __dmul_rn(__dmul_rn(__dsub_rn(1.0, b2), g), g));
     M[i] = m;
     V[i] = v;
-    const double p = P[i] - (lr_t * m) / (__dsqrt_rn(v) + eps);
+    const double p = __dsub_rn(P[i], __ddiv_rn(__dmul_rn(lr_t, m), __dadd_rn(__dsqrt_rn(v), eps)));
     P[i] = f32 ? (double)(float)p : p;
 }
 
