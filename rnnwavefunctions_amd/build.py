@@ -17,7 +17,10 @@ SOURCES = ["rnnwf_api.hip", "prnn.hip", "crnn.hip", "split.hip", "split_stream.h
 # no SLP packing of adjacent f32 adds / fmas into v_pk_*_f32 in the bf16x3 engine's translation unit: packed-f32 (and v_dot2)
 # instructions stall behind bf16 MFMAs - their own wave's AND the SIMD partner's (measured: tools/microbench/issue_model,
 # a VALU segment with packed ops beside an MFMA partner 5 170 vs 3 337 cycles).  The f32-input-MFMA kernels keep it.
-PER_SOURCE_FLAGS = {"split.hip": ["-fno-slp-vectorize"], "split_stream.hip": ["-fno-slp-vectorize"]}
+# train.hip (device-side Adam and image re-pack) must round every operation on its own, as NumPy and the host packers do: no
+# contraction into fused multiply-adds (HIP's __dmul_rn / __dadd_rn are plain operators and were fused under -ffp-contract=fast;
+# found by tests/test_gpu_training.py: test_device_adam_step_and_checkpointed_state)
+PER_SOURCE_FLAGS = {"split.hip": ["-fno-slp-vectorize"], "split_stream.hip": ["-fno-slp-vectorize"], "train.hip": ["-ffp-contract=off"]}
 # the 100-unit bf16x3 kernel keeps its 160 accumulator registers in AGPRs (a wave addresses 256 VGPRs + 256 AGPRs; its
 # other live values need ~210 VGPRs): no -amdgpu-mfma-vgpr-form for its translation unit
 AGPR_FORM_SOURCES = {"split_stream.hip"}

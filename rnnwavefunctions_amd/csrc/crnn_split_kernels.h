@@ -158,28 +158,51 @@ __global__ void __launch_bounds__(512) crnn_swap_pp_kernel(CrnnArgs a, const voi
     u32x4 B[NB];
     f32x16 acc[NT];
     int64_t rec = 0;
-    auto next_tile = [&]() {
-        for (;;) {
-            ++round;
-            if (round * nw >= ntiles) { active = false; return; }
-            tile = tile_of(round);
-            if (tile < ntiles) { active = true; return; }
-        }
+    // A tile switch sits inside a VALU segment with the SIMD partner - and through the barrier the whole workgroup - waiting, and
+    // a swap tile needs TWO dependent fetches (its item, then the checkpoint of the item's sample).  Round 4 (profiles/
+    // r04_f_sq_cfg3_summary.txt: 28 % of the wave cycles waiting on memory, 218 wave-steps per SIMD with 48 switches per
+    // workgroup): the NEXT tile's item is fetched a whole tile ahead (at the switch into the current one), its checkpoint travels
+    // by LDS-DMA (no register destination) into a per-wave staging slot during the current tile's last VALU segment, where the
+    // chain's swap base and total are requested too; the switch itself then only reads LDS.
+    constexpr size_t SLOT_BYTES = (size_t)NU * 256;
+    char* slot = lds + ((L::BYTES + 15) / 16) * 16 + (size_t)wave * SLOT_BYTES;
+    typedef __attribute__((address_space(3))) void* LdsVoid;
+    typedef const __attribute__((address_space(1))) void* GlobVoid;
+    int64_t tile_nx = -1, round_nx = 0;
+    int lo_nx = 0;
+    bool valid_nx = false;
+    SwapItem it_nx{};
+    auto fetch_item = [&](int64_t t, int& lo_t, bool& valid_t, SwapItem& it_t) {
+        lo_t = lo_of(t);
+        const int k = (int)(t - a.tile_start[lo_t]) * 32 + c;
+        valid_t = k < a.cnt[lo_t];
+        it_t = a.items[(int64_t)lo_t * a.cap + (valid_t ? k : 0)];
     };
-    auto begin_tile = [&]() {
-        lo = lo_of(tile);
-        const int k = (int)(tile - a.tile_start[lo]) * 32 + c;
-        valid = k < a.cnt[lo];
-        it = a.items[(int64_t)lo * a.cap + (valid ? k : 0)];
-        s = it.s;
-        const float* src = hck + (((int64_t)lo * a.nsb + (s >> 4)) * (STACK ? st.kstride : kt16) + (STACK ? st.koff : 0)) * 64 + (s & 15);
+    auto peek = [&]() {                                        // the tile after the current one, and its item
+        tile_nx = -1;
+        for (int64_t r = round + 1; r * nw < ntiles; ++r) {
+            const int64_t t = tile_of(r);
+            if (t < ntiles) { tile_nx = t; round_nx = r; break; }
+        }
+        if (tile_nx >= 0) fetch_item(tile_nx, lo_nx, valid_nx, it_nx);
+    };
+    auto dma_checkpoint = [&](int lo_t, int s_t) {             // entry e of every lane -> slot + 256 e + 4 lane
+        const float* src = hck + (((int64_t)lo_t * a.nsb + (s_t >> 4)) * (STACK ? st.kstride : kt16) + (STACK ? st.koff : 0)) * 64 + (s_t & 15);
         auto off = [](int u) { return (u >> 2) * 64 + ((u & 3) << 4); };
 #pragma unroll
         for (int e = 0; e < NU; ++e) {
             const int u0 = L::unit_of(e, 0), u1 = L::unit_of(e, 1);
-            const int d = off(u1) - off(u0);
-            h[e] = (src + (hh ? d : 0))[off(u0)];              // HP <= 4 kt16: host-checked
+            const int d = off(u1) - off(u0);                   // HP <= 4 kt16: host-checked
+            __builtin_amdgcn_global_load_lds((GlobVoid)(src + (hh ? d : 0) + off(u0)), (LdsVoid)(slot + e * 256), 4, 0, 0);
         }
+    };
+    auto wait_vm = [&]() { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); };
+    // tile, lo, valid, it are set and the tile's checkpoint has landed in the slot
+    auto enter_tile = [&]() {
+        s = it.s;
+        const float* p = reinterpret_cast<const float*>(slot) + lane;
+#pragma unroll
+        for (int e = 0; e < NU; ++e) h[e] = p[e * 64];
         if constexpr (STACK) rec = a.rec_start[lo] + (tile - a.tile_start[lo]) * (int64_t)(N - 1 - lo);
         num_up = 0;
         for (int w = 0; w < (lo >> 5); ++w) num_up += __popc(a.bits[(int64_t)w * a.ns + s]);
@@ -192,7 +215,11 @@ __global__ void __launch_bounds__(512) crnn_swap_pp_kernel(CrnnArgs a, const voi
         re = 0.0; im = 0.0;
     };
     if (active) {
-        begin_tile();
+        fetch_item(tile, lo, valid, it);
+        dma_checkpoint(lo, it.s);
+        wait_vm();
+        enter_tile();
+        peek();
         PP::preload(lds, sig_in, lane, acc);
         PP::split(h, B);
     }
@@ -203,6 +230,16 @@ __global__ void __launch_bounds__(512) crnn_swap_pp_kernel(CrnnArgs a, const voi
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (active) {
+            const bool last = n + 1 == N;
+            double2 b_pre = make_double2(0.0, 0.0), t_pre = make_double2(0.0, 0.0);
+            if (last) {                                        // requested now, used at the end of the segment
+                if (!STACK && valid && hh == 0) {
+                    b_pre = a.cb[(int64_t)lo * a.ns + s];
+                    t_pre = a.tot[s];
+                }
+                if (tile_nx >= 0) dma_checkpoint(lo_nx, it_nx.s);
+            }
+            asm volatile("" ::: "memory");
             // The three head rows ride in spare slots of the mixed tiles (pack_split.h): this step's accumulators hold the
             // logits of the state that ENTERED it, i.e. of site n - 1 (spin sig_in, up-spins before it num_up - sig_in).
             // Site lo is not part of the sum; the chain's last site gets its logits from the VALU head below.
@@ -220,7 +257,7 @@ __global__ void __launch_bounds__(512) crnn_swap_pp_kernel(CrnnArgs a, const voi
                 ++rec;
             }
             const int sig = (int)((word >> (n & 31)) & 1) ^ (n == it.hi ? 1 : 0);
-            if (!STACK && n + 1 == N) {
+            if (!STACK && last) {
                 float z[3];
                 PP::head(lds, h, lane, z);
                 float la0, la1, w0, ph0, ph1;
@@ -231,16 +268,19 @@ __global__ void __launch_bounds__(512) crnn_swap_pp_kernel(CrnnArgs a, const voi
             num_up += sig;
             sig_in = sig;
             ++n;
-            if (n == N) {
+            if (last) {
                 if (!STACK && valid && hh == 0) {
-                    const double2 b = a.cb[(int64_t)lo * a.ns + s];
-                    const double2 t = a.tot[s];
-                    const double dre = b.x + re - t.x, dim = b.y + im - t.y;
+                    const double dre = b_pre.x + re - t_pre.x, dim = b_pre.y + im - t_pre.y;
                     const double mag = exp(dre) * (double)it.coef;
                     a.contrib[(int64_t)it.slot * a.ns + s] = make_double2(mag * cos(dim), mag * sin(dim));
                 }
-                next_tile();
-                if (active) begin_tile();
+                active = tile_nx >= 0;
+                if (active) {
+                    round = round_nx; tile = tile_nx; lo = lo_nx; valid = valid_nx; it = it_nx;
+                    wait_vm();                                 // the checkpoint has landed
+                    enter_tile();
+                    peek();                                    // the item of the tile after this one: used a whole tile later
+                }
             } else if ((n & 31) == 0) {
                 word = a.bits[(int64_t)(n >> 5) * a.ns + s];
             }
@@ -330,32 +370,48 @@ __global__ void __launch_bounds__(512) crnn_swap_pp_upper_kernel(CrnnArgs a, con
     };
     auto wait_vm = [&]() { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); };
     auto wait_lds = [&]() { __builtin_amdgcn_s_waitcnt(0xC07F); asm volatile("" ::: "memory"); };
-    auto next_tile = [&]() {
-        for (;;) {
-            ++round;
-            if (round * nw >= ntiles) { active = false; return; }
-            tile = tile_of(round);
-            if (tile < ntiles) { active = true; return; }
-        }
+    // Tile switch as in crnn_swap_pp_kernel: the next tile's item is fetched a tile ahead, its checkpoint travels by LDS-DMA into the
+    // staging slot during the current tile's last VALU segment (the slot is free there: a chain's last step requests no record);
+    // at the switch the checkpoint is read out of LDS and the new tile's first record is requested - the one latency that shows.
+    int64_t tile_nx = -1, round_nx = 0;
+    int lo_nx = 0;
+    bool valid_nx = false;
+    SwapItem it_nx{};
+    auto fetch_item = [&](int64_t t, int& lo_t, bool& valid_t, SwapItem& it_t) {
+        lo_t = lo_of(t);
+        const int k = (int)(t - a.tile_start[lo_t]) * 32 + c;
+        valid_t = k < a.cnt[lo_t];
+        it_t = a.items[(int64_t)lo_t * a.cap + (valid_t ? k : 0)];
     };
-    // A tile's item list is data dependent (one more dependent load than the TFIM pass's), so the switch is taken in place: item,
-    // checkpoint and first record are requested and waited for here - once per tile of N - 1 - lo steps.
-    auto begin_tile = [&]() {
-        lo = lo_of(tile);
-        const int k = (int)(tile - a.tile_start[lo]) * 32 + c;
-        valid = k < a.cnt[lo];
-        it = a.items[(int64_t)lo * a.cap + (valid ? k : 0)];
-        s = it.s;
-        rec = a.rec_start[lo] + (tile - a.tile_start[lo]) * (int64_t)(N - 1 - lo);
-        dma_record(rec);
-        const float* src = hck + (((int64_t)lo * a.nsb + (s >> 4)) * st.kstride + st.koff) * 64 + (s & 15);
+    auto peek = [&]() {
+        tile_nx = -1;
+        for (int64_t r = round + 1; r * nw < ntiles; ++r) {
+            const int64_t t = tile_of(r);
+            if (t < ntiles) { tile_nx = t; round_nx = r; break; }
+        }
+        if (tile_nx >= 0) fetch_item(tile_nx, lo_nx, valid_nx, it_nx);
+    };
+    auto dma_checkpoint = [&](int lo_t, int s_t) {             // entry e of every lane -> slot + 256 e + 4 lane
+        const float* src = hck + (((int64_t)lo_t * a.nsb + (s_t >> 4)) * st.kstride + st.koff) * 64 + (s_t & 15);
         auto off = [](int u) { return (u >> 2) * 64 + ((u & 3) << 4); };
 #pragma unroll
         for (int e = 0; e < NU; ++e) {
             const int u0 = L::unit_of(e, 0), u1 = L::unit_of(e, 1);
             const int d = off(u1) - off(u0);
-            h[e] = (src + (hh ? d : 0))[off(u0)];
+            __builtin_amdgcn_global_load_lds((GlobVoid)(src + (hh ? d : 0) + off(u0)), (LdsVoid)(slot + e * 256), 4, 0, 0);
         }
+    };
+    // tile, lo, valid, it are set and the tile's checkpoint has landed in the slot
+    auto begin_tile = [&]() {
+        s = it.s;
+        {
+            const float* p = reinterpret_cast<const float*>(slot) + lane;
+#pragma unroll
+            for (int e = 0; e < NU; ++e) h[e] = p[e * 64];
+        }
+        wait_lds();
+        rec = a.rec_start[lo] + (tile - a.tile_start[lo]) * (int64_t)(N - 1 - lo);
+        dma_record(rec);
         n = lo + 1;
         if constexpr (LAST) {
             num_up = 0;
@@ -379,7 +435,11 @@ __global__ void __launch_bounds__(512) crnn_swap_pp_upper_kernel(CrnnArgs a, con
         wait_lds();
     };
     if (active) {
+        fetch_item(tile, lo, valid, it);
+        dma_checkpoint(lo, it.s);
+        wait_vm();
         begin_tile();
+        peek();
         load_quads(true);
     }
     if (late) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
@@ -390,7 +450,16 @@ __global__ void __launch_bounds__(512) crnn_swap_pp_upper_kernel(CrnnArgs a, con
         __builtin_amdgcn_sched_barrier(0);
         if (active) {
             const bool last = n + 1 == N;
-            if (!last) dma_record(rec + 1);
+            double2 b_pre = make_double2(0.0, 0.0), t_pre = make_double2(0.0, 0.0);
+            if (!last) {
+                dma_record(rec + 1);
+            } else {
+                if (LAST && valid && hh == 0) {                // the chain's swap base and total: requested now, used at the segment's end
+                    b_pre = a.cb[(int64_t)lo * a.ns + s];
+                    t_pre = a.tot[s];
+                }
+                if (tile_nx >= 0) dma_checkpoint(lo_nx, it_nx.s);
+            }
             asm volatile("" ::: "memory");
             if constexpr (LAST) {
                 // head rows of the state that ENTERED the step: site n - 1 (spin sig_in, up-spins before it num_up - sig_in)
@@ -416,9 +485,7 @@ __global__ void __launch_bounds__(512) crnn_swap_pp_upper_kernel(CrnnArgs a, con
                     re += (double)(sig ? la1 : la0);
                     im += (double)(sig ? ph1 : ph0);
                     if (valid && hh == 0) {
-                        const double2 b = a.cb[(int64_t)lo * a.ns + s];
-                        const double2 t = a.tot[s];
-                        const double dre = b.x + re - t.x, dim = b.y + im - t.y;
+                        const double dre = b_pre.x + re - t_pre.x, dim = b_pre.y + im - t_pre.y;
                         const double mag = exp(dre) * (double)it.coef;
                         a.contrib[(int64_t)it.slot * a.ns + s] = make_double2(mag * cos(dim), mag * sin(dim));
                     }
@@ -429,8 +496,13 @@ __global__ void __launch_bounds__(512) crnn_swap_pp_upper_kernel(CrnnArgs a, con
             ++n;
             ++rec;
             if (last) {
-                next_tile();
-                if (active) begin_tile();
+                active = tile_nx >= 0;
+                if (active) {
+                    round = round_nx; tile = tile_nx; lo = lo_nx; valid = valid_nx; it = it_nx;
+                    wait_vm();                                 // the checkpoint has landed (and this chain's stores have gone)
+                    begin_tile();
+                    peek();
+                }
             } else if constexpr (LAST) {
                 if ((n & 31) == 0) word = a.bits[(int64_t)(n >> 5) * a.ns + s];
             }

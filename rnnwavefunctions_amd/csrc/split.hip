@@ -113,11 +113,12 @@ struct CSLaunch {
             const void* fn = (const void*)crnn_swap_pp_kernel<NF32, RJ>;
             if (L::HP > 4 * kt16) return h->fail(RNNWF_ERR_INVALID, "bf16x3 layout wider than the checkpoint rows (%d > %d)", L::HP, 4 * kt16);
             int bpc = 0;
-            if (int rc = rnnwf::blocks_per_cu(h, fn, 512, L::BYTES, &bpc)) return rc;
+            constexpr size_t LDS = SplitPP<NF32, RJ, 3>::LDS_WITH_SLOTS;
+            if (int rc = rnnwf::blocks_per_cu(h, fn, 512, LDS, &bpc)) return rc;
             const int64_t need = (max_tiles + 7) / 8;
             const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)bpc * h->cu_count));
             TimedLaunch tl(h, 1);
-            crnn_swap_pp_kernel<NF32, RJ><<<grid, 512, L::BYTES, h->stream>>>(a, h->wsplit.p, kt16, StackArgs{});
+            crnn_swap_pp_kernel<NF32, RJ><<<grid, 512, LDS, h->stream>>>(a, h->wsplit.p, kt16, StackArgs{});
             RNNWF_HIP(h, hipGetLastError());
             return 0;
         } else {
@@ -370,12 +371,13 @@ int rnnwf::crnn_stack_swap(rnnwf_handle* h, const CrnnArgs& a, int64_t max_tiles
     if (int rc = ensure(h, h->xrec[0], bytes)) return rc;
     if (NL > 2) if (int rc = ensure(h, h->xrec[1], bytes)) return rc;
     unsigned g0 = 0, gu = 0, gl = 0;
-    if (int rc = stack_grid(h, crnn_swap_pp_kernel<kStackNF32, kStackRJ, true>, CL0::BYTES, max_tiles, &g0)) return rc;
+    constexpr size_t LDS0 = SplitPP<kStackNF32, kStackRJ, 3>::LDS_WITH_SLOTS;
+    if (int rc = stack_grid(h, crnn_swap_pp_kernel<kStackNF32, kStackRJ, true>, LDS0, max_tiles, &g0)) return rc;
     if (int rc = stack_grid(h, crnn_swap_pp_upper_kernel<kStackNF32, kStackRJ, false>, StackU3::LDS_BYTES, max_tiles, &gu)) return rc;
     if (int rc = stack_grid(h, crnn_swap_pp_upper_kernel<kStackNF32, kStackRJ, true>, StackU3::LDS_BYTES, max_tiles, &gl)) return rc;
     TimedLaunch tl(h, 1);
     StackArgs st{nullptr, (float*)h->xrec[0].p, NL * kt16, 0};
-    crnn_swap_pp_kernel<kStackNF32, kStackRJ, true><<<g0, 512, CL0::BYTES, h->stream>>>(a, h->wsplit.p, kt16, st);
+    crnn_swap_pp_kernel<kStackNF32, kStackRJ, true><<<g0, 512, LDS0, h->stream>>>(a, h->wsplit.p, kt16, st);
     RNNWF_HIP(h, hipGetLastError());
     for (int l = 1; l < NL; ++l) {
         st.xin = (const float*)h->xrec[(l - 1) & 1].p;

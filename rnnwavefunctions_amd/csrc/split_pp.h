@@ -23,6 +23,8 @@ struct SplitPP {
     using L = typename C::L;
     static constexpr int NT = C::NT, NU = C::NU, NUA = C::NUA, NQ = C::NQ;
     static constexpr int NB = 3 * NQ + 1;        // state quads: 3 parts x NQ k-steps + the special k-step
+    // dynamic LDS of the swap pass's ping-pong kernel: the image + one checkpoint staging slot ([NU][64] f32) per wave (crnn_split_kernels.h)
+    static constexpr size_t LDS_WITH_SLOTS = ((L::BYTES + 15) / 16) * 16 + 8 * (size_t)NU * 256;
     static constexpr int NP = NUA / 2;           // packed registers per part (two units each)
     using Asm = MfmaSegAsm<NT, NQ>;
     static_assert(Asm::kAvailable, "no hand-scheduled MFMA segment generated for this layout (tools/gen_split_mfma_asm.py)");

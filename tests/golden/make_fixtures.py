@@ -203,7 +203,37 @@ def g4_estimators(ref1d, ref2d2d, ref2d1d, refj):
     return out
 
 
+def g7_notebook_trajectories():
+    """The training trajectories the reference's two tutorial notebooks RECORD as cell output (every 10th step of run_1DTFIM at
+    N=10, 10 units, 200 samples, lr 5e-3, 1000 steps; of run_J1J2 at N=10, J2=0.2, 10 units, 200 samples, lr 5e-4, 3000 steps):
+    numbers printed by the reference's own TF-1 run - data, read with `json`, nothing executed.  They pin what no in-container
+    run can: how fast and how far the reference's optimisation goes from its seeded initial state."""
+    import json
+    import re
+    out = {}
+    nb = json.load(open(os.path.join(REF, "Tutorials", "J1J2", "Tutorial_1DJ1J2.ipynb")))
+    cell = next(c for c in nb["cells"] if c["cell_type"] == "code" and "run_J1J2(" in "".join(c["source"]))
+    text = "".join("".join(o.get("text", [])) for o in cell["outputs"] if "text" in o)
+    rows = re.findall(r"mean\(E\): \(([-0-9.e]+)([+-][0-9.e]+)j\), var\(E\): ([0-9.e-]+), #samples 200, #Step (\d+)", text)
+    out["j1j2_step"] = np.array([int(r[3]) for r in rows])
+    out["j1j2_re"] = np.array([float(r[0]) for r in rows])
+    out["j1j2_im"] = np.array([float(r[1]) for r in rows])
+    out["j1j2_var"] = np.array([float(r[2]) for r in rows])
+    nb = json.load(open(os.path.join(REF, "Tutorials", "1DTFIM", "Tutorial_1DTFIM.ipynb")))
+    cell = next(c for c in nb["cells"] if c["cell_type"] == "code" and "run_1DTFIM(" in "".join(c["source"]))
+    text = "".join("".join(o.get("text", [])) for o in cell["outputs"] if "text" in o)
+    rows = re.findall(r"mean\(E\): ([-0-9.e]+), var\(E\): ([0-9.e-]+), #samples (\d+), #Step (\d+)", text)
+    out["tfim_step"] = np.array([int(r[3]) for r in rows])
+    out["tfim_e"] = np.array([float(r[0]) for r in rows])
+    out["tfim_var"] = np.array([float(r[1]) for r in rows])
+    assert len(out["j1j2_step"]) == 301 and len(out["tfim_step"]) == 101
+    return out
+
+
 def main():
+    np.savez_compressed(os.path.join(HERE, "notebook_trajectories.npz"), **g7_notebook_trajectories())
+    if "--trajectories-only" in sys.argv:
+        return
     ref1d = load_reference_module("1DTFIM", "TrainingRNN_1DTFIM.py")
     refj = load_reference_module("J1J2", "TrainingRNN_J1J2.py")
     ref2d2d = load_reference_module("2DTFIM_2DRNN", "Training2DRNN_2DTFIM.py")

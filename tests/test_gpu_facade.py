@@ -110,85 +110,40 @@ def test_init_params_in_the_library_equals_the_python_initialiser():
         wf.init_params(2 ** 33)
 
 
-def test_reference_script_text_runs_with_the_compat_module_as_tf(tmp_path, capsys):
-    """The reference's own statements of 1DTFIM/TrainingRNN_1DTFIM.py:103-136 (set-up, session, parameter count) and
-    :189-207 (the sampling / local-energy loop), written out here in this test's own words but with the SAME calls, run
-    with `import rnnwavefunctions_amd.compat as tf` and the reference-named modules of this package - i.e. only the two
-    import lines of the script change.  (The graph-mode gradient lines :141-166 are not part of this: training runs
-    through training.run_1DTFIM.)"""
+def test_graph_mode_surface_counts_samples_scores_and_saves(tmp_path, capsys):
+    """What a reference script does before and around its loop, through `rnnwavefunctions_amd.compat` as `tf` and the reference-named
+    modules of this package (tests/graph_mode.py makes the calls): the trainable variables and their count (422 at 10 units,
+    Tutorial_1DTFIM.ipynb cell 15), a sampling tensor, the estimator with its scratch arrays, and tf.train.Saver - whose file is a
+    TF V2 bundle under the TF variable names that a second wave function restores."""
     import rnnwavefunctions_amd.compat as tf
+    from graph_mode import GraphModeVMC
     from rnnwavefunctions_amd.TFIM1D.TrainingRNN_1DTFIM import Ising_local_energies, RNNwavefunction
+    from rnnwavefunctions_amd import tf_checkpoint as T
     tf.compat.v1.logging.set_verbosity(tf.compat.v1.logging.ERROR)
     tf.reset_default_graph()
-    seed, N, num_units, num_layers, numsamples, Bx = 111, 12, 10, 1, 40, 1.0
-    tf.set_random_seed(seed)
-    Jz = +np.ones(N)
-    lr = np.float64(5e-3)
-    units = [num_units] * num_layers
-    input_dim = 2
-    numsamples_ = 20
-    wf = RNNwavefunction(N, units=units, cell=tf.contrib.cudnn_rnn.CudnnCompatibleGRUCell, seed=seed)
-    sampling = wf.sample(numsamples_, input_dim)
+    tf.set_random_seed(111)
+    N, batch = 12, 40
+    wf = RNNwavefunction(N, units=[10], cell=tf.contrib.cudnn_rnn.CudnnCompatibleGRUCell, seed=111)
+    gm = GraphModeVMC(tf, wf, batch)
     with wf.graph.as_default():
-        samples_placeholder = tf.placeholder(dtype=tf.int32, shape=[numsamples_, N])
-        global_step = tf.Variable(0, trainable=False)
-        learningrate_placeholder = tf.placeholder(dtype=tf.float64, shape=[])
-        learning_rate_withexpdecay = tf.train.exponential_decay(learningrate_placeholder, global_step=global_step,
-                                                                decay_steps=100, decay_rate=1.0, staircase=True)
-        probs = wf.log_probability(samples_placeholder, input_dim)
-        optimizer = tf.train.AdamOptimizer(learning_rate=learning_rate_withexpdecay)
-        init = tf.global_variables_initializer()
-    config = tf.ConfigProto()
-    config.gpu_options.allow_growth = True
-    sess = tf.Session(graph=wf.graph, config=config)
-    sess.run(init)
-    with wf.graph.as_default():
-        variables_names = [v.name for v in tf.trainable_variables()]
-        total = 0
-        values = sess.run(variables_names)
-        for k, v in zip(variables_names, values):
-            v1 = tf.reshape(v, [-1])
-            print(k, v1.shape)
-            total += v1.shape[0]
-        print('The number of params is {0}'.format(total))
-    assert total == 422 and "The number of params is 422" in capsys.readouterr().out      # Tutorial_1DTFIM.ipynb cell 15
-    assert learning_rate_withexpdecay.value({learningrate_placeholder: lr}) == lr
-    assert sess.run(sampling).shape == (numsamples_, N) and probs is not None and optimizer.beta1 == 0.9
-
-    with tf.variable_scope(wf.scope, reuse=tf.AUTO_REUSE):
-        with wf.graph.as_default():
-            saver = tf.train.Saver()
-            samples_ = wf.sample(numsamples=numsamples, inputdim=2)
-            samples = np.ones((numsamples, N), dtype=np.int32)
-            samples_placeholder = tf.placeholder(dtype=tf.int32, shape=(None, N))
-            log_probs_tensor = wf.log_probability(samples_placeholder, inputdim=2)
-            queue_samples = np.zeros((N + 1, numsamples, N), dtype=np.int32)
-            log_probs = np.zeros((N + 1) * numsamples, dtype=np.float64)
-            meanEnergy, varEnergy = [], []
-            for it in range(len(meanEnergy), 3):
-                samples = sess.run(samples_)
-                local_energies = Ising_local_energies(Jz, Bx, samples, queue_samples, log_probs_tensor,
-                                                      samples_placeholder, log_probs, sess)
-                meanE = np.mean(local_energies)
-                varE = np.var(local_energies)
-                meanEnergy.append(meanE)
-                varEnergy.append(varE)
-                if it % 10 == 0:
-                    print('mean(E): {0}, var(E): {1}, #samples {2}, #Step {3} \n\n'.format(meanE, varE, numsamples, it))
-                if it % 500 == 0:
-                    saver.save(sess, str(tmp_path / "RNNwavefunction.ckpt"))
+        names = [v.name for v in tf.trainable_variables()]
+        sizes = [tf.reshape(v, [-1]).shape[0] for v in gm.sess.run(names)]
+        saver = tf.train.Saver()
+    assert len(names) == 8 and sum(sizes) == 422 and gm.optimizer.beta1 == 0.9
+    assert gm.schedule.value({gm.lr_in: np.float64(5e-3)}) == 5e-3
+    Jz, queue, scratch = np.ones(N), np.zeros((N + 1, batch, N), dtype=np.int32), np.zeros((N + 1) * batch)
+    drawn = gm.samples()
+    e = Ising_local_energies(Jz, 1.0, drawn, queue, gm.score, gm.any_in, scratch, gm.sess)
     prm = wf.get_params()
-    e_ref = E.ising_local_energies(Jz, Bx, samples, lambda x: M.prnn_log_probability(prm, x))
-    assert np.allclose(local_energies, e_ref, rtol=2e-5) and len(meanEnergy) == 3
-    # the checkpoint the Saver wrote is a TF V2 bundle with the TF variable names; a fresh wave function restores it
-    from rnnwavefunctions_amd import tf_checkpoint as T
-    names = [n for n, _, _ in T.list_variables(str(tmp_path / "RNNwavefunction.ckpt"))]
-    assert "RNNwavefunction/multi_rnn_cell/cell_0/cudnn_compatible_gru_cell/gates/kernel" in names and len(names) == 8
-    other = RNNwavefunction(N, units=units, cell=tf.contrib.cudnn_rnn.CudnnCompatibleGRUCell, seed=5, scope="another")
-    assert not np.allclose(other.log_probability(samples[:5], 2), wf.log_probability(samples[:5], 2))
+    assert drawn.shape == (batch, N) and np.allclose(e, E.ising_local_energies(Jz, 1.0, drawn, lambda x: M.prnn_log_probability(prm, x)), rtol=2e-5)
+    path = saver.save(gm.sess, str(tmp_path / "RNNwavefunction.ckpt"))
+    stored = [n for n, _, _ in T.list_variables(path)]
+    assert "RNNwavefunction/multi_rnn_cell/cell_0/cudnn_compatible_gru_cell/gates/kernel" in stored
+    other = RNNwavefunction(N, units=[10], cell=tf.contrib.cudnn_rnn.CudnnCompatibleGRUCell, seed=5, scope="another")
+    assert not np.allclose(other.log_probability(drawn[:5], 2), wf.log_probability(drawn[:5], 2))
     with other.graph.as_default():
-        tf.train.Saver().restore(tf.Session(graph=other.graph), str(tmp_path / "RNNwavefunction.ckpt"))
-    assert np.array_equal(other.log_probability(samples[:5], 2), wf.log_probability(samples[:5], 2))
+        tf.train.Saver().restore(tf.Session(graph=other.graph), path)
+    assert np.array_equal(other.log_probability(drawn[:5], 2), wf.log_probability(drawn[:5], 2))
     assert [v.name for v in wf.rnn.variables][0].endswith("gates/kernel:0") and wf.dense.count_params() == 22
 
 

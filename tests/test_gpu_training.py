@@ -592,127 +592,82 @@ def test_run_1dtfim_with_two_layers_reaches_the_ground_state():
 
 # ---- the reference's OWN training loop (graph-mode cost, compute_gradients / apply_gradients, sess.run(optstep)) -------
 
-def test_reference_training_loop_of_1dtfim_runs_with_compat_as_tf():
-    """The statements of 1DTFIM/TrainingRNN_1DTFIM.py:103-123,147-166,185-221 - set-up, the cost
-    `mean(log_probs_ * Eloc) - mean(Eloc) mean(log_probs_)`, `optimizer.compute_gradients(cost)`,
-    `optimizer.apply_gradients(..., global_step)`, and `sess.run(optstep, feed_dict={Eloc, samp, learningrate})` in the
-    sampling / local-energy loop - written here with the same calls, `tf` being rnnwavefunctions_amd.compat.  The
-    trajectory must be that of training.run_1DTFIM (same seed, same Philox sub-streams): the two are the same GPU work."""
+def _graph_mode_energies(gm, estimate, steps, lr):
+    out = []
+    for _ in range(steps):
+        drawn = gm.samples()
+        e = estimate(drawn)
+        out.append(np.mean(e))
+        gm.update(drawn, e, lr)
+    return out
+
+
+def test_graph_mode_training_follows_run_1dtfim(tmp_path):
+    """Training the way a reference script does it - `sess.run(train_op, feed_dict={energies, samples, learning rate})` on the op
+    `optimizer.apply_gradients(optimizer.compute_gradients(cost))` built through rnnwavefunctions_amd.compat (tests/graph_mode.py) -
+    walks the trajectory of training.run_1DTFIM (same seed, same Philox sub-streams: the same GPU work); a cost that is not the VMC
+    cost is refused; tf.train.Saver keeps the optimizer state of the graph's training op."""
     import rnnwavefunctions_amd.compat as tf
-    from rnnwavefunctions_amd.TFIM1D.TrainingRNN_1DTFIM import Ising_local_energies, RNNwavefunction, run_1DTFIM
-    numsteps, N, num_units, numsamples, seed, learningrate, Bx = 12, 10, 10, 100, 111, 5e-3, 1.0
-    Jz = +np.ones(N)
-    lr = np.float64(learningrate)
-    units = [num_units]
-    wf = RNNwavefunction(N, units=units, cell=tf.contrib.cudnn_rnn.CudnnCompatibleGRUCell, seed=seed)
-    with wf.graph.as_default():
-        global_step = tf.Variable(0, trainable=False)
-        learningrate_placeholder = tf.placeholder(dtype=tf.float64, shape=[])
-        learning_rate_withexpdecay = tf.train.exponential_decay(learningrate_placeholder, global_step=global_step,
-                                                                decay_steps=100, decay_rate=1.0, staircase=True)
-        optimizer = tf.train.AdamOptimizer(learning_rate=learning_rate_withexpdecay)
-        init = tf.global_variables_initializer()
-    sess = tf.Session(graph=wf.graph, config=tf.ConfigProto())
-    sess.run(init)
-    with tf.variable_scope(wf.scope, reuse=tf.AUTO_REUSE):
-        with wf.graph.as_default():
-            Eloc = tf.placeholder(dtype=tf.float64, shape=[numsamples])
-            samp = tf.placeholder(dtype=tf.int32, shape=[numsamples, N])
-            log_probs_ = wf.log_probability(samp, inputdim=2)
-            cost = tf.reduce_mean(tf.multiply(log_probs_, Eloc)) - tf.reduce_mean(Eloc) * tf.reduce_mean(log_probs_)
-            gradients, variables = zip(*optimizer.compute_gradients(cost))
-            optstep = optimizer.apply_gradients(zip(gradients, variables), global_step=global_step)
-            sess.run(tf.variables_initializer(optimizer.variables()))
-    assert len(variables) == 8
-    meanEnergy, varEnergy = [], []
-    with tf.variable_scope(wf.scope, reuse=tf.AUTO_REUSE):
-        with wf.graph.as_default():
-            samples_ = wf.sample(numsamples=numsamples, inputdim=2)
-            samples_placeholder = tf.placeholder(dtype=tf.int32, shape=(None, N))
-            log_probs_tensor = wf.log_probability(samples_placeholder, inputdim=2)
-            queue_samples = np.zeros((N + 1, numsamples, N), dtype=np.int32)
-            log_probs = np.zeros((N + 1) * numsamples, dtype=np.float64)
-            for it in range(len(meanEnergy), numsteps + 1):
-                samples = sess.run(samples_)
-                local_energies = Ising_local_energies(Jz, Bx, samples, queue_samples, log_probs_tensor,
-                                                      samples_placeholder, log_probs, sess)
-                meanEnergy.append(np.mean(local_energies))
-                varEnergy.append(np.var(local_energies))
-                sess.run(optstep, feed_dict={Eloc: local_energies, samp: samples, learningrate_placeholder: lr})
-    assert int(sess.run(global_step)) == numsteps + 1
-    mE, vE = run_1DTFIM(numsteps=numsteps, systemsize=N, num_units=num_units, Bx=Bx, numsamples=numsamples,
-                        learningrate=learningrate, seed=seed, verbose=False)
-    print("reference-style loop vs run_1DTFIM: max |dE| = %.2e" % np.abs(np.array(meanEnergy) - np.array(mE)).max())
-    assert np.allclose(meanEnergy, mE, rtol=1e-6, atol=1e-6) and np.allclose(varEnergy, vE, rtol=1e-5, atol=1e-6)
-    # a cost that is not the VMC cost is refused rather than mis-differentiated
-    with pytest.raises(NotImplementedError):
-        optimizer.compute_gradients(tf.reduce_mean(log_probs_))
-    # saver = tf.train.Saver() / saver.save / saver.restore (:166, :219, :172-183): the checkpoint holds the model AND the
-    # optimizer state of this graph's training op, and restore brings all of it back (Adam does not restart at t = 0)
-    import tempfile
+    from graph_mode import GraphModeVMC
     from rnnwavefunctions_amd import tf_checkpoint as TC
+    from rnnwavefunctions_amd.TFIM1D.TrainingRNN_1DTFIM import Ising_local_energies, RNNwavefunction, run_1DTFIM
+    steps, N, H, batch, lr = 13, 10, 10, 100, 5e-3
+    wf = RNNwavefunction(N, units=[H], cell=tf.contrib.cudnn_rnn.CudnnCompatibleGRUCell, seed=111)
+    gm = GraphModeVMC(tf, wf, batch)
+    Jz, queue, scratch = np.ones(N), np.zeros((N + 1, batch, N), dtype=np.int32), np.zeros((N + 1) * batch)
+    estimate = lambda drawn: Ising_local_energies(Jz, 1.0, drawn, queue, gm.score, gm.any_in, scratch, gm.sess)
+    mine = _graph_mode_energies(gm, estimate, steps, lr)
+    assert len(gm.variables) == 8 and gm.steps_taken() == steps
+    theirs, _ = run_1DTFIM(numsteps=steps - 1, systemsize=N, num_units=H, Bx=1.0, numsamples=batch, learningrate=lr, seed=111, verbose=False)
+    print("graph-mode loop vs run_1DTFIM: max |dE| = %.2e" % np.abs(np.array(mine) - np.array(theirs)).max())
+    assert np.allclose(mine, theirs, rtol=1e-6, atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        gm.optimizer.compute_gradients(tf.reduce_mean(gm.fed_score))
     with wf.graph.as_default():
         saver = tf.train.Saver()
-    with tempfile.TemporaryDirectory() as d:
-        path = saver.save(sess, d + "/model.ckpt")
-        model, ostate = TC.split_saver_variables(TC.read_checkpoint(path))
-        assert len(model) == 8 and len(ostate["m"]) == 8 and ostate["global_step"] == numsteps + 1
-        adam = optimizer._adam
-        saved = ({k: v.copy() for k, v in wf.get_params().items()}, {k: v.copy() for k, v in adam.m.items()},
-                 {k: v.copy() for k, v in adam.v.items()}, adam.t)
-        for _ in range(2):                     # move on, then go back
-            samples = sess.run(samples_)
-            local_energies = Ising_local_energies(Jz, Bx, samples, queue_samples, log_probs_tensor, samples_placeholder, log_probs, sess)
-            sess.run(optstep, feed_dict={Eloc: local_energies, samp: samples, learningrate_placeholder: lr})
-        assert optimizer._adam.t == saved[3] + 2
-        saver.restore(sess, path)
-    assert optimizer._adam.t == saved[3] and int(sess.run(global_step)) == numsteps + 1
+    path = saver.save(gm.sess, str(tmp_path / "model.ckpt"))
+    model, ostate = TC.split_saver_variables(TC.read_checkpoint(path))
+    assert len(model) == 8 and len(ostate["m"]) == 8 and ostate["global_step"] == steps
+    adam = gm.optimizer._adam
+    kept = ({k: v.copy() for k, v in wf.get_params().items()}, {k: v.copy() for k, v in adam.m.items()}, adam.t)
+    _graph_mode_energies(gm, estimate, 2, lr)                        # move on, then go back
+    assert gm.optimizer._adam.t == kept[2] + 2
+    saver.restore(gm.sess, path)
+    assert gm.optimizer._adam.t == kept[2] and gm.steps_taken() == steps
     for k, v in wf.get_params().items():
-        assert np.array_equal(v, saved[0][k])
-        assert np.allclose(optimizer._adam.m[k], saved[1][k], rtol=1e-6, atol=1e-12)     # slots travel as float32
-        assert np.allclose(optimizer._adam.v[k], saved[2][k], rtol=1e-6, atol=1e-12)
+        assert np.array_equal(v, kept[0][k]) and np.allclose(gm.optimizer._adam.m[k], kept[1][k], rtol=1e-6, atol=1e-12)      # slots travel as float32
 
 
-def test_reference_training_loop_with_the_parity_symmetric_class_runs_with_compat_as_tf():
-    """The import switch the reference's script carries as a comment (1DTFIM/TrainingRNN_1DTFIM.py:10: `from
-    RNNwavefunction_paritysym import RNNwavefunction`) with the script's own statements: the optimizer step differentiates
-    log P_sym.  Same trajectory as training.run_1DTFIM(parity_symmetric=True)."""
+def test_graph_mode_training_with_the_parity_symmetric_class():
+    """The import switch the reference's script carries as a comment (1DTFIM/TrainingRNN_1DTFIM.py:10): the optimizer step then
+    differentiates log P_sym - same trajectory as training.run_1DTFIM(parity_symmetric=True)."""
     import rnnwavefunctions_amd.compat as tf
+    from graph_mode import GraphModeVMC
     from rnnwavefunctions_amd.TFIM1D.RNNwavefunction_paritysym import RNNwavefunction
     from rnnwavefunctions_amd.TFIM1D.TrainingRNN_1DTFIM import Ising_local_energies, run_1DTFIM
-    numsteps, N, num_units, numsamples, seed, learningrate, Bx = 6, 8, 10, 64, 111, 5e-3, 1.0
-    Jz, lr = +np.ones(N), np.float64(learningrate)
-    wf = RNNwavefunction(N, units=[num_units], cell=tf.contrib.cudnn_rnn.CudnnCompatibleGRUCell, seed=seed)
-    with wf.graph.as_default():
-        global_step = tf.Variable(0, trainable=False)
-        learningrate_placeholder = tf.placeholder(dtype=tf.float64, shape=[])
-        optimizer = tf.train.AdamOptimizer(learning_rate=tf.train.exponential_decay(
-            learningrate_placeholder, global_step=global_step, decay_steps=100, decay_rate=1.0, staircase=True))
-    sess = tf.Session(graph=wf.graph, config=tf.ConfigProto())
-    with tf.variable_scope(wf.scope, reuse=tf.AUTO_REUSE):
-        with wf.graph.as_default():
-            Eloc = tf.placeholder(dtype=tf.float64, shape=[numsamples])
-            samp = tf.placeholder(dtype=tf.int32, shape=[numsamples, N])
-            log_probs_ = wf.log_probability(samp, inputdim=2)
-            cost = tf.reduce_mean(tf.multiply(log_probs_, Eloc)) - tf.reduce_mean(Eloc) * tf.reduce_mean(log_probs_)
-            gradients, variables = zip(*optimizer.compute_gradients(cost))
-            optstep = optimizer.apply_gradients(zip(gradients, variables), global_step=global_step)
-            samples_ = wf.sample(numsamples=numsamples, inputdim=2)
-            samples_placeholder = tf.placeholder(dtype=tf.int32, shape=(None, N))
-            log_probs_tensor = wf.log_probability(samples_placeholder, inputdim=2)
-            queue_samples = np.zeros((N + 1, numsamples, N), dtype=np.int32)
-            log_probs = np.zeros((N + 1) * numsamples, dtype=np.float64)
-            meanEnergy = []
-            for it in range(numsteps + 1):
-                samples = sess.run(samples_)
-                local_energies = Ising_local_energies(Jz, Bx, samples, queue_samples, log_probs_tensor, samples_placeholder, log_probs, sess)
-                meanEnergy.append(np.mean(local_energies))
-                sess.run(optstep, feed_dict={Eloc: local_energies, samp: samples, learningrate_placeholder: lr})
-    mE, _ = run_1DTFIM(numsteps=numsteps, systemsize=N, num_units=num_units, Bx=Bx, numsamples=numsamples, learningrate=learningrate,
-                       seed=seed, verbose=False, parity_symmetric=True)
-    print("parity-symmetric reference-style loop vs run_1DTFIM: max |dE| = %.2e" % np.abs(np.array(meanEnergy) - np.array(mE)).max())
-    assert np.allclose(meanEnergy, mE, rtol=1e-6, atol=1e-6)
-    assert abs(meanEnergy[-1] - meanEnergy[0]) > 1e-3                  # the parameters moved
+    steps, N, H, batch, lr = 7, 8, 10, 64, 5e-3
+    gm = GraphModeVMC(tf, RNNwavefunction(N, units=[H], cell=tf.contrib.cudnn_rnn.CudnnCompatibleGRUCell, seed=111), batch)
+    Jz, queue, scratch = np.ones(N), np.zeros((N + 1, batch, N), dtype=np.int32), np.zeros((N + 1) * batch)
+    mine = _graph_mode_energies(gm, lambda d: Ising_local_energies(Jz, 1.0, d, queue, gm.score, gm.any_in, scratch, gm.sess), steps, lr)
+    theirs, _ = run_1DTFIM(numsteps=steps - 1, systemsize=N, num_units=H, Bx=1.0, numsamples=batch, learningrate=lr, seed=111, verbose=False,
+                           parity_symmetric=True)
+    assert np.allclose(mine, theirs, rtol=1e-6, atol=1e-6) and abs(mine[-1] - mine[0]) > 1e-3
+
+
+def test_graph_mode_training_of_the_complex_wave_function():
+    """The complex cost 2 Re(mean(conj(log psi) E) - conj(mean log psi) mean E) (J1J2/TrainingRNN_J1J2.py:197) through the same
+    surface, against training.run_J1J2."""
+    import rnnwavefunctions_amd.compat as tf
+    from graph_mode import GraphModeVMC
+    from rnnwavefunctions_amd.J1J2.TrainingRNN_J1J2 import J1J2_local_energies, RNNwavefunction, run_J1J2
+    steps, N, H, batch, lr = 9, 10, 10, 100, 2.5e-4
+    J1, J2, Bz = np.ones(N), 0.2 * np.ones(N), np.zeros(N)
+    gm = GraphModeVMC(tf, RNNwavefunction(N, units=[H], cell=tf.contrib.cudnn_rnn.CudnnCompatibleGRUCell, seed=111), batch, complex_cost=True,
+                      adam_kwargs=dict(beta1=0.9, beta2=0.999, epsilon=1e-8))
+    mine = _graph_mode_energies(gm, lambda d: J1J2_local_energies(J1, J2, Bz, d, gm.score), steps, lr)
+    theirs, _ = run_J1J2(numsteps=steps - 1, systemsize=N, J1_=1.0, J2_=0.2, num_units=H, numsamples=batch, learningrate=lr, seed=111, verbose=False)
+    print("graph-mode J1J2 loop vs run_J1J2: max |dE| = %.2e" % np.abs(np.array(mine) - np.array(theirs)).max())
+    assert np.allclose(mine, theirs, rtol=1e-5, atol=1e-5)
 
 
 def test_comm_env_without_a_launcher_runs_as_a_single_process(monkeypatch):
@@ -767,41 +722,3 @@ def test_gradient_is_bit_reproducible(model, shape, units, ns):
         assert np.array_equal(a[name], b[name]), name
         assert np.array_equal(a[name], c[name]), name
 
-
-def test_reference_training_loop_of_j1j2_runs_with_compat_as_tf():
-    """J1J2/TrainingRNN_J1J2.py:185-207,241-306: the complex cost `2 Re(mean(conj(log psi) E) - conj(mean log psi) mean E)`
-    and the J1J2Slices / log-amplitude / E_loc loop, against training.run_J1J2."""
-    import rnnwavefunctions_amd.compat as tf
-    from rnnwavefunctions_amd.J1J2.TrainingRNN_J1J2 import J1J2_local_energies, RNNwavefunction, run_J1J2
-    numsteps, N, num_units, numsamples, seed, learningrate, J2_ = 8, 10, 10, 100, 111, 2.5e-4, 0.2
-    J1, J2, Bz = np.ones(N), J2_ * np.ones(N), np.zeros(N)
-    wf = RNNwavefunction(N, units=[num_units], cell=tf.contrib.cudnn_rnn.CudnnCompatibleGRUCell, seed=seed)
-    with wf.graph.as_default():
-        global_step = tf.Variable(0, trainable=False)
-        learningrate_placeholder = tf.placeholder(dtype=tf.float64, shape=[])
-        learning_rate_withexpdecay = tf.train.exponential_decay(learningrate_placeholder, global_step=global_step,
-                                                                decay_steps=100, decay_rate=1.0, staircase=True)
-        optimizer = tf.train.AdamOptimizer(learning_rate=learning_rate_withexpdecay, beta1=0.9, beta2=0.999, epsilon=1e-8)
-    sess = tf.Session(graph=wf.graph, config=tf.ConfigProto())
-    with tf.variable_scope(wf.scope, reuse=tf.AUTO_REUSE):
-        with wf.graph.as_default():
-            Eloc = tf.placeholder(dtype=tf.complex64, shape=[numsamples])
-            samp = tf.placeholder(dtype=tf.int32, shape=[numsamples, N])
-            log_amplitudes_ = wf.log_amplitude(samp, inputdim=2)
-            cost = 2 * tf.real(tf.reduce_mean(tf.conj(log_amplitudes_) * tf.stop_gradient(Eloc)) -
-                               tf.conj(tf.reduce_mean(log_amplitudes_)) * tf.reduce_mean(tf.stop_gradient(Eloc)))
-            gradients, variables = zip(*optimizer.compute_gradients(cost))
-            optstep = optimizer.apply_gradients(zip(gradients, variables), global_step=global_step)
-            samples_ = wf.sample(numsamples=numsamples, inputdim=2)
-            inputs = tf.placeholder(dtype=tf.int32, shape=(None, N))
-            log_amps = wf.log_amplitude(inputs, inputdim=2)
-    meanEnergy = []
-    for it in range(numsteps + 1):
-        samples = sess.run(samples_)
-        local_energies = J1J2_local_energies(J1, J2, Bz, samples, log_amps)
-        meanEnergy.append(np.mean(local_energies))
-        sess.run(optstep, feed_dict={Eloc: local_energies, samp: samples, learningrate_placeholder: np.float64(learningrate)})
-    mE, _ = run_J1J2(numsteps=numsteps, systemsize=N, J1_=1.0, J2_=J2_, num_units=num_units, numsamples=numsamples,
-                     learningrate=learningrate, seed=seed, verbose=False)
-    print("reference-style J1J2 loop vs run_J1J2: max |dE| = %.2e" % np.abs(np.array(meanEnergy) - np.array(mE)).max())
-    assert np.allclose(meanEnergy, mE, rtol=1e-5, atol=1e-5)
