@@ -197,8 +197,12 @@ inline int upload_reset(rnnwf_handle* h) {
 }
 inline int upload(rnnwf_handle* h, void* dst, const void* src, size_t bytes) {
     const size_t off = (h->upbuf_off + 255) & ~(size_t)255;
-    if (off + bytes > h->upbuf_cap) {                     // grow: wait for what is in flight, then start over in a larger buffer
-        RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+    if (off + bytes > h->upbuf_cap) {                     // full: wait for what is in flight, then start over - in the same buffer when the
+        RNNWF_HIP(h, hipStreamSynchronize(h->stream));    // image fits it (a caller that packs again and again without a commit in between, which
+        if (bytes <= h->upbuf_cap) {                      // alone resets the offset, must not double the buffer at every overflow), else a larger one
+            h->upbuf_off = 0;
+            return upload(h, dst, src, bytes);
+        }
         if (h->upbuf) RNNWF_HIP(h, hipHostFree(h->upbuf));
         h->upbuf = nullptr;
         h->upbuf_cap = 0;

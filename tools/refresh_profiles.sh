@@ -14,7 +14,7 @@ for w in cfg1 cfg2 cfg3 cfg4 cfg5; do
   echo "bench $w done"
 done
 # SURVEY 8 rows f4 / f1 "at speed": the parity-symmetric model, stacked layers, and the gradient leg (--train) of every config
-for w in cfg2_parity cfg2_l2 cfg2_l3; do
+for w in cfg2_parity cfg2_l2 cfg2_l3 cfg3_l2; do
   timeout -k 10 300 python bench.py --workload $w --steps 10 --warmup 2 --train 5 > $out/${tag}_bench_$w.json 2> $out/${tag}_bench_$w.err || { echo "bench $w failed"; exit 1; }
 done
 for w in cfg2 cfg3 cfg4 cfg5; do
@@ -24,7 +24,7 @@ for w in cfg2 cfg3; do
   RNNWF_ENGINE=f32 timeout -k 10 200 python bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline --no-alt-engine > $out/${tag}_bench_${w}_engine_f32.json 2>/dev/null || exit 1
 done
 cd /tmp && export TMPDIR=/tmp
-for w in cfg1 cfg2 cfg3 cfg4 cfg5 cfg2_parity cfg2_l2 cfg2_l3; do
+for w in cfg1 cfg2 cfg3 cfg4 cfg5 cfg2_parity cfg2_l2 cfg2_l3 cfg3_l2; do
   steps=10; [ $w = cfg5 ] && steps=4
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof_$w -- python3 $R/bench.py --workload $w --steps $steps --warmup 2 --train 3 --no-cpu-baseline --no-alt-engine --no-parity > $out/${tag}_prof_$w.log 2>&1 || { echo "rocprof $w failed"; exit 1; }
   cp $out/${tag}_prof_$w/*/*kernel_stats.csv $out/${tag}_kernel_stats_$w.csv
