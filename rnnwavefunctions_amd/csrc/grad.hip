@@ -195,13 +195,16 @@ struct MLGrad {
     static constexpr size_t DWU = (size_t)GU::PCOLS * GU::QCOLS;
     static constexpr size_t DW_FLOATS = DW0 + HEAD + (NL - 1) * DWU;       // [dW layer 0 | head | dW layer 1 | ...]
 
+    template <class S = double>
     static std::vector<char> pack_upper_bwd(const rnnwf_handle* h, int layer) {
+        using Out = PackSink<S>;
         const int H = h->H;
         std::vector<char> img(GU::BWD_BYTES, 0);
+        Out::begin(img);
         const std::string pre = "multi_rnn_cell/cell_" + std::to_string(layer) + "/cudnn_compatible_gru_cell/";
-        const auto& Wg = pv(h, pre + "gates/kernel");                         // [H + H, 2H]
-        const auto& Wci = pv(h, pre + "candidate/input_projection/kernel");   // [H, H]
-        const auto& Wch = pv(h, pre + "candidate/hidden_projection/kernel");  // [H, H]
+        const auto Wg = pvs<S>(h, pre + "gates/kernel");                         // [H + H, 2H]
+        const auto Wci = pvs<S>(h, pre + "candidate/input_projection/kernel");   // [H, H]
+        const auto Wch = pvs<S>(h, pre + "candidate/hidden_projection/kernel");  // [H, H]
         for (int side = 0; side < 2; ++side) {                                // 0: H side (-> dh), 1: X side (-> dx)
             T* A = reinterpret_cast<T*>(img.data() + side * GU::SIDE_BYTES);
             for (int t = 0; t < GU::NTO; ++t)
@@ -217,11 +220,12 @@ struct MLGrad {
                         for (int kk = 0; kk < GU::KB; ++kk) {
                             const int g = kk / GU::KT, kt = kk % GU::KT, u = 4 * kt + kq;
                             if (u >= H) continue;
-                            double w;
+                            S w;
                             if (g == 0) w = Wg[grow * 2 * H + u];
                             else if (g == 1) w = Wg[grow * 2 * H + H + u];
-                            else w = side == 0 ? Wch[(size_t)kout * H + u] : Wci[(size_t)kout * H + u];
-                            A[(((size_t)t * GU::KBG + kk / GU::VW) * 64 + lane) * GU::VW + (kk % GU::VW)] = (T)w;
+                            else if (side == 0) w = Wch[(size_t)kout * H + u];
+                            else w = Wci[(size_t)kout * H + u];
+                            Out::put(&A[(((size_t)t * GU::KBG + kk / GU::VW) * 64 + lane) * GU::VW + (kk % GU::VW)], w);
                         }
                     }
                 }
@@ -232,10 +236,37 @@ struct MLGrad {
     static std::vector<char> pack_all(const rnnwf_handle* h) {
         std::vector<char> img = G0::template pack_bwd<double>(h);
         for (int l = 1; l < NL; ++l) {
-            const std::vector<char> up = pack_upper_bwd(h, l);
+            const std::vector<char> up = pack_upper_bwd<double>(h, l);
             img.insert(img.end(), up.begin(), up.end());
         }
         return img;
+    }
+    // the same images once more over Lin: the table of the whole backward buffer (pack_value.h; the active PackTrace's shift moves along)
+    static void pack_all_table(const rnnwf_handle* h) {
+        const size_t base = pack_trace().shift;
+        G0::template pack_bwd<Lin>(h);
+        for (int l = 1; l < NL; ++l) {
+            pack_trace().shift = base + G0::G::BWD_BYTES + (size_t)(l - 1) * GU::BWD_BYTES;
+            pack_upper_bwd<Lin>(h, l);
+        }
+        pack_trace().shift = base;
+    }
+    // and of the forward buffer [layer 0 | upper layers]
+    static void pack_forward_table(const rnnwf_handle* h) {
+        const size_t base = pack_trace().shift;
+        pack_gru_image<T, NFULL, NOUT, Lin>(h);
+        for (int l = 1; l < NL; ++l) {
+            pack_trace().shift = base + L0::BYTES + (size_t)(l - 1) * U::BYTES;
+            pack_upper_image<NFULL, T, Lin>(h, l);
+        }
+        pack_trace().shift = base;
+    }
+    static void probe_unpack(rnnwf_handle* h, size_t* count) {
+        std::vector<T> img(DW_FLOATS);
+        for (size_t k = 0; k < DW_FLOATS; ++k) img[k] = (T)(k + 1);
+        G0::unpack(h, img.data(), DW0);
+        for (int l = 1; l < NL; ++l) unpack_upper(h, img.data() + DW0 + HEAD + (size_t)(l - 1) * DWU, l);
+        *count = DW_FLOATS;
     }
 
     template <bool TOP>
@@ -268,9 +299,21 @@ struct MLGrad {
     }
 
     static int run(rnnwf_handle* h, double mean_energy, double mean_energy_im, double norm) {
+        if (int rc = run_device(h, mean_energy, mean_energy_im, norm, nullptr)) return rc;
+        if (int rc = ensure_staging(h, DW_FLOATS * ES)) return rc;
+        const T* host = (const T*)h->staging;
+        RNNWF_HIP(h, hipMemcpyAsync(h->staging, h->gradW.p, DW_FLOATS * ES, hipMemcpyDeviceToHost, h->stream));
+        RNNWF_HIP(h, hipStreamSynchronize(h->stream));
+        G0::unpack(h, host, DW0);                              // layer 0 + head (written by the top layer's pass)
+        for (int l = 1; l < NL; ++l) unpack_upper(h, host + DW0 + HEAD + (size_t)(l - 1) * DWU, l);
+        return RNNWF_OK;
+    }
+
+    // every kernel of the stacked gradient, result left in h->gradW; mom_dev != nullptr: device-resident training (grad_single_layer_device)
+    static int run_device(rnnwf_handle* h, double mean_energy, double mean_energy_im, double norm, const double* mom_dev) {
         const int N = h->N;
         const int64_t ns = h->last_ns, R = ns * N, nsb = (ns + kChains - 1) / kChains;
-        const double inv_norm = (NOUT == 3 ? 2.0 : 1.0) / norm;     // the complex cost carries a factor 2 (TrainingRNN_J1J2.py:197)
+        const double inv_norm = mom_dev ? (NOUT == 3 ? 2.0 : 1.0) : (NOUT == 3 ? 2.0 : 1.0) / norm;     // the complex cost carries a factor 2 (TrainingRNN_J1J2.py:197)
         const bool parity = h->model == RNNWF_MODEL_GRU1D_PARITY;
         if (!h->wbwd_valid) {
             const std::vector<char> img = pack_all(h);
@@ -295,24 +338,19 @@ struct MLGrad {
                 if (int rc = prnn_teacher_base(h, ns, false, lpF)) return rc;
                 if (int rc = prnn_teacher_base(h, ns, true, lpR)) return rc;
                 if (int rc = run_parity_share(h, lpF, lpR, ns)) return rc;
-                if (int rc = passes(h, mean_energy, mean_energy_im, inv_norm, (const uint32_t*)h->bits2.p, lpR)) return rc;
+                if (int rc = passes(h, mean_energy, mean_energy_im, inv_norm, (const uint32_t*)h->bits2.p, lpR, mom_dev)) return rc;
                 if (int rc = prnn_teacher_base(h, ns, false, nullptr)) return rc;
-                if (int rc = passes(h, mean_energy, mean_energy_im, inv_norm, (const uint32_t*)h->bits.p, lpF)) return rc;
+                if (int rc = passes(h, mean_energy, mean_energy_im, inv_norm, (const uint32_t*)h->bits.p, lpF, mom_dev)) return rc;
             }
         } else {
-            if (int rc = passes(h, mean_energy, mean_energy_im, inv_norm, (const uint32_t*)h->bits.p, nullptr)) return rc;
+            if (int rc = passes(h, mean_energy, mean_energy_im, inv_norm, (const uint32_t*)h->bits.p, nullptr, mom_dev)) return rc;
         }
-        if (int rc = ensure_staging(h, DW_FLOATS * ES)) return rc;
-        const T* host = (const T*)h->staging;
-        RNNWF_HIP(h, hipMemcpyAsync(h->staging, h->gradW.p, DW_FLOATS * ES, hipMemcpyDeviceToHost, h->stream));
-        RNNWF_HIP(h, hipStreamSynchronize(h->stream));
-        G0::unpack(h, host, DW0);                              // layer 0 + head (written by the top layer's pass)
-        for (int l = 1; l < NL; ++l) unpack_upper(h, host + DW0 + HEAD + (size_t)(l - 1) * DWU, l);
         return RNNWF_OK;
     }
 
     // one backward pass per layer, top first, over the resident checkpoints of the chains in `bits`; everything is ADDED to gradW
-    static int passes(rnnwf_handle* h, double mean_energy, double mean_energy_im, double inv_norm, const uint32_t* bits, const double* wfac) {
+    static int passes(rnnwf_handle* h, double mean_energy, double mean_energy_im, double inv_norm, const uint32_t* bits, const double* wfac,
+                      const double* mom_dev) {
         const int N = h->N;
         const int64_t ns = h->last_ns, R = ns * N, nsb = (ns + kChains - 1) / kChains;
         T* dW = (T*)h->gradW.p;
@@ -333,6 +371,7 @@ struct MLGrad {
             a.mean_e = mean_energy;
             a.mean_im = mean_energy_im;
             a.inv_norm = inv_norm;
+            a.mom = mom_dev;
             a.dh_in = dh_in;
             a.dx_out = h->gradDX[(NL - 1 - l) & 1].p;
             a.P = h->gradP.p;
@@ -354,6 +393,7 @@ struct MLGrad {
         a.mean_e = mean_energy;
         a.mean_im = mean_energy_im;
         a.inv_norm = inv_norm;
+        a.mom = mom_dev;
         a.P = h->gradP.p;
         a.Q = h->gradQ.p;
         a.head_grad = dW + DW_FLOATS;          // scratch rows: layer 0 has no head term here (its adds are zeros)
@@ -480,6 +520,13 @@ extern "C" int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double me
 // and norm come from the step's moments on the device (mean_energy / norm arguments unused) and nothing visits the host.
 int rnnwf::grad_single_layer_device(rnnwf_handle* h, double mean_energy, double mean_energy_im, double norm, const double* mom_dev,
                                     size_t* dw_count) {
+    if (h->NL != 1) {                       // stacked layers: one backward pass per layer, top first (MLGrad)
+        if (h->last_ns <= 0 || !h->last_has_ckpt)
+            return h->fail(RNNWF_ERR_STATE, "rnnwf_vmc_gradient: call rnnwf_vmc_step first (its samples, states and E_loc are reused)");
+        RNNWF_HIP(h, hipSetDevice(h->cfg.device));
+        MLGRAD_DISPATCH(h, { if (dw_count) *dw_count = K::DW_FLOATS; return K::run_device(h, mean_energy, mean_energy_im, norm, mom_dev); });
+        return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: no stacked-layer kernel for this width");
+    }
     const bool parity = h->model == RNNWF_MODEL_GRU1D_PARITY;
     const bool cplx = h->model == RNNWF_MODEL_CRNN_U1;
     const bool f64 = h->model == RNNWF_MODEL_GRU1D_F64;
@@ -545,8 +592,17 @@ int rnnwf::grad_single_layer_device(rnnwf_handle* h, double mean_energy, double 
 }
 
 // ---- what train.hip needs from this translation unit (the layouts live in its anonymous namespace) -------------------------
+// table of a stack's forward buffer [layer 0 | upper layers] into the active PackTrace
+int rnnwf::grad_stack_forward_table(rnnwf_handle* h) {
+    MLGRAD_DISPATCH(h, { K::pack_forward_table(h); return 0; });
+    return h->fail(RNNWF_ERR_INVALID, "no stacked-layer layout for NFULL=%d", h->NFULL);
+}
 // table of the backward image (pack_value.h) into the active PackTrace
 int rnnwf::grad_bwd_pack_table(rnnwf_handle* h) {
+    if (h->NL != 1) {
+        MLGRAD_DISPATCH(h, { K::pack_all_table(h); return 0; });
+        return h->fail(RNNWF_ERR_INVALID, "no stacked-layer gradient for NFULL=%d", h->NFULL);
+    }
     GRAD_DISPATCH(h, { K::template pack_bwd<Lin>(h); return 0; });
     return h->fail(RNNWF_ERR_INVALID, "no gradient kernel for NFULL=%d", h->NFULL);
 }
@@ -556,11 +612,19 @@ int rnnwf::grad_flat_probe(rnnwf_handle* h, std::vector<int32_t>& sidx, size_t* 
     const bool cplx = h->model == RNNWF_MODEL_CRNN_U1;
     const bool f64 = h->model == RNNWF_MODEL_GRU1D_F64;
     int pcols = 0, qcols = 0, hgn = 0;
-    GRAD_DISPATCH(h, { pcols = K::G::PCOLS; qcols = K::G::QCOLS; hgn = K::G::HEAD_ROW * (cplx ? 3 : 1); break; });
-    const size_t n = (size_t)pcols * qcols + hgn;
-    if (n == 0 || n >= ((size_t)1 << 24)) return h->fail(RNNWF_ERR_INVALID, "gradient image of %zu elements cannot be probed", n);
+    size_t n = 0;
     const auto saved = h->grads;
-    if (f64) {
+    if (h->NL != 1) {
+        bool done = false;
+        MLGRAD_DISPATCH(h, { if (K::DW_FLOATS < ((size_t)1 << 24)) { K::probe_unpack(h, &n); done = true; } break; });
+        if (!done) return h->fail(RNNWF_ERR_INVALID, "stacked gradient image cannot be probed");
+    } else {
+    GRAD_DISPATCH(h, { pcols = K::G::PCOLS; qcols = K::G::QCOLS; hgn = K::G::HEAD_ROW * (cplx ? 3 : 1); break; });
+    n = (size_t)pcols * qcols + hgn;
+    if (n == 0 || n >= ((size_t)1 << 24)) return h->fail(RNNWF_ERR_INVALID, "gradient image of %zu elements cannot be probed", n);
+    }
+    if (h->NL != 1) {
+    } else if (f64) {
         std::vector<double> img(n);
         for (size_t k = 0; k < n; ++k) img[k] = (double)(k + 1);
         GRAD_DISPATCH(h, { K::unpack(h, img.data(), (size_t)pcols * qcols); break; });

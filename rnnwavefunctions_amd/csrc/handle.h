@@ -53,7 +53,7 @@ struct TrainState {
     int64_t nparams = 0;
     size_t dw_count = 0;
     bool dw_f64 = false;
-    TrainImage img[5];
+    TrainImage img[8];
     int nimg = 0;
     int64_t adam_t = 0;           // updates applied so far (tf.train.AdamOptimizer's beta powers are beta^(t+1))
     bool host_newer = true;       // the host copy of the parameters changed since the device copy was made

@@ -44,6 +44,7 @@ struct UpperGradArgs {
     const double* eloc;        // [ns] f64 (positive RNN) ...
     const float2* eloc_c;      // ... or [ns] complex64 (complex RNN)
     double mean_e, mean_im, inv_norm;
+    const double* mom;         // device-resident training: the step's moments on the device (grad_kernels.h: GradArgs::mom), nullptr: the fields above
     const double* wfac;        // [ns] extra factor of w_s or nullptr (parity-symmetric model: the direction's share of P_sym)
     const void* dh_in;         // [N][nsb][KT][64] T from the layer above (nullptr: top layer, head)
     void* dx_out;              // [N][nsb][KT][64] T
@@ -114,12 +115,14 @@ __global__ void __launch_bounds__(WAVES * 64) gru_upper_bwd_kernel(UpperGradArgs
         const int64_t sc = valid ? s : a.ns - 1;
         T w = T(0), w_im = T(0);
         if (TOP && valid) {
+            const double mean_e = a.mom ? a.mom[0] / a.mom[2] : a.mean_e, mean_im = a.mom ? a.mom[3] / a.mom[2] : a.mean_im;
+            const double inv_norm = a.mom ? a.inv_norm / a.mom[2] : a.inv_norm;
             if constexpr (NOUT == 1) {
-                w = (T)((a.eloc[sc] - a.mean_e) * a.inv_norm * (a.wfac ? a.wfac[sc] : 1.0));
+                w = (T)((a.eloc[sc] - mean_e) * inv_norm * (a.wfac ? a.wfac[sc] : 1.0));
             } else {
                 const float2 e = a.eloc_c[sc];
-                w = (T)(((double)e.x - a.mean_e) * a.inv_norm);
-                w_im = (T)(((double)e.y - a.mean_im) * a.inv_norm);
+                w = (T)(((double)e.x - mean_e) * inv_norm);
+                w_im = (T)(((double)e.y - mean_im) * inv_norm);
             }
         }
         auto spin = [&](int n) { return (int)((a.bits[(int64_t)(n >> 5) * a.ns + sc] >> (n & 31)) & 1); };

@@ -96,6 +96,7 @@ int mdrnn_load_batch(rnnwf_handle* h, const int32_t* samples, int64_t ns);
 int mdrnn_vmc_gradient(rnnwf_handle* h, double mean_energy, double norm);
 int grad_single_layer_device(rnnwf_handle* h, double mean_energy, double mean_energy_im, double norm, const double* mom_dev, size_t* dw_count);
 int grad_bwd_pack_table(rnnwf_handle* h);
+int grad_stack_forward_table(rnnwf_handle* h);
 int grad_flat_probe(rnnwf_handle* h, std::vector<int32_t>& sidx, size_t* dw_count, bool* is_f64);
 // ---- device-resident training (train.hip) ------------------------------------------------------------
 void train_params_changed_on_host(rnnwf_handle* h);           // rnnwf_set_param / rnnwf_commit_params: the device copy is stale

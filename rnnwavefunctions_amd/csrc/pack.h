@@ -143,18 +143,20 @@ inline void fill_f64_tables(double* t) {
 }
 
 // Image of GRU layer `layer` >= 1 (input = state of the layer below, dimension H), UpperLayout<NFULL, T>.
-template <int NFULL, typename T = float>
+template <int NFULL, typename T = float, class S = double>
 std::vector<char> pack_upper_image(const rnnwf_handle* h, int layer) {
     using U = UpperLayout<NFULL, T>;
+    using Out = PackSink<S>;
     const int H = h->H;
     std::vector<char> img(U::BYTES, 0);
+    Out::begin(img);
     const std::string pre = "multi_rnn_cell/cell_" + std::to_string(layer) + "/cudnn_compatible_gru_cell/";
-    const auto& Wg = pv(h, pre + "gates/kernel");                         // [H + H, 2H]: input rows first, cols r | u
-    const auto& bg = pv(h, pre + "gates/bias");
-    const auto& Wci = pv(h, pre + "candidate/input_projection/kernel");   // [H, H]
-    const auto& bci = pv(h, pre + "candidate/input_projection/bias");
-    const auto& Wch = pv(h, pre + "candidate/hidden_projection/kernel");  // [H, H]
-    const auto& bch = pv(h, pre + "candidate/hidden_projection/bias");
+    const auto Wg = pvs<S>(h, pre + "gates/kernel");                         // [H + H, 2H]: input rows first, cols r | u
+    const auto bg = pvs<S>(h, pre + "gates/bias");
+    const auto Wci = pvs<S>(h, pre + "candidate/input_projection/kernel");   // [H, H]
+    const auto bci = pvs<S>(h, pre + "candidate/input_projection/bias");
+    const auto Wch = pvs<S>(h, pre + "candidate/hidden_projection/kernel");  // [H, H]
+    const auto bch = pvs<S>(h, pre + "candidate/hidden_projection/bias");
     const double sg = PackScale<T>::gate, sc = PackScale<T>::cand;
     // gate ids: 0 r, 1 u, 2 q (hidden candidate), 3 y (input candidate)
     auto decode = [&](bool xblock, int tile, int q, int r, int& gate, int& unit) -> bool {
@@ -169,8 +171,8 @@ std::vector<char> pack_upper_image(const rnnwf_handle* h, int layer) {
         }
         return unit < H;
     };
-    auto wt = [&](bool xblock, int gate, int unit, int k) -> double {
-        if (k >= H) return 0.0;
+    auto wt = [&](bool xblock, int gate, int unit, int k) -> S {
+        if (k >= H) return S(0.0);
         const size_t row = xblock ? k : H + k;
         if (gate == 0) return sg * Wg[row * 2 * H + unit];
         if (gate == 1) return sg * Wg[row * 2 * H + H + unit];
@@ -190,8 +192,8 @@ std::vector<char> pack_upper_image(const rnnwf_handle* h, int layer) {
                     const int lane = (kq << 4) | row;
                     for (int g = 0; g < U::NG; ++g)
                         for (int j = 0; j < U::VW; ++j)
-                            avec[(((size_t)tile * U::NG + g) * 64 + lane) * U::VW + j] = (T)wt(xb, gate, unit, 4 * (g * U::VW + j) + kq);
-                    arem[(size_t)tile * 64 + lane] = (T)wt(xb, gate, unit, 4 * (U::KT - 1) + kq);
+                            Out::put(&avec[(((size_t)tile * U::NG + g) * 64 + lane) * U::VW + j], wt(xb, gate, unit, 4 * (g * U::VW + j) + kq));
+                    Out::put(&arem[(size_t)tile * 64 + lane], wt(xb, gate, unit, 4 * (U::KT - 1) + kq));
                 }
             }
     }
@@ -202,8 +204,12 @@ std::vector<char> pack_upper_image(const rnnwf_handle* h, int layer) {
                 const int gate = t < 4 * NFULL ? t / NFULL : r;
                 const int unit = t < 4 * NFULL ? 16 * (t % NFULL) + 4 * r + q : 16 * NFULL + q;
                 if (unit >= H) continue;
-                const double v = gate == 0 ? sg * bg[unit] : gate == 1 ? sg * bg[H + unit] : gate == 2 ? sc * bch[unit] : sc * bci[unit];
-                b[t * 16 + q * 4 + r] = (T)v;
+                S v;
+                if (gate == 0) v = sg * bg[unit];
+                else if (gate == 1) v = sg * bg[H + unit];
+                else if (gate == 2) v = sc * bch[unit];
+                else v = sc * bci[unit];
+                Out::put(&b[t * 16 + q * 4 + r], v);
             }
     return img;
 }

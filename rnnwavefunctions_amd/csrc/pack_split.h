@@ -352,27 +352,32 @@ std::vector<char> pack_split_image(const rnnwf_handle* h) {
 // Image of GRU layer `layer` >= 1 on the bf16x3 engine (split_core.h: SplitUpperLayout): the X block (input = state of the layer
 // below) and the H block, each laid out as the MODE 2 image of the first layer, the biases as accumulator start values, and - for
 // the top layer - the head rows in the H block's spare mixed-tile slots plus the VALU head's tables.
-template <int NF32, int RJ, int NOUT>
+template <int NF32, int RJ, int NOUT, class S = double>
 std::vector<char> pack_split_upper_image(const rnnwf_handle* h, int layer, bool top) {
     using U = SplitUpperLayout<NF32, RJ, NOUT>;
     using L = typename U::L0;
+    using Out = PackSink<S>;
     const int H = h->H;
     std::vector<char> img(U::BYTES, 0);
+    Out::begin(img);
     const std::string pre = "multi_rnn_cell/cell_" + std::to_string(layer) + "/cudnn_compatible_gru_cell/";
-    const auto& Wg = pv(h, pre + "gates/kernel");                         // [H + H, 2H]: input rows first, cols r | u
-    const auto& bg = pv(h, pre + "gates/bias");
-    const auto& Wci = pv(h, pre + "candidate/input_projection/kernel");   // [H, H]
-    const auto& bci = pv(h, pre + "candidate/input_projection/bias");
-    const auto& Wch = pv(h, pre + "candidate/hidden_projection/kernel");  // [H, H]
-    const auto& bch = pv(h, pre + "candidate/hidden_projection/bias");
-    const auto& Wd = pv(h, NOUT == 1 ? "wf_dense/kernel" : "wf_dense_ampl/kernel");
-    const auto& bd = pv(h, NOUT == 1 ? "wf_dense/bias" : "wf_dense_ampl/bias");
+    const auto Wg = pvs<S>(h, pre + "gates/kernel");                         // [H + H, 2H]: input rows first, cols r | u
+    const auto bg = pvs<S>(h, pre + "gates/bias");
+    const auto Wci = pvs<S>(h, pre + "candidate/input_projection/kernel");   // [H, H]
+    const auto bci = pvs<S>(h, pre + "candidate/input_projection/bias");
+    const auto Wch = pvs<S>(h, pre + "candidate/hidden_projection/kernel");  // [H, H]
+    const auto bch = pvs<S>(h, pre + "candidate/hidden_projection/bias");
+    const auto Wd = pvs<S>(h, NOUT == 1 ? "wf_dense/kernel" : "wf_dense_ampl/kernel");
+    const auto bd = pvs<S>(h, NOUT == 1 ? "wf_dense/bias" : "wf_dense_ampl/bias");
     const double sg = PackScale<float>::gate, sc = PackScale<float>::cand;
-    auto head_w = [&](int o, int ui) -> double {
+    auto head_w = [&](int o, int ui) -> S {
         if (o == 0) return Wd[(size_t)ui * 2 + 1] - Wd[(size_t)ui * 2];
-        return pv(h, "wf_dense_phase/kernel")[(size_t)ui * 2 + (o - 1)];
+        return pvs<S>(h, "wf_dense_phase/kernel")[(size_t)ui * 2 + (o - 1)];
     };
-    auto head_b = [&](int o) -> double { return o == 0 ? bd[1] - bd[0] : pv(h, "wf_dense_phase/bias")[o - 1]; };
+    auto head_b = [&](int o) -> S {
+        if (o == 0) return bd[1] - bd[0];
+        return pvs<S>(h, "wf_dense_phase/bias")[o - 1];
+    };
     for (int blk = 0; blk < 2; ++blk) {
         const bool xb = blk == 0;
         uint16_t* A = reinterpret_cast<uint16_t*>(img.data() + (xb ? U::OFF_AX : U::OFF_AH));
@@ -391,34 +396,35 @@ std::vector<char> pack_split_upper_image(const rnnwf_handle* h, int layer, bool 
                     else if (!xb && top && sl < L::HEAD_SLOT + NOUT) { g = 3 + (sl - L::HEAD_SLOT); uo = 0; }
                 }
                 if (g < 0 || uo >= H) continue;
-                auto weight = [&](int ui) -> double {          // (scaled) weight from input unit ui into row (g, uo)
-                    if (ui >= H) return 0.0;
+                auto weight = [&](int ui) -> S {               // (scaled) weight from input unit ui into row (g, uo)
+                    if (ui >= H) return S(0.0);
                     const size_t row = xb ? (size_t)ui : (size_t)(H + ui);
-                    return g == 0 ? sg * Wg[row * 2 * H + uo]
-                         : g == 1 ? sg * Wg[row * 2 * H + H + uo]
-                         : g == 2 ? sc * (xb ? Wci[(size_t)ui * H + uo] : Wch[(size_t)ui * H + uo])
-                                  : head_w(g - 3, ui);
+                    if (g == 0) return sg * Wg[row * 2 * H + uo];
+                    if (g == 1) return sg * Wg[row * 2 * H + H + uo];
+                    if (g == 2) return xb ? sc * Wci[(size_t)ui * H + uo] : sc * Wch[(size_t)ui * H + uo];
+                    return head_w(g - 3, ui);
                 };
                 {   // special unit of K half hhk: parts {w1, w1, w1, w2, w2, w3} against the B entries {h1, h2, h3, h1, h2, h1}
-                    uint16_t p[3];
-                    split3(weight(L::unit_of(L::NU - 1, hhk)), p);
+                    const S ws = weight(L::unit_of(L::NU - 1, hhk));
                     const int part[6] = {0, 0, 0, 1, 1, 2};
-                    for (int jj = 0; jj < 6; ++jj) ASP[((size_t)T * 64 + lane) * 8 + jj] = p[part[jj]];
+                    for (int jj = 0; jj < 6; ++jj) Out::put_part(&ASP[((size_t)T * 64 + lane) * 8 + jj], ws, part[jj]);
                     // K entries 6, 7 of both halves meet the constant 1.0: the three parts of the row's bias.  The r / u biases enter
                     // once, through the X block; the H block carries the candidate's hidden bias and the head biases.
-                    const double bias = g == 0 ? (xb ? sg * bg[uo] : 0.0) : g == 1 ? (xb ? sg * bg[H + uo] : 0.0)
-                                      : g == 2 ? sc * (xb ? bci[uo] : bch[uo]) : head_b(g - 3);
-                    uint16_t b[3];
-                    split3(bias, b);
-                    ASP[((size_t)T * 64 + lane) * 8 + 6] = hhk == 0 ? b[0] : b[2];
-                    ASP[((size_t)T * 64 + lane) * 8 + 7] = hhk == 0 ? b[1] : (uint16_t)0;
+                    S bias = S(0.0);
+                    if (g == 0) { if (xb) bias = sg * bg[uo]; }
+                    else if (g == 1) { if (xb) bias = sg * bg[H + uo]; }
+                    else if (g == 2) bias = xb ? sc * bci[uo] : sc * bch[uo];
+                    else bias = head_b(g - 3);
+                    uint16_t* b6 = &ASP[((size_t)T * 64 + lane) * 8 + 6];
+                    uint16_t* b7 = &ASP[((size_t)T * 64 + lane) * 8 + 7];
+                    if (hhk == 0) { Out::put_part(b6, bias, 0); Out::put_part(b7, bias, 1); }
+                    else { Out::put_part(b6, bias, 2); }
                 }
                 for (int x = 0; x < L::NQ; ++x)
                     for (int jj = 0; jj < 8; ++jj) {
                         const int e = 8 * x + jj;
-                        uint16_t p[3];
-                        split3(e < L::NUA ? weight(L::unit_of(e, hhk)) : 0.0, p);
-                        for (int a = 0; a < 3; ++a) A[((((size_t)T * 3 + a) * L::NQ + x) * 64 + lane) * 8 + jj] = p[a];
+                        auto at = [&](int a) { return &A[((((size_t)T * 3 + a) * L::NQ + x) * 64 + lane) * 8 + jj]; };
+                        Out::put_parts(at(0), at(1), at(2), e < L::NUA ? weight(L::unit_of(e, hhk)) : S(0.0));
                     }
             }
     }
@@ -429,9 +435,9 @@ std::vector<char> pack_split_upper_image(const rnnwf_handle* h, int layer, bool 
             for (int e = 0; e < L::NU; ++e) {
                 const int u = L::unit_of(e, hh);
                 if (u >= H) continue;
-                for (int o = 0; o < NOUT; ++o) WD[((size_t)hh * L::NUP + e) * NOUT + o] = (float)head_w(o, u);
+                for (int o = 0; o < NOUT; ++o) Out::put(&WD[((size_t)hh * L::NUP + e) * NOUT + o], head_w(o, u));
             }
-        for (int o = 0; o < NOUT; ++o) BD[o] = (float)head_b(o);
+        for (int o = 0; o < NOUT; ++o) Out::put(&BD[o], head_b(o));
     }
     return img;
 }

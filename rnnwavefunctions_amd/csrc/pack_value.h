@@ -10,6 +10,7 @@
 //              Because it is the packer's own arithmetic that is recorded (same operation order: t = P[a] +- P[b] in double, then
 //              c * t, then the conversion), the replayed image equals the host-packed one bit for bit (tests/test_gpu_training.py).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -90,6 +91,8 @@ enum { PACK_F32 = 0, PACK_F64 = 1, PACK_BF16 = 2, PACK_MINUS = 256 };
 struct PackTrace {
     const char* base = nullptr;
     PackTable* table = nullptr;
+    size_t shift = 0;            // where the image being packed starts inside the device buffer the table rebuilds (stacked layers: one
+                                 // buffer holds the images of all layers, one after the other)
 };
 inline PackTrace& pack_trace() {
     static thread_local PackTrace t;
@@ -114,13 +117,13 @@ template <> struct PackSink<double> {
 template <> struct PackSink<Lin> {
     static void begin(const std::vector<char>& img) {
         pack_trace().base = img.data();
-        if (pack_trace().table) pack_trace().table->image_bytes = img.size();
+        if (pack_trace().table) pack_trace().table->image_bytes = std::max(pack_trace().table->image_bytes, pack_trace().shift + img.size());
     }
     static void record(const void* dst, const Lin& x, int kind) {
         PackTrace& t = pack_trace();
         if (!t.table || x.a < 0) return;                      // constants stay what the host-packed image holds
         PackEntry e;
-        e.off = (uint32_t)((const char*)dst - t.base);
+        e.off = (uint32_t)((const char*)dst - t.base + t.shift);
         e.a = x.a; e.b = x.b;
         e.kind = kind | (x.b >= 0 && x.s < 0 ? PACK_MINUS : 0);
         e.c = x.c;

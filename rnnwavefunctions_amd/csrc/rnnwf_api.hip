@@ -243,7 +243,8 @@ extern "C" int rnnwf_destroy(rnnwf_handle* h) {
                       &h->tile_count, &h->cbase, &h->cout, &h->rowbuf, &h->wbwd, &h->gradP, &h->gradQ, &h->gradW, &h->gradPart, &h->gradHeadPart, &h->wsplit, &h->wsplit16, &h->wbasebf, &h->gradDX[0], &h->gradDX[1], &h->reduce_scratch,
                       &h->xrec[0], &h->xrec[1], &h->wsplit_up[0], &h->wsplit_up[1], &h->wsplit_up[2],
                       &h->train.P, &h->train.M, &h->train.V, &h->train.G, &h->train.gidx, &h->train.img[0].table, &h->train.img[1].table,
-                      &h->train.img[2].table, &h->train.img[3].table, &h->train.img[4].table};
+                      &h->train.img[2].table, &h->train.img[3].table, &h->train.img[4].table, &h->train.img[5].table, &h->train.img[6].table,
+                      &h->train.img[7].table};
     static_assert(RNNWF_MAX_LAYERS == 4, "wsplit_up has RNNWF_MAX_LAYERS - 1 entries");
     for (DevBuf* b : bufs) free_buf(*b);
     for (auto& t : h->timers) {

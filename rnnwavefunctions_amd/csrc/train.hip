@@ -10,8 +10,8 @@
 //     adam_kernel         m, v, theta in f64; theta rounded to the model's type as the host optimizer does
 //     repack_kernel       every weight image rebuilt from theta by replaying the host packers' recorded tables (pack_value.h)
 // The arithmetic is the host path's, operation for operation (IEEE f64, no contraction), so a trajectory equals the host-Adam
-// one bit for bit (tests/test_gpu_training.py).  Supported: the single-layer f32 GRU models (positive, parity-symmetric, complex);
-// other models keep the host optimizer (rnnwf_device_training_supported says which).
+// one bit for bit (tests/test_gpu_training.py).  Supported: every GRU model - positive, parity-symmetric, complex, float64 on the
+// 2D lattice - with one layer or a stack; the 2D RNN keeps the host optimizer (rnnwf_device_training_supported says which).
 #include <cmath>
 
 #include "models.h"
@@ -102,6 +102,16 @@ int wsplit_table(rnnwf_handle* h) {
     }
     return 1;
 }
+int wimg_table_f64(rnnwf_handle* h) {
+    switch (h->NFULL) {
+        case 1: pack_gru_image<double, 1, 1, Lin>(h); return 0;
+        case 2: pack_gru_image<double, 2, 1, Lin>(h); return 0;
+        case 3: pack_gru_image<double, 3, 1, Lin>(h); return 0;
+        case 4: pack_gru_image<double, 4, 1, Lin>(h); return 0;
+        case 6: pack_gru_image<double, 6, 1, Lin>(h); return 0;
+    }
+    return 1;
+}
 int wbasebf_table(rnnwf_handle* h) {
     switch (h->NFULL) {
         case 1: pack_base_bf_image<1, Lin>(h); return 0;
@@ -145,9 +155,10 @@ int build(rnnwf_handle* h) {
     TrainState& t = h->train;
     if (t.built) return t.supported ? 0 : h->fail(RNNWF_ERR_INVALID, "device-resident training is not available for this model: %s", t.why.c_str());
     t.built = true;
-    const bool gru = h->model == RNNWF_MODEL_GRU1D || h->model == RNNWF_MODEL_GRU1D_PARITY || h->model == RNNWF_MODEL_CRNN_U1;
-    if (!gru || h->f64 || h->NL != 1) {
-        t.why = "single-layer float32 GRU models only (stacked layers, float64 models and the 2D RNN keep the host optimizer)";
+    const bool gru = h->model == RNNWF_MODEL_GRU1D || h->model == RNNWF_MODEL_GRU1D_PARITY || h->model == RNNWF_MODEL_CRNN_U1 ||
+                     h->model == RNNWF_MODEL_GRU1D_F64;
+    if (!gru) {
+        t.why = "GRU models only (the 2D RNN keeps the host optimizer)";
         return h->fail(RNNWF_ERR_INVALID, "device-resident training is not available for this model: %s", t.why.c_str());
     }
     const bool cplx = h->model == RNNWF_MODEL_CRNN_U1;
@@ -167,11 +178,26 @@ int build(rnnwf_handle* h) {
     RNNWF_HIP(h, hipMemcpy(t.gidx.p, sidx.data(), sidx.size() * 4, hipMemcpyHostToDevice));
     // images (the backward image's table is added on first use: its buffer exists once the gradient has packed it on the host)
     t.nimg = 0;
-    if (int rc = add_image(h, &h->wimg, [&] { return cplx ? wimg_table<3>(h) : wimg_table<1>(h); })) return rc;
-    if (h->engine_split) {
-        if (int rc = add_image(h, &h->wsplit, [&] { return cplx ? wsplit_table<3>(h) : wsplit_table<1>(h); })) return rc;
-        if (h->NFULL == 6 && !cplx && h->wsplit16.p)
-            if (int rc = add_image(h, &h->wsplit16, [&] { pack_split16_image<1, Lin>(h); return 0; })) return rc;
+    if (h->NL > 1) {
+        // a stack: the forward buffer holds [layer 0 | upper layers] (grad.hip knows the layouts); on the bf16x3 engine (37..50 units)
+        // the layer pipeline's images beside it (split.hip: prnn_stack_pack / crnn_stack_pack)
+        if (int rc = add_image(h, &h->wimg, [&] { return grad_stack_forward_table(h); })) return rc;
+        if (h->engine_split) {
+            if (int rc = add_image(h, &h->wsplit, [&] { if (cplx) pack_split_image<1, 9, 3, 2, Lin>(h); else pack_split_image<1, 9, 1, 2, Lin>(h); return 0; })) return rc;
+            for (int l = 1; l < h->NL; ++l) {
+                const bool top = l == h->NL - 1;
+                if (int rc = add_image(h, &h->wsplit_up[l - 1], [&] {
+                        if (cplx) pack_split_upper_image<1, 9, 3, Lin>(h, l, top); else pack_split_upper_image<1, 9, 1, Lin>(h, l, top);
+                        return 0; })) return rc;
+            }
+        }
+    } else {
+        if (int rc = add_image(h, &h->wimg, [&] { return h->f64 ? wimg_table_f64(h) : cplx ? wimg_table<3>(h) : wimg_table<1>(h); })) return rc;
+        if (h->engine_split) {
+            if (int rc = add_image(h, &h->wsplit, [&] { return cplx ? wsplit_table<3>(h) : wsplit_table<1>(h); })) return rc;
+            if (h->NFULL == 6 && !cplx && h->wsplit16.p)
+                if (int rc = add_image(h, &h->wsplit16, [&] { pack_split16_image<1, Lin>(h); return 0; })) return rc;
+        }
     }
     if (h->base_bf)
         if (int rc = add_image(h, &h->wbasebf, [&] { return wbasebf_table(h); })) return rc;
