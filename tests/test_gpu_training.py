@@ -149,6 +149,16 @@ def test_run_1dtfim_reaches_the_exact_ground_state_energy():
     ("tfim", dict(systemsize=9, num_units=20, numsamples=100, learningrate=5e-3, parity_symmetric=True)),
     ("j1j2", dict(systemsize=10, num_units=10, numsamples=200, learningrate=5e-4, J2_=0.2)),
     ("j1j2", dict(systemsize=12, num_units=50, numsamples=300, learningrate=5e-4, J2_=0.5)),
+    # stacked layers: the f32-input MFMA stack, the bf16x3 layer pipeline (37..50 units, a batch large enough to choose it), the complex
+    # wave function's default two layers of ten units, three layers of unequal... (equal here: the drivers take [h] * num_layers)
+    ("tfim", dict(systemsize=10, num_units=20, numsamples=200, learningrate=5e-3, num_layers=2)),
+    ("tfim", dict(systemsize=34, num_units=50, numsamples=2400, learningrate=2e-3, num_layers=2)),
+    ("tfim", dict(systemsize=8, num_units=10, numsamples=100, learningrate=5e-3, num_layers=3, parity_symmetric=True)),
+    ("j1j2", dict(systemsize=10, num_units=10, numsamples=200, learningrate=5e-4, J2_=0.2, num_layers=2)),
+    ("j1j2", dict(systemsize=24, num_units=44, numsamples=2000, learningrate=5e-4, J2_=0.5, num_layers=2)),
+    # the float64 GRU on the 2D lattice (2DTFIM_1DRNN), whose driver adapts the learning rate every iteration
+    ("2d1d", dict(systemsize_x=3, systemsize_y=3, num_units=20, numsamples=100, learningrate=1e-3)),
+    ("2d1d", dict(systemsize_x=4, systemsize_y=3, num_units=10, numsamples=100, learningrate=1e-3, num_layers=2)),
 ])
 def test_device_resident_training_equals_the_host_optimizer_bit_for_bit(kind, kw, monkeypatch):
     """50 iterations of run_1DTFIM / run_J1J2 with the whole iteration on the device (rnnwf_train_steps: gradient from the
@@ -156,7 +166,7 @@ def test_device_resident_training_equals_the_host_optimizer_bit_for_bit(kind, kw
     synchronisation) against the same run with the optimizer and the packers on the host: energies, variances and final
     parameters are IDENTICAL - which also proves the re-packed images equal the host-packed ones bit for bit, step after step."""
     from rnnwavefunctions_amd import training as T
-    run = T.run_1DTFIM if kind == "tfim" else T.run_J1J2
+    run = {"tfim": T.run_1DTFIM, "j1j2": T.run_J1J2, "2d1d": T.run_2DTFIM_1DRNN}[kind]
     out = {}
     for mode in (True, False):
         monkeypatch.setattr(T, "DEVICE_TRAINING", mode)
@@ -194,9 +204,9 @@ def test_device_adam_step_and_checkpointed_state(tmp_path, monkeypatch):
             assert np.array_equal(dev[k], host[k]), (it, k)
     mflat, vflat, t = wf.adam_get_state()
     assert t == 3 and np.array_equal(mflat, opt.to_flat(wf, prm, SCOPE)[0]) and np.array_equal(vflat, opt.to_flat(wf, prm, SCOPE)[1])
-    # the stacked / float64 / 2D models keep the host optimizer and say so
-    wf2 = _lib.NativeWavefunction(_lib.MODEL_GRU1D, N, 1, (20, 20))
-    wf2.set_params(P.init_gru_params([20, 20], seed=1), scope=SCOPE)
+    # the 2D RNN keeps the host optimizer and says so
+    wf2 = _lib.NativeWavefunction(_lib.MODEL_MDRNN2D, 3, 3, (10,))
+    wf2.set_params(P.init_mdrnn_params(10, seed=1), scope=SCOPE)
     assert not wf2.device_training_supported()
     with pytest.raises((ValueError, _lib.RnnwfError), match="not available"):
         wf2.adam_step(1e-3)
