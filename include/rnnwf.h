@@ -180,8 +180,8 @@ int rnnwf_vmc_step(rnnwf_handle* h, int64_t numsamples, uint64_t seed, uint64_t 
  *   log(0.5 (P(s) + P(reversed s))), two backward passes weighted by each direction's share of P_sym.
  *   Every reduction has a fixed order: the same batch gives the same bits.
  * rnnwf_get_grad     <- the gradient of one TF variable (same names and shapes as rnnwf_set_param).
- * rnnwf_allreduce_grads: one RCCL all-reduce (sum) over all gradient arrays of the handle (single-layer float32 GRU models:
- *   flattened and summed on the device, in-stream, then copied to the host arrays; other models: through pinned staging). */
+ * rnnwf_allreduce_grads: one RCCL all-reduce (sum) over all gradient arrays of the handle (flattened and summed on the
+ *   device, in-stream, then copied to the host arrays; through pinned staging when the device-side map is unavailable).  */
 int rnnwf_vmc_gradient(rnnwf_handle* h, double mean_energy, double mean_energy_im, double norm);
 /* rnnwf_load_batch: the batch rnnwf_vmc_gradient works on, supplied by the caller instead of drawn by rnnwf_vmc_step -
  * what `sess.run(optstep, feed_dict={Eloc: local_energies, samp: samples, ...})` feeds (TrainingRNN_1DTFIM.py:221,
@@ -196,15 +196,15 @@ int rnnwf_get_grads_flat(rnnwf_handle* h, double* flat, int64_t count);
 const char* rnnwf_param_name(const rnnwf_handle* h, int32_t i, int64_t* count);
 int rnnwf_allreduce_grads(rnnwf_handle* h);
 
-/* ---- device-resident training iteration (single-layer float32 GRU models) ---------------------------------------------
+/* ---- device-resident training iteration (every model of the four drivers) ----------------------------------------------
  * The reference's update is one `sess.run(optstep)` on the device (1DTFIM/TrainingRNN_1DTFIM.py:113,162,221;
  * J1J2/TrainingRNN_J1J2.py:164,286): tf.train.AdamOptimizer on the gradient of the cost, variables never leave the device.
  * rnnwf_device_training_supported: 1 when this handle can do the same (parameters, Adam moments and gradient resident on the
- *   device, the kernels' weight images rebuilt there after every update); 0: keep the host optimizer
- *   (rnnwf_get_grads_flat / rnnwf_set_params_flat).
+ *   device, the kernels' weight images rebuilt there after every update) - every GRU model, one layer or a stack, and the 2D
+ *   RNN; 0 (a width without a packer table): keep the host optimizer (rnnwf_get_grads_flat / rnnwf_set_params_flat).
  * rnnwf_adam_step  <- optimizer.apply_gradients on the gradient the last rnnwf_vmc_gradient left on the device:
  *   t += 1; lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t); m = beta1 m + (1 - beta1) g; v = beta2 v + (1 - beta2) g^2;
- *   theta -= lr_t m / (sqrt(v) + epsilon) in float64, theta rounded to float32; then every weight image is rebuilt on the device.
+ *   theta -= lr_t m / (sqrt(v) + epsilon) in float64, theta rounded to the model's type; then every weight image is rebuilt on the device.
  * rnnwf_train_steps <- K iterations of the loop at TrainingRNN_1DTFIM.py:199-227 (sample, local energies, moments, gradient,
  *   update) with ONE host synchronisation: iteration k draws with step index step0 + k and uses learning_rates[k];
  *   moments: [K][4] as rnnwf_vmc_step returns them (summed over the ranks when rnnwf_comm_reduce_in_step is on, as is the

@@ -154,7 +154,7 @@ extern "C" int rnnwf_allreduce_grads(rnnwf_handle* h) {
         return h->fail(RNNWF_ERR_STATE, "rnnwf_allreduce_grads: communicator not initialised");
     }
     RNNWF_HIP(h, hipSetDevice(h->cfg.device));
-    {   // single-layer f32 GRU models: the gradient is flattened and summed on the device, in-stream (train.hip)
+    {   // the gradient is flattened and summed on the device, in-stream (train.hip); the staged road below is the fall-back
         const int done = rnnwf::train_allreduce_grads_device(h);
         if (done < 0) return done;
         if (done == 1) return RNNWF_OK;

@@ -80,16 +80,21 @@ struct MLaunch {
     static size_t hs_bytes_per_block() { return (size_t)((L::KT + 1) / 2) * 64 * 16; }
     static double mfma_flops_per_step() { return (double)NFULL * 2 * L::KT * 2048.0; }
 
+    // S = double: the image of the committed parameters; S = Lin: the same code recording, for the device re-pack kernel of
+    // train.hip, which parameters every element is made of (pack_value.h)
+    template <class S = double>
     static std::vector<char> pack(const rnnwf_handle* h) {
+        using Out = PackSink<S>;
         const int H = h->H;
         std::vector<char> img(L::BYTES, 0);
-        const auto& Wh = pv(h, "Wh_rnn_0");   // [H, H]
-        const auto& Uh = pv(h, "Uh_rnn_0");   // [2, H]
-        const auto& Wv = pv(h, "Wv_rnn_0");
-        const auto& Uv = pv(h, "Uv_rnn_0");
-        const auto& b = pv(h, "b_rnn_0");
-        const auto& Wd = pv(h, "wf_dense/kernel");
-        const auto& bd = pv(h, "wf_dense/bias");
+        Out::begin(img);
+        const auto Wh = pvs<S>(h, "Wh_rnn_0");   // [H, H]
+        const auto Uh = pvs<S>(h, "Uh_rnn_0");   // [2, H]
+        const auto Wv = pvs<S>(h, "Wv_rnn_0");
+        const auto Uv = pvs<S>(h, "Uv_rnn_0");
+        const auto b = pvs<S>(h, "b_rnn_0");
+        const auto Wd = pvs<S>(h, "wf_dense/kernel");
+        const auto bd = pvs<S>(h, "wf_dense/bias");
         double* A = reinterpret_cast<double*>(img.data() + L::OFF_A);
         for (int t = 0; t < NFULL; ++t)
             for (int row = 0; row < 16; ++row) {
@@ -100,8 +105,8 @@ struct MLaunch {
                     for (int kk = 0; kk < 2 * L::KT; ++kk) {
                         const int k = 4 * (kk < L::KT ? kk : kk - L::KT) + kq;
                         if (k >= H) continue;
-                        const double w = kk < L::KT ? Wh[(size_t)k * H + unit] : Wv[(size_t)k * H + unit];
-                        A[(((size_t)t * L::KT + kk / 2) * 64 + lane) * 2 + (kk & 1)] = w;
+                        Out::put(&A[(((size_t)t * L::KT + kk / 2) * 64 + lane) * 2 + (kk & 1)],
+                                 kk < L::KT ? Wh[(size_t)k * H + unit] : Wv[(size_t)k * H + unit]);
                     }
                 }
             }
@@ -113,45 +118,43 @@ struct MLaunch {
                 for (int j = 0; j < 4; ++j) {
                     const int unit = 16 * NFULL + j;
                     if (unit >= H) continue;
-                    WR[(kk * 4 + q) * 4 + j] = kk < L::KT ? Wh[(size_t)k * H + unit] : Wv[(size_t)k * H + unit];
+                    Out::put(&WR[(kk * 4 + q) * 4 + j], kk < L::KT ? Wh[(size_t)k * H + unit] : Wv[(size_t)k * H + unit]);
                 }
             }
-        for (int v = 0; v < 3; ++v) {
-            double* BH = reinterpret_cast<double*>(img.data() + L::OFF_BH + v * L::SZ_B);
-            double* BV = reinterpret_cast<double*>(img.data() + L::OFF_BV + v * L::SZ_B);
-            for (int t = 0; t < L::NT; ++t)
-                for (int q = 0; q < 4; ++q)
-                    for (int r = 0; r < 4; ++r) {
-                        if (t == NFULL && r != 0) continue;
-                        const int unit = t < NFULL ? 16 * t + 4 * r + q : 16 * NFULL + q;
-                        if (unit >= H) continue;
-                        BH[t * 16 + q * 4 + r] = b[unit] + (v ? Uh[(size_t)(v - 1) * H + unit] : 0.0);
-                        BV[t * 16 + q * 4 + r] = v ? Uv[(size_t)(v - 1) * H + unit] : 0.0;
+        // b + Uh[x_h] (BH), Uv[x_v] (BV) for x in {none, 0, 1}, and their nine sums (BHV): one accumulator start value per step
+        auto bh_of = [&](int v, int unit) -> S { return b[unit] + (v ? Uh[(size_t)(v - 1) * H + unit] : S(0.0)); };
+        auto bv_of = [&](int v, int unit) -> S { return v ? Uv[(size_t)(v - 1) * H + unit] : S(0.0); };
+        for (int t = 0; t < L::NT; ++t)
+            for (int q = 0; q < 4; ++q)
+                for (int r = 0; r < 4; ++r) {
+                    if (t == NFULL && r != 0) continue;
+                    const int unit = t < NFULL ? 16 * t + 4 * r + q : 16 * NFULL + q;
+                    if (unit >= H) continue;
+                    const int k = t * 16 + q * 4 + r;
+                    for (int v = 0; v < 3; ++v) {
+                        Out::put(reinterpret_cast<double*>(img.data() + L::OFF_BH + v * L::SZ_B) + k, bh_of(v, unit));
+                        Out::put(reinterpret_cast<double*>(img.data() + L::OFF_BV + v * L::SZ_B) + k, bv_of(v, unit));
                     }
-        }
+                    for (int vh = 0; vh < 3; ++vh)
+                        for (int vv = 0; vv < 3; ++vv)
+                            Out::put(reinterpret_cast<double*>(img.data() + L::OFF_BHV + (size_t)(vh * 3 + vv) * L::SZ_B) + k,
+                                     bh_of(vh, unit) + bv_of(vv, unit));
+                }
         double* WD = reinterpret_cast<double*>(img.data() + L::OFF_WD);
         double* BD = reinterpret_cast<double*>(img.data() + L::OFF_BD);
         for (int kt = 0; kt < L::KT; ++kt)
             for (int q = 0; q < 4; ++q) {
                 const int unit = 4 * kt + q;
                 if (unit >= H) continue;
-                WD[(kt * 4 + q) * 2] = Wd[(size_t)unit * 2];
-                WD[(kt * 4 + q) * 2 + 1] = Wd[(size_t)unit * 2 + 1];
+                Out::put(&WD[(kt * 4 + q) * 2], Wd[(size_t)unit * 2]);
+                Out::put(&WD[(kt * 4 + q) * 2 + 1], Wd[(size_t)unit * 2 + 1]);
             }
-        BD[0] = bd[0];
-        BD[1] = bd[1];
-        // b + Uh[x_h] + Uv[x_v] for the nine (x_h, x_v) in {none, 0, 1}^2: one accumulator start value per step
-        for (int vh = 0; vh < 3; ++vh)
-            for (int vv = 0; vv < 3; ++vv) {
-                double* BHV = reinterpret_cast<double*>(img.data() + L::OFF_BHV + (size_t)(vh * 3 + vv) * L::SZ_B);
-                const double* BH = reinterpret_cast<const double*>(img.data() + L::OFF_BH + vh * L::SZ_B);
-                const double* BV = reinterpret_cast<const double*>(img.data() + L::OFF_BV + vv * L::SZ_B);
-                for (size_t k = 0; k < L::SZ_B / 8; ++k) BHV[k] = BH[k] + BV[k];
-            }
+        Out::put(&BD[0], bd[0]);
+        Out::put(&BD[1], bd[1]);
         fill_f64_tables(reinterpret_cast<double*>(img.data() + L::OFF_TAB));
         double* WDD = reinterpret_cast<double*>(img.data() + L::OFF_WDD);
-        for (int unit = 0; unit < H; ++unit) WDD[unit] = Wd[(size_t)unit * 2 + 1] - Wd[(size_t)unit * 2];   // slot 4 kt + q
-        WDD[L::KT * 4] = bd[1] - bd[0];
+        for (int unit = 0; unit < H; ++unit) Out::put(&WDD[unit], Wd[(size_t)unit * 2 + 1] - Wd[(size_t)unit * 2]);   // slot 4 kt + q
+        Out::put(&WDD[L::KT * 4], bd[1] - bd[0]);
         return img;
     }
 };
@@ -264,7 +267,7 @@ int eloc_on_device(rnnwf_handle* h, int64_t ns, const Maps& m, bool sampling, ui
 
 int rnnwf::mdrnn_pack_image(rnnwf_handle* h, std::vector<char>& img) {
     if (h->N > 256) return h->fail(RNNWF_ERR_INVALID, "MDRNN: lattices above 256 sites are not implemented");
-    MD_DISPATCH(h, { img = K::pack(h); return 0; });
+    MD_DISPATCH(h, { img = K::template pack<double>(h); return 0; });
     return h->fail(RNNWF_ERR_INVALID, "MDRNN: num_units > 84 is not implemented on gfx950 yet");
 }
 
@@ -375,13 +378,16 @@ template <int NFULL, int WAVES>
 struct MGrad {
     using G = MdGradLayout<NFULL>;
 
+    template <class S = double>
     static std::vector<char> pack(const rnnwf_handle* h) {
+        using Out = PackSink<S>;
         const int H = h->H;
         std::vector<char> img(G::BYTES, 0);
-        const auto& Wh = pv(h, "Wh_rnn_0");
-        const auto& Wv = pv(h, "Wv_rnn_0");
-        const auto& Wd = pv(h, "wf_dense/kernel");
-        const auto& bd = pv(h, "wf_dense/bias");
+        Out::begin(img);
+        const auto Wh = pvs<S>(h, "Wh_rnn_0");
+        const auto Wv = pvs<S>(h, "Wv_rnn_0");
+        const auto Wd = pvs<S>(h, "wf_dense/kernel");
+        const auto bd = pvs<S>(h, "wf_dense/bias");
         double* A = reinterpret_cast<double*>(img.data() + G::OFF_A);
         for (int t = 0; t < G::NTO; ++t) {
             const int tt = t % G::NT;
@@ -394,7 +400,7 @@ struct MGrad {
                     for (int kk = 0; kk < G::KT; ++kk) {
                         const int u = 4 * kk + kq;
                         if (u >= H) continue;
-                        A[(((size_t)t * G::KBG + kk / 2) * 64 + lane) * 2 + (kk & 1)] = Wsrc[(size_t)kout * H + u];
+                        Out::put(&A[(((size_t)t * G::KBG + kk / 2) * 64 + lane) * 2 + (kk & 1)], Wsrc[(size_t)kout * H + u]);
                     }
                 }
             }
@@ -405,11 +411,11 @@ struct MGrad {
             for (int q = 0; q < 4; ++q) {
                 const int unit = 4 * kt + q;
                 if (unit >= H) continue;
-                WD[(kt * 4 + q) * 2] = Wd[(size_t)unit * 2];
-                WD[(kt * 4 + q) * 2 + 1] = Wd[(size_t)unit * 2 + 1];
+                Out::put(&WD[(kt * 4 + q) * 2], Wd[(size_t)unit * 2]);
+                Out::put(&WD[(kt * 4 + q) * 2 + 1], Wd[(size_t)unit * 2 + 1]);
             }
-        BD[0] = bd[0];
-        BD[1] = bd[1];
+        Out::put(&BD[0], bd[0]);
+        Out::put(&BD[1], bd[1]);
         return img;
     }
 
@@ -478,11 +484,13 @@ struct MGrad {
 
 }  // namespace
 
-int rnnwf::mdrnn_vmc_gradient(rnnwf_handle* h, double mean_energy, double norm) {
+// The gradient's kernels on the batch of the last rnnwf_vmc_step; result (dW image, then the head rows) left in h->gradW.
+// mom_dev != nullptr (device-resident training, train.hip): mean energy and norm come from the step's moments on the device.
+int rnnwf::mdrnn_grad_device(rnnwf_handle* h, double mean_energy, double norm, const double* mom_dev, size_t* dw_count) {
     if (h->NFULL > 5) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: num_units > 84 not implemented");
     if (h->last_ns <= 0 || !h->last_has_ckpt)
         return h->fail(RNNWF_ERR_STATE, "rnnwf_vmc_gradient: call rnnwf_vmc_step first (its samples, states and E_loc are reused)");
-    if (!(norm > 0)) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: norm must be positive");
+    if (!mom_dev && !(norm > 0)) return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: norm must be positive");
     RNNWF_HIP(h, hipSetDevice(h->cfg.device));
     Maps m;
     if (int rc = get_maps(h, &m)) return rc;
@@ -492,7 +500,7 @@ int rnnwf::mdrnn_vmc_gradient(rnnwf_handle* h, double mean_energy, double norm) 
     MG_DISPATCH(h, { pcols = K::G::PCOLS; qcols = K::G::QCOLS; hgn = 2 * K::G::HEAD_ROW; break; });
     if (!h->wbwd_valid) {
         std::vector<char> img;
-        MG_DISPATCH(h, { img = K::pack(h); break; });
+        MG_DISPATCH(h, { img = K::template pack<double>(h); break; });
         if (int rc = ensure(h, h->wbwd, img.size())) return rc;
         if (int rc = upload(h, h->wbwd.p, img.data(), img.size())) return rc;
         h->wbwd_valid = true;
@@ -500,6 +508,7 @@ int rnnwf::mdrnn_vmc_gradient(rnnwf_handle* h, double mean_energy, double norm) 
     if (int rc = ensure(h, h->gradP, (size_t)R * pcols * 8)) return rc;
     if (int rc = ensure(h, h->gradQ, (size_t)R * qcols * 8)) return rc;
     const size_t dwn = (size_t)pcols * qcols + hgn;
+    if (dw_count) *dw_count = dwn;
     if (int rc = ensure(h, h->gradW, dwn * 8)) return rc;
     RNNWF_HIP(h, hipMemsetAsync(h->gradW.p, 0, dwn * 8, h->stream));
     MdGradArgs a{};
@@ -512,17 +521,59 @@ int rnnwf::mdrnn_vmc_gradient(rnnwf_handle* h, double mean_energy, double norm) 
     a.hs = (const double*)h->hck.p;
     a.eloc = (const double*)h->eloc.p;
     a.mean_e = mean_energy;
-    a.inv_norm = 1.0 / norm;
+    a.inv_norm = mom_dev ? 1.0 : 1.0 / norm;
+    a.mom = mom_dev;
     a.P = (double*)h->gradP.p;
     a.Q = (double*)h->gradQ.p;
     a.head_grad = (double*)h->gradW.p + (size_t)pcols * qcols;
     a.vert_pos = m.vert_pos;
     a.row_first = m.row_first;
     MG_DISPATCH(h, { if (int rc = K::run(h, a, R, (double*)h->gradW.p)) return rc; break; });
+    return RNNWF_OK;
+}
+
+int rnnwf::mdrnn_vmc_gradient(rnnwf_handle* h, double mean_energy, double norm) {
+    size_t dwn = 0;
+    if (int rc = mdrnn_grad_device(h, mean_energy, norm, nullptr, &dwn)) return rc;
+    int pcols = 0, qcols = 0;
+    MG_DISPATCH(h, { pcols = K::G::PCOLS; qcols = K::G::QCOLS; break; });
     if (int rc = ensure_staging(h, dwn * 8)) return rc;
     const double* host = (const double*)h->staging;
     RNNWF_HIP(h, hipMemcpyAsync(h->staging, h->gradW.p, dwn * 8, hipMemcpyDeviceToHost, h->stream));
     RNNWF_HIP(h, hipStreamSynchronize(h->stream));
     MG_DISPATCH(h, { K::unpack(h, host, host + (size_t)pcols * qcols); break; });
     return RNNWF_OK;
+}
+
+// ---- device-resident training (train.hip): the packers' tables and the gradient image's map ---------------------------------
+int rnnwf::mdrnn_pack_table(rnnwf_handle* h, bool backward) {
+    if (backward) { MG_DISPATCH(h, { K::template pack<Lin>(h); return 0; }); }
+    else { MD_DISPATCH(h, { K::template pack<Lin>(h); return 0; }); }
+    return 1;
+}
+
+// sidx[i] = 1 + the gradient image element parameter i (order of rnnwf_set_params_flat) is read from, found by running the host
+// unpacker on an image holding its own indices
+int rnnwf::mdrnn_grad_probe(rnnwf_handle* h, std::vector<int32_t>& sidx, size_t* dw_count) {
+    int pcols = 0, qcols = 0, hgn = 0;
+    MG_DISPATCH(h, { pcols = K::G::PCOLS; qcols = K::G::QCOLS; hgn = 2 * K::G::HEAD_ROW; break; });
+    const size_t n = (size_t)pcols * qcols + hgn;
+    if (n == 0 || n >= ((size_t)1 << 31)) return h->fail(RNNWF_ERR_INVALID, "gradient image of %zu elements cannot be probed", n);
+    const auto saved = h->grads;
+    std::vector<double> img(n);
+    for (size_t k = 0; k < n; ++k) img[k] = (double)(k + 1);
+    MG_DISPATCH(h, { K::unpack(h, img.data(), img.data() + (size_t)pcols * qcols); break; });
+    sidx.clear();
+    int rc = 0;
+    for (auto& kv : h->params) {
+        auto it = h->grads.find(kv.first);
+        if (it == h->grads.end() || it->second.size() != kv.second.value.size()) {
+            rc = h->fail(RNNWF_ERR_STATE, "mdrnn_grad_probe: no gradient for '%s'", kv.first.c_str());
+            break;
+        }
+        for (size_t i = 0; i < kv.second.slot.size(); ++i) sidx.push_back((int32_t)std::llround(it->second[(size_t)kv.second.slot[i]]));
+    }
+    h->grads = saved;
+    if (dw_count) *dw_count = n;
+    return rc;
 }

@@ -38,6 +38,7 @@ struct MdGradArgs {
     double* ring;                  // [total waves][2 Nx][KT][64]
     const double* eloc;            // [ns]
     double mean_e, inv_norm;
+    const double* mom;             // device-resident training: the step's moments on the device (grad_kernels.h: GradArgs::mom), nullptr: the fields above
     double* P;
     double* Q;
     double* head_grad;             // [2][HEAD_ROW], zeroed before the launch (written by head_reduce_kernel)
@@ -76,7 +77,8 @@ __global__ void __launch_bounds__(WAVES * 64) mdrnn_bwd_kernel(MdGradArgs a) {
         const int64_t s = sb * kChains + c;
         const bool valid = s < a.ns;
         const int64_t sc = valid ? s : a.ns - 1;
-        const double w = valid ? (a.eloc[sc] - a.mean_e) * a.inv_norm : 0.0;
+        const double mean_e = a.mom ? a.mom[0] / a.mom[2] : a.mean_e, inv_norm = a.mom ? a.inv_norm / a.mom[2] : a.inv_norm;
+        const double w = valid ? (a.eloc[sc] - mean_e) * inv_norm : 0.0;
         double carry[KT];
 #pragma unroll
         for (int k = 0; k < KT; ++k) carry[k] = 0.0;

@@ -94,6 +94,9 @@ int mdrnn_load_batch(rnnwf_handle* h, const int32_t* samples, int64_t ns);
 
 // ---- gradient (grad.hip) ---------------------------------------------------------------------------
 int mdrnn_vmc_gradient(rnnwf_handle* h, double mean_energy, double norm);
+int mdrnn_grad_device(rnnwf_handle* h, double mean_energy, double norm, const double* mom_dev, size_t* dw_count);
+int mdrnn_pack_table(rnnwf_handle* h, bool backward);
+int mdrnn_grad_probe(rnnwf_handle* h, std::vector<int32_t>& sidx, size_t* dw_count);
 int grad_single_layer_device(rnnwf_handle* h, double mean_energy, double mean_energy_im, double norm, const double* mom_dev, size_t* dw_count);
 int grad_bwd_pack_table(rnnwf_handle* h);
 int grad_stack_forward_table(rnnwf_handle* h);

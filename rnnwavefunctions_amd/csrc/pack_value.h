@@ -2,13 +2,14 @@
 //
 // S = double : the packer fills the image with the values of the committed parameters (what rnnwf_commit_params uploads).
 // S = Lin    : the SAME code, run once per handle, records for every image element WHICH parameters it is made of and how:
-//                  value = c * (P[a] + s * P[b])          (b optional; a bias plus an input row, a head column difference, ...)
+//                  value = c * ((P[a] + s * P[b]) + P[d])   (b, d optional; a bias plus an input row, a head column difference, the 2D
+//                                                            cell's b + Uh[x_h] + Uv[x_v], ...)
 //              followed by the store's conversion (f32, f64, or part k of the exact three-way bf16 split of the f32 value).
 //              The record - a PackTable - is what the device-side re-pack kernel (train.hip: repack_kernel) replays on the
 //              device-resident parameters after every optimizer step, so that a training iteration never visits the host
 //              (the reference runs `sess.run(optstep)` on the device, 1DTFIM/TrainingRNN_1DTFIM.py:113,162,221).
-//              Because it is the packer's own arithmetic that is recorded (same operation order: t = P[a] +- P[b] in double, then
-//              c * t, then the conversion), the replayed image equals the host-packed one bit for bit (tests/test_gpu_training.py).
+//              Because it is the packer's own arithmetic that is recorded (same operation order: t = P[a] +- P[b] in double, + P[d],
+//              then c * t, then the conversion), the replayed image equals the host-packed one bit for bit (tests/test_gpu_training.py).
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -42,10 +43,10 @@ inline void split3(double w, uint16_t (&p)[3]) {
     }
 }
 
-// c * (P[a] + s * P[b]); a < 0: the constant v.  v always holds the value for the parameters the packer sees.
+// c * ((P[a] + s * P[b]) + P[d]); a < 0: the constant v.  v always holds the value for the parameters the packer sees.
 struct Lin {
     double v = 0.0;
-    int32_t a = -1, b = -1;
+    int32_t a = -1, b = -1, d = -1;
     double c = 1.0;
     int32_t s = 0;
     Lin() = default;
@@ -54,14 +55,16 @@ struct Lin {
 inline Lin operator+(const Lin& x, const Lin& y) {
     if (x.a < 0 && x.v == 0.0) return y;
     if (y.a < 0 && y.v == 0.0) return x;
-    if (x.a < 0 || y.a < 0 || x.b >= 0 || y.b >= 0 || x.c != 1.0 || y.c != 1.0) throw std::logic_error("pack_value.h: unsupported sum in a packer");
-    Lin r;
-    r.v = x.v + y.v; r.a = x.a; r.b = y.a; r.s = 1;
+    if (x.a < 0 || y.a < 0 || x.d >= 0 || y.b >= 0 || y.d >= 0 || x.c != 1.0 || y.c != 1.0) throw std::logic_error("pack_value.h: unsupported sum in a packer");
+    Lin r = x;
+    r.v = x.v + y.v;
+    if (x.b < 0) { r.b = y.a; r.s = 1; }
+    else r.d = y.a;                                           // (P[a] +- P[b]) + P[d]
     return r;
 }
 inline Lin operator-(const Lin& x, const Lin& y) {
     if (y.a < 0 && y.v == 0.0) return x;
-    if (x.a < 0 || y.a < 0 || x.b >= 0 || y.b >= 0 || x.c != 1.0 || y.c != 1.0) throw std::logic_error("pack_value.h: unsupported difference in a packer");
+    if (x.a < 0 || y.a < 0 || x.b >= 0 || y.b >= 0 || x.d >= 0 || y.d >= 0 || x.c != 1.0 || y.c != 1.0) throw std::logic_error("pack_value.h: unsupported difference in a packer");
     Lin r;
     r.v = x.v - y.v; r.a = x.a; r.b = y.a; r.s = -1;
     return r;
@@ -79,6 +82,7 @@ struct PackEntry {
     uint32_t off;        // byte offset in the image
     int32_t a, b;        // flat parameter indices (order of rnnwf_set_params_flat), b < 0: none
     int32_t kind;        // 0: f32, 1: f64, 2 + k: bf16 part k of the f32 value; bit 8: s = -1 (difference instead of sum)
+    int32_t d;           // third term (added after a +- b), < 0: none
     double c;            // scale (1.0: none)
 };
 struct PackTable {
@@ -124,7 +128,7 @@ template <> struct PackSink<Lin> {
         if (!t.table || x.a < 0) return;                      // constants stay what the host-packed image holds
         PackEntry e;
         e.off = (uint32_t)((const char*)dst - t.base + t.shift);
-        e.a = x.a; e.b = x.b;
+        e.a = x.a; e.b = x.b; e.d = x.d;
         e.kind = kind | (x.b >= 0 && x.s < 0 ? PACK_MINUS : 0);
         e.c = x.c;
         t.table->entries.push_back(e);

@@ -10,8 +10,8 @@
 //     adam_kernel         m, v, theta in f64; theta rounded to the model's type as the host optimizer does
 //     repack_kernel       every weight image rebuilt from theta by replaying the host packers' recorded tables (pack_value.h)
 // The arithmetic is the host path's, operation for operation (IEEE f64, no contraction), so a trajectory equals the host-Adam
-// one bit for bit (tests/test_gpu_training.py).  Supported: every GRU model - positive, parity-symmetric, complex, float64 on the
-// 2D lattice - with one layer or a stack; the 2D RNN keeps the host optimizer (rnnwf_device_training_supported says which).
+// one bit for bit (tests/test_gpu_training.py).  Supported: every model of the four drivers - the positive, parity-symmetric, complex
+// and float64 GRU with one layer or a stack, and the 2D RNN (rnnwf_device_training_supported answers for a handle).
 #include <cmath>
 
 #include "models.h"
@@ -31,6 +31,7 @@ __global__ void repack_kernel(const PackEntry* __restrict__ e, int64_t n, const 
     const PackEntry t = e[i];
     double v = P[t.a];
     if (t.b >= 0) v = (t.kind & PACK_MINUS) ? __dsub_rn(v, P[t.b]) : __dadd_rn(v, P[t.b]);
+    if (t.d >= 0) v = __dadd_rn(v, P[t.d]);
     if (t.c != 1.0) v = __dmul_rn(t.c, v);
     const int kind = t.kind & 255;
     if (kind == PACK_F32) {
@@ -65,7 +66,7 @@ __global__ void adam_kernel(double* __restrict__ P, double* __restrict__ M, doub
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     // every operation rounded on its own, as NumPy evaluates the host optimizer's expressions (no fused multiply-add: the
-    // translation unit is compiled with -ffp-contract=fast)
+    // translation unit is compiled with -ffp-contract=off, build.py)
     const double g = G[i];
     const double m = __dadd_rn(__dmul_rn(b1, M[i]), __dmul_rn(__dsub_rn(1.0, b1), g));
     const double v = __dadd_rn(__dmul_rn(b2, V[i]), __dmul_rn(__dmul_rn(__dsub_rn(1.0, b2), g), g));
@@ -140,7 +141,7 @@ int add_image(rnnwf_handle* h, DevBuf* target, Fn&& run_packer) {
     for (const PackEntry& e : tbl.entries) {
         const int kind = e.kind & 255;
         const size_t width = kind == PACK_F32 ? 4 : kind == PACK_F64 ? 8 : 2;
-        if (e.a < 0 || e.a >= t.nparams || e.b >= t.nparams || kind > PACK_BF16 + 2 || (size_t)e.off + width > tbl.image_bytes)
+        if (e.a < 0 || e.a >= t.nparams || e.b >= t.nparams || e.d >= t.nparams || kind > PACK_BF16 + 2 || (size_t)e.off + width > tbl.image_bytes)
             return h->fail(RNNWF_ERR_STATE, "device training: image table entry out of range");
     }
     TrainImage& im = t.img[t.nimg++];
@@ -155,12 +156,7 @@ int build(rnnwf_handle* h) {
     TrainState& t = h->train;
     if (t.built) return t.supported ? 0 : h->fail(RNNWF_ERR_INVALID, "device-resident training is not available for this model: %s", t.why.c_str());
     t.built = true;
-    const bool gru = h->model == RNNWF_MODEL_GRU1D || h->model == RNNWF_MODEL_GRU1D_PARITY || h->model == RNNWF_MODEL_CRNN_U1 ||
-                     h->model == RNNWF_MODEL_GRU1D_F64;
-    if (!gru) {
-        t.why = "GRU models only (the 2D RNN keeps the host optimizer)";
-        return h->fail(RNNWF_ERR_INVALID, "device-resident training is not available for this model: %s", t.why.c_str());
-    }
+    const bool md = h->model == RNNWF_MODEL_MDRNN2D;
     const bool cplx = h->model == RNNWF_MODEL_CRNN_U1;
     t.nparams = rnnwf_num_params(h);
     for (DevBuf* b : {&t.P, &t.M, &t.V, &t.G})
@@ -170,7 +166,10 @@ int build(rnnwf_handle* h) {
     RNNWF_HIP(h, hipHostMalloc(&t.mom_host, (size_t)kMaxSteps * 4 * sizeof(double), hipHostMallocDefault));
     // gradient: dW image -> flat
     std::vector<int32_t> sidx;
-    if (int rc = grad_flat_probe(h, sidx, &t.dw_count, &t.dw_f64)) return rc;
+    if (md) {
+        t.dw_f64 = true;
+        if (int rc = mdrnn_grad_probe(h, sidx, &t.dw_count)) return rc;
+    } else if (int rc = grad_flat_probe(h, sidx, &t.dw_count, &t.dw_f64)) return rc;
     if ((int64_t)sidx.size() != t.nparams) return h->fail(RNNWF_ERR_STATE, "device training: gradient probe size mismatch");
     for (int32_t k : sidx)
         if ((size_t)(k < 0 ? -k : k) > t.dw_count) return h->fail(RNNWF_ERR_STATE, "device training: gradient probe index out of range");
@@ -178,7 +177,9 @@ int build(rnnwf_handle* h) {
     RNNWF_HIP(h, hipMemcpy(t.gidx.p, sidx.data(), sidx.size() * 4, hipMemcpyHostToDevice));
     // images (the backward image's table is added on first use: its buffer exists once the gradient has packed it on the host)
     t.nimg = 0;
-    if (h->NL > 1) {
+    if (md) {
+        if (int rc = add_image(h, &h->wimg, [&] { return mdrnn_pack_table(h, false); })) return rc;
+    } else if (h->NL > 1) {
         // a stack: the forward buffer holds [layer 0 | upper layers] (grad.hip knows the layouts); on the bf16x3 engine (37..50 units)
         // the layer pipeline's images beside it (split.hip: prnn_stack_pack / crnn_stack_pack)
         if (int rc = add_image(h, &h->wimg, [&] { return grad_stack_forward_table(h); })) return rc;
@@ -211,7 +212,7 @@ int ensure_bwd_image(rnnwf_handle* h) {
     for (int i = 0; i < t.nimg; ++i)
         if (t.img[i].target == &h->wbwd) return 0;
     if (!h->wbwd.p) return h->fail(RNNWF_ERR_STATE, "device training: the backward image has not been packed yet");
-    return add_image(h, &h->wbwd, [&] { return grad_bwd_pack_table(h); });
+    return add_image(h, &h->wbwd, [&] { return h->model == RNNWF_MODEL_MDRNN2D ? mdrnn_pack_table(h, true) : grad_bwd_pack_table(h); });
 }
 
 int params_to_device(rnnwf_handle* h) {
@@ -375,16 +376,18 @@ extern "C" int rnnwf_train_steps(rnnwf_handle* h, int32_t K, int64_t numsamples,
     RNNWF_HIP(h, hipSetDevice(h->cfg.device));
     if (int rc = build(h)) return rc;
     TrainState& t = h->train;
-    const bool cplx = h->model == RNNWF_MODEL_CRNN_U1;
+    const bool cplx = h->model == RNNWF_MODEL_CRNN_U1, md = h->model == RNNWF_MODEL_MDRNN2D;
     if (n_couplings != (cplx ? 3 * h->N + 2 : h->N + 1)) return h->fail(RNNWF_ERR_INVALID, "rnnwf_train_steps: wrong number of couplings");
     if (int rc = params_to_device(h)) return rc;
     for (int k = 0; k < K; ++k) {
         int rc;
         if (cplx) rc = crnn_vmc_step(h, numsamples, seed, step0 + (uint64_t)k, sample_offset, couplings, nullptr, nullptr, nullptr);
+        else if (md) rc = mdrnn_vmc_step(h, numsamples, seed, step0 + (uint64_t)k, sample_offset, couplings, nullptr, nullptr, nullptr);
         else rc = prnn_vmc_step(h, numsamples, seed, step0 + (uint64_t)k, sample_offset, couplings, nullptr, nullptr, nullptr);
         if (rc) return rc;
         RNNWF_HIP(h, hipMemcpyAsync((double*)t.mom_host + 4 * k, h->moments.p, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        if (int r2 = grad_single_layer_device(h, 0.0, 0.0, 0.0, (const double*)h->moments.p, nullptr)) return r2;
+        if (int r2 = md ? mdrnn_grad_device(h, 0.0, 0.0, (const double*)h->moments.p, nullptr)
+                        : grad_single_layer_device(h, 0.0, 0.0, 0.0, (const double*)h->moments.p, nullptr)) return r2;
         if (int r2 = ensure_bwd_image(h)) return r2;
         if (int r2 = launch_update(h, adam_lr_t(learning_rates[k], beta1, beta2, t.adam_t + k + 1), beta1, beta2, epsilon)) return r2;
     }

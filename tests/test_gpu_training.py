@@ -159,14 +159,18 @@ def test_run_1dtfim_reaches_the_exact_ground_state_energy():
     # the float64 GRU on the 2D lattice (2DTFIM_1DRNN), whose driver adapts the learning rate every iteration
     ("2d1d", dict(systemsize_x=3, systemsize_y=3, num_units=20, numsamples=100, learningrate=1e-3)),
     ("2d1d", dict(systemsize_x=4, systemsize_y=3, num_units=10, numsamples=100, learningrate=1e-3, num_layers=2)),
+    # the 2D RNN (2DTFIM_2DRNN): 2 + 2 padded units of the 4-unit remainder tile, a full tile, the driver's 50 units
+    ("2d2d", dict(systemsize_x=3, systemsize_y=3, num_units=10, numsamples=100, learningrate=5e-3)),
+    ("2d2d", dict(systemsize_x=4, systemsize_y=3, num_units=16, numsamples=200, learningrate=5e-3)),
+    ("2d2d", dict(systemsize_x=4, systemsize_y=4, num_units=50, numsamples=500, learningrate=5e-3)),
 ])
 def test_device_resident_training_equals_the_host_optimizer_bit_for_bit(kind, kw, monkeypatch):
-    """50 iterations of run_1DTFIM / run_J1J2 with the whole iteration on the device (rnnwf_train_steps: gradient from the
+    """50 iterations of each of the four drivers with the whole iteration on the device (rnnwf_train_steps: gradient from the
     device-resident moments, Adam and the re-pack of every weight image by the recorded packer tables, ten iterations per host
     synchronisation) against the same run with the optimizer and the packers on the host: energies, variances and final
     parameters are IDENTICAL - which also proves the re-packed images equal the host-packed ones bit for bit, step after step."""
     from rnnwavefunctions_amd import training as T
-    run = {"tfim": T.run_1DTFIM, "j1j2": T.run_J1J2, "2d1d": T.run_2DTFIM_1DRNN}[kind]
+    run = {"tfim": T.run_1DTFIM, "j1j2": T.run_J1J2, "2d1d": T.run_2DTFIM_1DRNN, "2d2d": T.run_2DTFIM_2DRNN}[kind]
     out = {}
     for mode in (True, False):
         monkeypatch.setattr(T, "DEVICE_TRAINING", mode)
@@ -204,12 +208,23 @@ def test_device_adam_step_and_checkpointed_state(tmp_path, monkeypatch):
             assert np.array_equal(dev[k], host[k]), (it, k)
     mflat, vflat, t = wf.adam_get_state()
     assert t == 3 and np.array_equal(mflat, opt.to_flat(wf, prm, SCOPE)[0]) and np.array_equal(vflat, opt.to_flat(wf, prm, SCOPE)[1])
-    # the 2D RNN keeps the host optimizer and says so
+    # the 2D RNN: the same, and a step without a gradient is refused
+    prm2 = P.init_mdrnn_params(10, seed=1)
+    shapes2 = {k[len(SCOPE) + 1:]: v.shape for k, v in prm2.items()}
     wf2 = _lib.NativeWavefunction(_lib.MODEL_MDRNN2D, 3, 3, (10,))
-    wf2.set_params(P.init_mdrnn_params(10, seed=1), scope=SCOPE)
-    assert not wf2.device_training_supported()
-    with pytest.raises((ValueError, _lib.RnnwfError), match="not available"):
+    wf2.set_params(prm2, scope=SCOPE)
+    assert wf2.device_training_supported()
+    with pytest.raises((ValueError, _lib.RnnwfError), match="no gradient"):
         wf2.adam_step(1e-3)
+    opt2, host2 = T.Adam(), dict(prm2)
+    for it in range(3):
+        m = wf2.vmc_step(100, seed=3, step=it, couplings=np.append(np.ones(9), 2.0))["moments"]
+        g = wf2.vmc_gradient(m[0] / m[2], m[2], shapes2)
+        host2 = opt2.step(host2, {SCOPE + "/" + k: v for k, v in g.items()}, 5e-3)
+        wf2.adam_step(5e-3)
+        dev2 = wf2.get_params_dict(prm2, SCOPE)
+        for k in prm2:
+            assert np.array_equal(dev2[k], host2[k]), (it, k)
     # saving cadence: files of both loops
     files = {}
     for mode in (True, False):
