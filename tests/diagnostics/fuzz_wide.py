@@ -1,5 +1,5 @@
 """Random widths, layer counts and models (one to four layers of any widths, single layers up to 150 units): local energies against the
-float64 oracle, gradients against its finite differences.  python tools/fuzz_wide.py SEED TRIALS (GPU box)."""
+float64 oracle, gradients against its finite differences.  python tests/diagnostics/fuzz_wide.py SEED TRIALS (GPU box)."""
 import sys, os, time
 sys.path.insert(0, os.getcwd())
 import numpy as np

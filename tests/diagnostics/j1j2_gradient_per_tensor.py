@@ -1,6 +1,6 @@
 """Per-tensor check of the complex RNN's gradient against float64 finite differences of the oracle's cost, at the reference run script's
 size and on initial (unscaled) weights - every tensor relative to ITS OWN largest entry (the unit test normalises by the global maximum).
-python tools/j1j2_gradient_per_tensor.py"""
+python tests/diagnostics/j1j2_gradient_per_tensor.py"""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np

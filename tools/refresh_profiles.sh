@@ -1,12 +1,15 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root):  tools/refresh_profiles.sh <tag>     e.g.  r01_e
+# usage (on the GPU box, from the repo root):  tools/refresh_profiles.sh <tag> [bench|prof|all]     e.g.  r04_z bench
+# (two gpurun calls of <= 20 minutes each: "bench" = the bench / train lines, "prof" = rocprofv3 stats and counters)
 # Writes gpurun_out/<tag>_*: bench lines of the five BASELINE configs, rocprofv3 kernel stats (cfg2, cfg3, cfg4),
 # FETCH_SIZE / WRITE_SIZE passes of cfg2, cfg4 and cfg5 (separate --pmc runs, as the gfx950 guide prescribes).
 tag=${1:-r01_x}
+part=${2:-all}
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out
 set -o pipefail
 cd $R
+if [ $part != prof ]; then
 for w in cfg1 cfg2 cfg3 cfg4 cfg5; do
   extra="--no-cpu-baseline"; [ $w = cfg2 ] && extra=""
   steps=20; [ $w = cfg5 ] && steps=5; [ $w = cfg4 ] && steps=10
@@ -23,6 +26,9 @@ done
 for w in cfg2 cfg3; do
   RNNWF_ENGINE=f32 timeout -k 10 200 python bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline --no-alt-engine > $out/${tag}_bench_${w}_engine_f32.json 2>/dev/null || exit 1
 done
+echo "bench part done"
+fi
+[ $part = bench ] && exit 0
 cd /tmp && export TMPDIR=/tmp
 for w in cfg1 cfg2 cfg3 cfg4 cfg5 cfg2_parity cfg2_l2 cfg2_l3 cfg3_l2; do
   steps=10; [ $w = cfg5 ] && steps=4
@@ -35,25 +41,11 @@ for w in cfg2 cfg4 cfg5; do
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/${tag}_pmc_${w}_$c -- python3 $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-alt-engine --no-parity > $out/${tag}_pmc_${w}_$c.log 2>&1 || { echo "pmc $w $c failed"; exit 1; }
   done
 done
-# SQ counters of the dominant kernels at config 2 (one pass per counter set; no trace domains besides --kernel-trace)
-for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" "SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES"; do
-  t=$(echo $set | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/${tag}_sq_cfg2/$t -- python3 $R/bench.py --workload cfg2 --steps 2 --warmup 1 --no-cpu-baseline --no-alt-engine --no-parity > $out/${tag}_sq_cfg2_$t.log 2>&1 || echo "sq set failed: $set"
+# SQ counters and held clocks of the dominant kernels (one pass per counter set; no trace domains besides --kernel-trace)
+for w in cfg2 cfg4 cfg5; do
+  bash $R/tools/sq_counters.sh $w $tag > $out/${tag}_sq_$w.log 2>&1 || echo "sq counters $w failed"
 done
-python3 - <<PY
-import csv, glob, collections
-root = "$out/${tag}_sq_cfg2"
-agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(lambda: collections.defaultdict(int))
-for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][:70]
-        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
-with open("$out/${tag}_sq_cfg2_summary.txt", "w") as o:
-    for k in agg:
-        o.write(k + "\n")
-        for c in sorted(agg[k]):
-            o.write("    %-28s per launch %.6g  (launches %d)\n" % (c, agg[k][c] / cnt[k][c], cnt[k][c]))
-PY
+cd /tmp
 python3 - <<PY
 import csv, glob, json, collections
 out = "$out"; tag = "$tag"
@@ -85,6 +77,17 @@ for w, sub in (("cfg2", "flip"), ("cfg4", "mdrnn_flip"), ("cfg5", "flip")):
                       "hbm_bytes_per_launch": 2 * fetch + write, "build": tag,
                       "source": "gpurun_out/%s_pmc_%s_{FETCH,WRITE}_SIZE (rocprofv3 --pmc, separate passes, tools/refresh_profiles.sh); "
                                 "FETCH_SIZE doubled as the gfx950 guide prescribes" % (tag, w)}
+# the clock each dominant kernel holds, from the same call's GRBM_GUI_ACTIVE pass (tools/sq_counters.sh)
+import re
+for w in traffic:
+    try:
+        txt = open("%s/%s_sq_%s_summary.txt" % (out, tag, w)).read()
+    except OSError:
+        continue
+    m = re.search(re.escape(traffic[w]["kernel"][:70]) + r".*?held clock[^:]*: ([0-9.]+) GHz", txt, re.S)
+    if m:
+        traffic[w]["held_clock_ghz"] = float(m.group(1))
+        traffic[w]["held_clock_source"] = "profiles/%s_sq_%s_summary.txt (rocprofv3 --pmc GRBM_GUI_ACTIVE / 8 XCDs / kernel duration, tools/sq_counters.sh)" % (tag, w)
 json.dump(traffic, open("%s/%s_pmc_traffic.json" % (out, tag), "w"), indent=1)
 PY
 echo refresh done
