@@ -239,7 +239,7 @@ int launch_update(rnnwf_handle* h, double lr_t, double b1, double b2, double eps
     if (t.dw_f64) grad_flat_kernel<double><<<blocks, 256, 0, h->stream>>>((const int32_t*)t.gidx.p, t.nparams, (const double*)h->gradW.p, (double*)t.G.p);
     else grad_flat_kernel<float><<<blocks, 256, 0, h->stream>>>((const int32_t*)t.gidx.p, t.nparams, (const float*)h->gradW.p, (double*)t.G.p);
     RNNWF_HIP(h, hipGetLastError());
-    if (h->comm && h->nranks > 1)
+    if (h->comm)                                                                          // (also with a one-rank communicator: the single-GPU test walks the road)
         if (int rc = comm_allreduce_device(h, t.G.p, (size_t)t.nparams)) return rc;       // one in-stream RCCL sum of the gradient
     adam_kernel<<<blocks, 256, 0, h->stream>>>((double*)t.P.p, (double*)t.M.p, (double*)t.V.p, (const double*)t.G.p, t.nparams, lr_t, b1, b2, eps,
                                                h->f64 ? 0 : 1);
@@ -265,7 +265,7 @@ double adam_lr_t(double lr, double b1, double b2, int64_t t) {
 // the call, 0 when the caller must take the staged road, < 0 on error.
 int rnnwf::train_allreduce_grads_device(rnnwf_handle* h) {
     TrainState& t = h->train;
-    if (!h->comm || h->nranks < 2 || !h->gradW.p) return 0;
+    if (!h->comm || !h->gradW.p) return 0;
     if (!t.built) { if (build(h) != 0) { h->err.clear(); return 0; } }
     if (!t.supported) return 0;
     const unsigned blocks = (unsigned)((t.nparams + 255) / 256);

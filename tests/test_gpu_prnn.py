@@ -277,6 +277,21 @@ def test_rccl_all_reduce_single_rank():
     m0 = wf.vmc_step(64, seed=3, step=0, couplings=c)["moments"]
     wf.comm_reduce_in_step(True)
     assert np.array_equal(wf.vmc_step(64, seed=3, step=0, couplings=c)["moments"], m0)
+    # the gradient's two collectives, walked with the one-rank communicator (a sum over one rank changes nothing): rnnwf_allreduce_grads
+    # on the device-side flat gradient, and the in-stream all-reduce inside rnnwf_train_steps
+    shapes = {k[len(SCOPE) + 1:]: v.shape for k, v in prm.items()}
+    g0 = wf.vmc_gradient(m0[0] / m0[2], m0[2], shapes)
+    g1 = wf.vmc_gradient(m0[0] / m0[2], m0[2], shapes, allreduce=True)           # rnnwf_allreduce_grads
+    for k in g0:
+        assert np.array_equal(g0[k], g1[k]), k
+    plain = make_wf(_lib.MODEL_GRU1D, 8, 10, prm)
+    lrs = [5e-3] * 10
+    ma = wf.train_steps(64, 3, 0, c, lrs)
+    mb = plain.train_steps(64, 3, 0, c, lrs)
+    assert np.array_equal(ma, mb) and ma[0][0] != ma[-1][0]
+    pa, pb = wf.get_params_dict(prm, SCOPE), plain.get_params_dict(prm, SCOPE)
+    for k in prm:
+        assert np.array_equal(pa[k], pb[k]), k
     with pytest.raises(ValueError):
         wf.comm_init(uid, 3, 2)
 
