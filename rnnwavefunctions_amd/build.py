@@ -20,7 +20,13 @@ SOURCES = ["rnnwf_api.hip", "prnn.hip", "crnn.hip", "split.hip", "split_stream.h
 # train.hip (device-side Adam and image re-pack) must round every operation on its own, as NumPy and the host packers do: no
 # contraction into fused multiply-adds (HIP's __dmul_rn / __dadd_rn are plain operators and were fused under -ffp-contract=fast;
 # found by tests/test_gpu_training.py: test_device_adam_step_and_checkpointed_state)
-PER_SOURCE_FLAGS = {"split.hip": ["-fno-slp-vectorize"], "split_stream.hip": ["-fno-slp-vectorize"], "train.hip": ["-ffp-contract=off"]}
+# prnn.hip / crnn.hip: the streamed-weight products of the 133..260-unit kernels (gru_core.h: mfma_streamed, 160 k-groups x 5 tiles) must
+# unroll completely - their fragment ring is indexed by the loop counter.  Past clang's default size budget for `#pragma unroll` the loop
+# stayed rolled, the ring went to scratch memory and the 260-unit flip pass ran at 587 ms per config-2-sized step instead of 95
+# (profiles/r04_m_wide_widths.txt); the budget is raised for these two translation units.
+WIDE_UNROLL = ["-mllvm", "-pragma-unroll-threshold=400000"]
+PER_SOURCE_FLAGS = {"split.hip": ["-fno-slp-vectorize"], "split_stream.hip": ["-fno-slp-vectorize"], "train.hip": ["-ffp-contract=off"],
+                    "prnn.hip": WIDE_UNROLL, "crnn.hip": WIDE_UNROLL}
 # the 100-unit bf16x3 kernel keeps its 160 accumulator registers in AGPRs (a wave addresses 256 VGPRs + 256 AGPRs; its
 # other live values need ~210 VGPRs): no -amdgpu-mfma-vgpr-form for its translation unit
 AGPR_FORM_SOURCES = {"split_stream.hip"}

@@ -114,7 +114,8 @@ struct GruCore {
     static __device__ __forceinline__ void mfma_streamed(const char* img, const T (&h)[KT], V4 (&acc)[NT], int lane) {
         typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
         const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(img), 0, (int)L::OFF_BINIT, 0x00020000);
-        constexpr int NTG = (NT + TC - 1) / TC, NGR = NG * NTG, AHEAD = 2;
+        // (133..260 units run one wave per SIMD - nothing else hides the L2 latency: four groups ahead instead of two)
+        constexpr int NTG = (NT + TC - 1) / TC, NGR = NG * NTG, AHEAD = NFULL >= 12 ? 4 : 2;
         VA ring[AHEAD + 1][TC];
         auto request = [&](int k, VA (&dstv)[TC]) {
             const int g = k / NTG, t0 = (k % NTG) * TC;
@@ -131,12 +132,16 @@ struct GruCore {
         for (int k = 0; k < NGR; ++k) {
             if (k + AHEAD < NGR) request(k + AHEAD, ring[(k + AHEAD) % (AHEAD + 1)]);
             asm volatile("" ::: "memory");
+            // one wave per SIMD: left alone, the scheduler sinks every request down to its first use (short live ranges) and the
+            // wave waits out a full L2 round trip per group - 60 % of its cycles at 260 units (profiles/r04_m_wide_widths.txt)
+            if constexpr (NFULL >= 12) __builtin_amdgcn_sched_barrier(0);
             const int g = k / NTG, t0 = (k % NTG) * TC;
 #pragma unroll
             for (int j = 0; j < VW; ++j)
 #pragma unroll
                 for (int t = 0; t < TC; ++t)
                     if (t0 + t < NT) acc[t0 + t] = F::mfma(ring[k % (AHEAD + 1)][t][j], h[g * VW + j], acc[t0 + t]);
+            if constexpr (NFULL >= 12) __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
