@@ -17,6 +17,23 @@ if sys.argv[1:2] == ["stacks"]:
             wf.vmc_step(ns, seed=1, step=1 + i, couplings=c)
         print("stack units=%-22s engine=%-7s step %8.3f ms" % (units, wf.engine_name(), (time.perf_counter() - t0) / 3 * 1e3), flush=True)
     sys.exit(0)
+if sys.argv[1:2] == ["f64"]:
+    for H in [36, 52, 68, 84, 100]:
+        prm = P.init_gru_params([H], seed=1, dtype=np.float64)
+        wf = _lib.NativeWavefunction(_lib.MODEL_GRU1D_F64, 8, 8, (H,))
+        wf.set_params(prm, scope="RNNwavefunction")
+        c = np.append(np.ones(64), 2.0)
+        wf.vmc_step(4000, seed=1, step=0, couplings=c)
+        wf.timing_enable(1); wf.timing_reset()
+        t0 = time.perf_counter()
+        for i in range(3):
+            wf.vmc_step(4000, seed=1, step=1 + i, couplings=c)
+        dt = (time.perf_counter() - t0) / 3
+        flip = wf.timing_get(1)
+        cells = 64 * 65 / 2 * 4000
+        print("f64 GRU 8x8 H=%3d step %8.3f ms  flip %8.3f ms  %.1f TF/s algorithmic" % (H, dt * 1e3, flip["total_ms"] / max(flip["launches"], 1),
+              cells * 6.0 * H * H / (flip["total_ms"] / max(flip["launches"], 1) * 1e-3) / 1e12), flush=True)
+    sys.exit(0)
 if sys.argv[1:2] == ["grad"]:
     for H in [50, 100, 132, 196, 260]:
         prm = P.init_gru_params([H], seed=1)
