@@ -68,6 +68,22 @@ template <int NFULL, int NL, int WAVES>
 struct CMLaunch {
     using M = CrnnMlCore<NFULL, NL>;
     static int base(rnnwf_handle* h, const CrnnArgs& a) {
+        // all layers' images resident in LDS (up to 52 units): the gate tiles of every layer spread over NFULL + 1 waves per block of
+        // 16 chains (ml_coop.h) - for every batch size, its accumulation order is not the one-wave kernel's; RNNWF_NO_COOP=1 keeps that one
+        if constexpr (MlCoopLayout<NFULL, NL, 3>::FITS && M::SPILL == 0) {
+            if (!h->knobs.no_coop) {
+                using ML = MlCoopLayout<NFULL, NL, 3>;
+                const void* cfn = (const void*)crnn_base_coop_kernel<NFULL, false, NL>;
+                int cb = 0;
+                if (int rc = rnnwf::blocks_per_cu(h, cfn, ML::THREADS, ML::LDS, &cb)) return rc;
+                const int64_t need = (a.nsb + ML::NB - 1) / ML::NB;
+                const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(need, (int64_t)cb * h->cu_count));
+                TimedLaunch tl(h, 0);
+                crnn_base_coop_kernel<NFULL, false, NL><<<grid, ML::THREADS, ML::LDS, h->stream>>>(a);
+                RNNWF_HIP(h, hipGetLastError());
+                return 0;
+            }
+        }
         const void* fn = (const void*)crnn_ml_base_kernel<NFULL, NL, WAVES>;
         int bpc = 0;
         if (int rc = rnnwf::blocks_per_cu(h, fn, WAVES * 64, M::BYTES, &bpc)) return rc;

@@ -135,8 +135,9 @@ __global__ void __launch_bounds__(WAVES * 64) crnn_base_kernel(CrnnArgs a) {
 
 // The same pass with NFULL + 1 waves per block of 16 chains (gru_kernels.h, coop_base_pass): used when there are fewer
 // blocks than SIMDs.  Bit-identical to crnn_base_kernel.
-template <int NFULL, bool BF = false>
-__global__ void __launch_bounds__(BF ? (NFULL + 2) * 64 * BaseBfLayout<NFULL>::NB : (NFULL + 1) * 64) crnn_base_coop_kernel(CrnnArgs a) {
+template <int NFULL, bool BF = false, int NL = 1>
+__global__ void __launch_bounds__((NL > 1 ? MlCoopLayout<NFULL, NL, 3>::THREADS : BF ? (NFULL + 2) * 64 * BaseBfLayout<NFULL>::NB : (NFULL + 1) * 64))
+crnn_base_coop_kernel(CrnnArgs a) {
     using C = GruCore<float, NFULL, 3>;
     constexpr int KT = C::KT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -189,7 +190,8 @@ __global__ void __launch_bounds__(BF ? (NFULL + 2) * 64 * BaseBfLayout<NFULL>::N
                 if (a.out_logp) a.out_logp[s] = 2.0 * re;
             }
         };
-    if constexpr (BF) coop_base_pass_bf<NFULL, 3>(lds, a.wimg, a.wbf, N, a.nsb, a.hck, begin, site, end);
+    if constexpr (NL > 1) coop_ml_base_pass<NFULL, NL, 3>(lds, a.wimg, N, a.nsb, a.hck, begin, site, end);      // stacked layers (ml_coop.h)
+    else if constexpr (BF) coop_base_pass_bf<NFULL, 3>(lds, a.wimg, a.wbf, N, a.nsb, a.hck, begin, site, end);
     else coop_base_pass<NFULL, 3>(lds, a.wimg, N, a.nsb, a.hck, 0, begin, site, end);
 }
 

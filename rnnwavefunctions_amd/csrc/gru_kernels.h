@@ -15,6 +15,7 @@
 //   lpq  [N+1][ns]            f64   row 0: log P(s); row k+1: log P(s with site k flipped)
 #pragma once
 #include "gru_core.h"
+#include "ml_coop.h"
 #include "split_core.h"
 
 namespace rnnwf {
@@ -418,8 +419,10 @@ __device__ __forceinline__ void coop_base_pass_bf(char* lds, const void* wimg, c
 #endif
 }
 
-template <int NFULL, bool BF = false>
-__global__ void __launch_bounds__(BF ? (NFULL + 2) * 64 * BaseBfLayout<NFULL>::NB : (NFULL + 1) * 64) prnn_base_coop_kernel(PrnnArgs a) {
+// NL > 1: stacked layers (ml_coop.h), same hooks
+template <int NFULL, bool BF = false, int NL = 1>
+__global__ void __launch_bounds__((NL > 1 ? MlCoopLayout<NFULL, NL, 1>::THREADS : BF ? (NFULL + 2) * 64 * BaseBfLayout<NFULL>::NB : (NFULL + 1) * 64))
+prnn_base_coop_kernel(PrnnArgs a) {
     using C = GruCore<float, NFULL, 1>;
     constexpr int KT = C::KT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -473,7 +476,8 @@ __global__ void __launch_bounds__(BF ? (NFULL + 2) * 64 * BaseBfLayout<NFULL>::N
                 if (a.out_lp) a.out_lp[s] = cum;
             }
         };
-    if constexpr (BF) coop_base_pass_bf<NFULL, 1>(lds, a.wimg, a.wbf, N, a.nsb, a.hck, begin, site, end, a.stamps);
+    if constexpr (NL > 1) coop_ml_base_pass<NFULL, NL, 1>(lds, a.wimg, N, a.nsb, a.hck, begin, site, end);
+    else if constexpr (BF) coop_base_pass_bf<NFULL, 1>(lds, a.wimg, a.wbf, N, a.nsb, a.hck, begin, site, end, a.stamps);
     else coop_base_pass<NFULL, 1>(lds, a.wimg, N, a.nsb, a.hck, a.ablate, begin, site, end);
 }
 
