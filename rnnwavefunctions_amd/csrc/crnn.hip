@@ -240,7 +240,6 @@ int j1j2_on_device(rnnwf_handle* h, int64_t ns, bool sampling, uint64_t seed, ui
     // the item counters are zeroed by the previous step's assembly kernel (j1j2_eloc_kernel); a memset only when that did not happen
     if (!h->j1j2_cnt_clean) RNNWF_HIP(h, hipMemsetAsync(cnt, 0, (size_t)N * 4, h->stream));
     h->j1j2_cnt_clean = false;
-    RNNWF_HIP(h, hipMemsetAsync(h->lpq.p, 0, (size_t)ns * 2 * N * sizeof(double2), h->stream));   // contrib: inactive bonds contribute 0
     J1J2Args e{};
     e.bits = (const uint32_t*)h->bits.p;
     e.ns = ns; e.N = N;

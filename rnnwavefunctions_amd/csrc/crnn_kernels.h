@@ -205,7 +205,7 @@ struct J1J2Args {
     int32_t* cnt;                 // [N] zeroed before launch
     SwapItem* items;              // [N][cap]
     int64_t cap;
-    double2* contrib;             // [ns][2N], every entry written here (0 for inactive bonds)
+    double2* contrib;             // [2N][ns] (bond slot major), every entry zeroed here; the swap pass overwrites the active bonds
     double* diag;                 // [ns]
 };
 
@@ -239,8 +239,10 @@ static __global__ void __launch_bounds__(256) j1j2_enumerate_kernel(J1J2Args a) 
         hi = site < t ? t : site;
         active = spin_of(a.bits, a.ns, s, lo) != spin_of(a.bits, a.ns, s, hi);
     }
-    // (contrib is zeroed by one contiguous memset before the launch: per-thread 16-byte stores at a 2N*16-byte
-    //  stride cost 80 of this kernel's 107 us at config 3)
+    // contrib [2N][ns] starts as zeros (inactive bonds contribute 0; the swap pass overwrites the active ones): with the bond-slot-major
+    // layout this thread's element is its wave's next 16 bytes - one coalesced store here instead of a 12.8 MB memset launch per step
+    // (round 1's sample-major layout made these stores cost 80 of this kernel's 107 us; hence the memset that stood here until round 4)
+    if (in_range) a.contrib[(int64_t)slot * a.ns + s] = make_double2(0.0, 0.0);
     // lo depends on the slot only, i.e. it is uniform over the block: ballot-ranked slots inside each wave, the four
     // waves' counts combined in LDS, ONE atomic per block (same-address atomics serialise at L2: 314 per counter
     // with one per wave at config 3, 79 now)
