@@ -363,7 +363,7 @@ struct TnGemmShape {
 // LAST: what this wave's chunk slot ILAST = (NC - 1) / WAVES holds: 0 nothing, 1 the row's narrow last chunk, 2 a full chunk.
 template <typename T, int PT, int QT, int WAVES, int LAST>
 __device__ __forceinline__ void tn_gemm_body(const T* __restrict__ P, const T* __restrict__ Q, int64_t r0, int64_t r1,
-                                             T* __restrict__ part, int wave, int li, int lk) {
+                                             T* __restrict__ part, int wave, int li, int lk, int q_stride) {
     using V4 = typename Frag<T>::V4;
     using CP = typename TnGemmShape<T, PT, QT>::CP;
     using CQ = typename TnGemmShape<T, PT, QT>::CQ;
@@ -395,7 +395,7 @@ __device__ __forceinline__ void tn_gemm_body(const T* __restrict__ P, const T* _
                     if (i == ILAST && LAST == 1) CP::template load<CP::WL>(prow + 16 * VW * WAVES * i, li, pv[s][i]);
                     else CP::template load<VW>(prow + 16 * VW * WAVES * i, li, pv[s][i]);
                 }
-                const T* qrow = Q + rc * CQ::COLS;
+                const T* qrow = Q + rc * q_stride;          // (Q points at this launch's first column: tn_gemm.h slices wide products)
 #pragma unroll
                 for (int c = 0; c < CQ::NC; ++c) {
                     if (c == CQ::NC - 1) CQ::template load<CQ::WL>(qrow + 16 * VQ * c, li, qv[s][c]);
@@ -447,7 +447,7 @@ __device__ __forceinline__ void tn_gemm_body(const T* __restrict__ P, const T* _
 
 template <typename T, int PT, int QT>
 __global__ void __launch_bounds__((TnGemmShape<T, PT, QT>::WAVES * 64)) tn_gemm_kernel(const T* __restrict__ P, const T* __restrict__ Q, int64_t R,
-                                                                                    int64_t rows_per_block, T* __restrict__ part) {
+                                                                                    int64_t rows_per_block, T* __restrict__ part, int q_stride) {
     using CP = typename TnGemmShape<T, PT, QT>::CP;
     constexpr int WAVES = TnGemmShape<T, PT, QT>::WAVES;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -455,15 +455,15 @@ __global__ void __launch_bounds__((TnGemmShape<T, PT, QT>::WAVES * 64)) tn_gemm_
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;      // the host launches ceil(R / rows_per_block) blocks: r0 < R
     const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
     constexpr int WLAST = (CP::NC - 1) % WAVES;            // the wave that owns the row's last chunk
-    if (wave < WLAST) tn_gemm_body<T, PT, QT, WAVES, 2>(P, Q, r0, r1, part, wave, li, lk);
-    else if (wave == WLAST) tn_gemm_body<T, PT, QT, WAVES, CP::WL == CP::VW ? 2 : 1>(P, Q, r0, r1, part, wave, li, lk);
-    else tn_gemm_body<T, PT, QT, WAVES, 0>(P, Q, r0, r1, part, wave, li, lk);
+    if (wave < WLAST) tn_gemm_body<T, PT, QT, WAVES, 2>(P, Q, r0, r1, part, wave, li, lk, q_stride);
+    else if (wave == WLAST) tn_gemm_body<T, PT, QT, WAVES, CP::WL == CP::VW ? 2 : 1>(P, Q, r0, r1, part, wave, li, lk, q_stride);
+    else tn_gemm_body<T, PT, QT, WAVES, 0>(P, Q, r0, r1, part, wave, li, lk, q_stride);
 }
 
 // dW[P column][Q column] += sum over the blocks' partial fragments, in a fixed order (no atomics: the weight gradients are
 // bit-reproducible).  One workgroup of 16 waves per output tile: wave w adds the blocks w, w + 16, ..., wave 0 the sixteen sums.
 template <typename T, int PT, int QT>
-__global__ void __launch_bounds__(1024) tn_reduce_kernel(const T* __restrict__ part, int nblocks, T* __restrict__ dW) {
+__global__ void __launch_bounds__(1024) tn_reduce_kernel(const T* __restrict__ part, int nblocks, T* __restrict__ dW, int dw_stride) {
     using V4 = typename Frag<T>::V4;
     using CP = typename TnGemmShape<T, PT, QT>::CP;
     using CQ = typename TnGemmShape<T, PT, QT>::CQ;
@@ -484,7 +484,7 @@ __global__ void __launch_bounds__(1024) tn_reduce_kernel(const T* __restrict__ p
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int fr = sizeof(T) == 4 ? 4 * lk + rr : lk + 4 * rr;      // C/D fragment row of (lane quarter lk, register rr)
-        dW[(size_t)CP::col(c, fr, jp) * CQ::COLS + CQ::col(cq, li, t % VQ)] += v[rr];
+        dW[(size_t)CP::col(c, fr, jp) * dw_stride + CQ::col(cq, li, t % VQ)] += v[rr];      // (dW points at this launch's first column)
     }
 }
 

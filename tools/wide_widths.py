@@ -43,10 +43,13 @@ if sys.argv[1:2] == ["grad"]:
         c = np.append(np.ones(N), 1.0)
         m = wf.vmc_step(ns, seed=1, step=0, couplings=c)["moments"]
         wf.vmc_gradient(m[0] / m[2], m[2], shapes)
+        wf.timing_enable(1); wf.timing_reset()
         wf.synchronize(); t0 = time.perf_counter()
         for i in range(3):
             wf.vmc_gradient(m[0] / m[2], m[2], shapes)
-        print("gradient H=%3d  %8.3f ms" % (H, (time.perf_counter() - t0) / 3 * 1e3), flush=True)
+        bptt, gemm = wf.timing_get(3), wf.timing_get(4)
+        print("gradient H=%3d  %8.3f ms   (BPTT kernel %.3f ms, weight-gradient GEMM %.3f ms per call)" %
+              (H, (time.perf_counter() - t0) / 3 * 1e3, bptt["total_ms"] / 3, gemm["total_ms"] / 3), flush=True)
     sys.exit(0)
 for H in [int(a) for a in sys.argv[1:]] or [50, 68, 100, 104, 128, 132, 160, 200, 256]:
     prm = P.init_gru_params([H], seed=1)
