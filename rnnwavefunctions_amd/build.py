@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "librnnwf_hip.so")
-SOURCES = ["rnnwf_api.hip", "prnn.hip", "crnn.hip", "split.hip", "split_stream.hip", "mdrnn.hip", "grad.hip", "comm.hip", "train.hip"]
+SOURCES = ["rnnwf_api.hip", "prnn.hip", "crnn.hip", "split.hip", "split_stream.hip", "mdrnn.hip", "grad.hip", "comm.hip", "train.hip", "grad_wide.hip"]
 # no SLP packing of adjacent f32 adds / fmas into v_pk_*_f32 in the bf16x3 engine's translation unit: packed-f32 (and v_dot2)
 # instructions stall behind bf16 MFMAs - their own wave's AND the SIMD partner's (measured: tools/microbench/issue_model,
 # a VALU segment with packed ops beside an MFMA partner 5 170 vs 3 337 cycles).  The f32-input-MFMA kernels keep it.
@@ -26,10 +26,10 @@ SOURCES = ["rnnwf_api.hip", "prnn.hip", "crnn.hip", "split.hip", "split_stream.h
 # (profiles/r04_m_wide_widths.txt); the budget is raised for these two translation units.
 WIDE_UNROLL = ["-mllvm", "-pragma-unroll-threshold=400000"]
 PER_SOURCE_FLAGS = {"split.hip": ["-fno-slp-vectorize"], "split_stream.hip": ["-fno-slp-vectorize"], "train.hip": ["-ffp-contract=off"],
-                    "prnn.hip": WIDE_UNROLL, "crnn.hip": WIDE_UNROLL}
+                    "prnn.hip": WIDE_UNROLL, "crnn.hip": WIDE_UNROLL, "grad_wide.hip": WIDE_UNROLL}
 # the 100-unit bf16x3 kernel keeps its 160 accumulator registers in AGPRs (a wave addresses 256 VGPRs + 256 AGPRs; its
 # other live values need ~210 VGPRs): no -amdgpu-mfma-vgpr-form for its translation unit
-AGPR_FORM_SOURCES = {"split_stream.hip"}
+AGPR_FORM_SOURCES = {"split_stream.hip", "grad_wide.hip"}     # grad_wide.hip: see its header (a compiler crash in the VGPR form)
 MFMA_VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",

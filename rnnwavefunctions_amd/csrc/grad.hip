@@ -52,8 +52,20 @@ struct GLaunch {
         return img;
     }
 
+    // the three shapes whose 4-wave kernel only grad_wide.hip's translation unit can compile (see there): -1 otherwise
+    static constexpr int WIDE = (std::is_same<T, float>::value && NOUT == 3 && WAVES == 4) ? (NFULL == 8 ? 0 : NFULL == 12 ? 1 : -1)
+                              : (std::is_same<T, double>::value && NOUT == 1 && WAVES == 4 && NFULL == 6) ? 2 : -1;
+    static const void* kernel() {
+        if constexpr (WIDE >= 0) return grad_wide_kernel(WIDE);
+        else return (const void*)gru_bwd_kernel<T, NFULL, WAVES, NOUT>;
+    }
+    static void launch(unsigned grid, size_t lds, hipStream_t stream, const GradArgs& a) {
+        if constexpr (WIDE >= 0) grad_wide_launch(WIDE, grid, lds, stream, a);
+        else gru_bwd_kernel<T, NFULL, WAVES, NOUT><<<grid, WAVES * 64, lds, stream>>>(a);
+    }
+
     static int run(rnnwf_handle* h, GradArgs a, int64_t R, void* dW) {
-        const void* fn = (const void*)gru_bwd_kernel<T, NFULL, WAVES, NOUT>;
+        const void* fn = kernel();
         const size_t lds = LDS;
         if (lds > 160 * 1024)
             return h->fail(RNNWF_ERR_INVALID, "rnnwf_vmc_gradient: forward + backward weight images (%zu B) exceed the 160 KB LDS", lds);
@@ -67,7 +79,7 @@ struct GLaunch {
         a.head_part = part;
         {
             TimedLaunch tl(h, 3);
-            gru_bwd_kernel<T, NFULL, WAVES, NOUT><<<grid, WAVES * 64, lds, h->stream>>>(a);
+            launch(grid, lds, h->stream, a);
             head_reduce_launch<T>(h, (size_t)grid * WAVES, HN, (T*)a.head_grad);
         }
         RNNWF_HIP(h, hipGetLastError());
@@ -154,8 +166,8 @@ struct GLaunch {
                 case 3: { using K = GLaunch<float, 3, 4, 3>; EXPR; }    \
                 case 4: { using K = GLaunch<float, 4, 4, 3>; EXPR; }    \
                 case 6: { using K = GLaunch<float, 6, 4, 3>; EXPR; }    \
-                case 8: { using K = GLaunch<float, 8, 8, 3>; EXPR; }    /* 8 waves: with AGPRs in reach hipcc 7.2 crashes in */ \
-                case 12: { using K = GLaunch<float, 12, 8, 3>; EXPR; }  /* 'AMDGPU Rewrite AGPR-Copy-MFMA' on these two      */ \
+                case 8: { using K = GLaunch<float, 8, 4, 3>; EXPR; }    /* these two and the float64 GRU's widest: the      */ \
+                case 12: { using K = GLaunch<float, 12, 4, 3>; EXPR; }  /* kernels live in grad_wide.hip (GLaunch::WIDE)    */ \
                 case 16: { using K = GLaunch<float, 16, 4, 3>; EXPR; }  \
             }                                                           \
         } else if ((h)->model == RNNWF_MODEL_GRU1D_F64) {               \
@@ -164,7 +176,7 @@ struct GLaunch {
                 case 2: { using K = GLaunch<double, 2, 4, 1>; EXPR; }   \
                 case 3: { using K = GLaunch<double, 3, 4, 1>; EXPR; }   \
                 case 4: { using K = GLaunch<double, 4, 4, 1>; EXPR; }   \
-                case 6: { using K = GLaunch<double, 6, 8, 1>; EXPR; }   /* 8 waves: see the complex RNN's wide cases */ \
+                case 6: { using K = GLaunch<double, 6, 4, 1>; EXPR; }   /* kernel in grad_wide.hip */ \
             }                                                           \
         } else {                                                        \
             switch ((h)->NFULL) {                                       \

@@ -94,6 +94,10 @@ int mdrnn_load_batch(rnnwf_handle* h, const int32_t* samples, int64_t ns);
 
 // ---- gradient (grad.hip) ---------------------------------------------------------------------------
 int mdrnn_vmc_gradient(rnnwf_handle* h, double mean_energy, double norm);
+// grad_wide.hip: backward kernels compiled in their own translation unit (0: complex RNN 101..132 units, 1: 133..196, 2: float64 GRU 69..100)
+struct GradArgs;
+const void* grad_wide_kernel(int which);
+void grad_wide_launch(int which, unsigned grid, size_t lds, hipStream_t stream, const GradArgs& a);
 int mdrnn_grad_device(rnnwf_handle* h, double mean_energy, double norm, const double* mom_dev, size_t* dw_count);
 int mdrnn_pack_table(rnnwf_handle* h, bool backward);
 int mdrnn_grad_probe(rnnwf_handle* h, std::vector<int32_t>& sidx, size_t* dw_count);
