@@ -52,8 +52,9 @@ struct GLaunch {
         return img;
     }
 
-    // the three shapes whose 4-wave kernel only grad_wide.hip's translation unit can compile (see there): -1 otherwise
-    static constexpr int WIDE = (std::is_same<T, float>::value && NOUT == 3 && WAVES == 4) ? (NFULL == 8 ? 0 : NFULL == 12 ? 1 : -1)
+    // the wide shapes, whose kernels live in grad_wide.hip's translation unit (see there): -1 otherwise
+    static constexpr int WIDE = (std::is_same<T, float>::value && NOUT == 3 && WAVES == 4) ? (NFULL == 8 ? 0 : NFULL == 12 ? 1 : NFULL == 16 ? 3 : -1)
+                              : (std::is_same<T, float>::value && NOUT == 1 && WAVES == 4) ? (NFULL == 8 ? 4 : NFULL == 12 ? 5 : NFULL == 16 ? 6 : -1)
                               : (std::is_same<T, double>::value && NOUT == 1 && WAVES == 4 && NFULL == 6) ? 2 : -1;
     static const void* kernel() {
         if constexpr (WIDE >= 0) return grad_wide_kernel(WIDE);
@@ -64,7 +65,34 @@ struct GLaunch {
         else gru_bwd_kernel<T, NFULL, WAVES, NOUT><<<grid, WAVES * 64, lds, stream>>>(a);
     }
 
+    // small batches: two waves per block of 16 chains (grad_kernels.h: GradPair) while every pair still gets SIMDs of its own
+    static constexpr bool PAIR_OK = WIDE < 0 && std::is_same<T, float>::value && WAVES == 4 && GradPair<T, NFULL, NOUT>::FITS;
+    static int run_pair(rnnwf_handle* h, GradArgs a, int64_t R, void* dW) {
+        if constexpr (PAIR_OK) {
+            using GP = GradPair<T, NFULL, NOUT>;
+            const void* fn = (const void*)gru_bwd_kernel<T, NFULL, 2 * GP::NB, NOUT, true>;
+            int bpc = 0;
+            if (int rc = rnnwf::blocks_per_cu(h, fn, 2 * GP::NB * 64, GP::LDS, &bpc)) return rc;
+            const int64_t need = (a.nsb + GP::NB - 1) / GP::NB;
+            const unsigned grid = (unsigned)std::min<int64_t>(need, (int64_t)bpc * h->cu_count);
+            constexpr int HN = NOUT * G::HEAD_ROW;
+            T* part = nullptr;
+            if (int rc = head_part_alloc<T>(h, (size_t)grid * GP::NB, HN, &part)) return rc;
+            a.head_part = part;
+            {
+                TimedLaunch tl(h, 3);
+                gru_bwd_kernel<T, NFULL, 2 * GP::NB, NOUT, true><<<grid, 2 * GP::NB * 64, GP::LDS, h->stream>>>(a);
+                head_reduce_launch<T>(h, (size_t)grid * GP::NB, HN, (T*)a.head_grad);
+            }
+            RNNWF_HIP(h, hipGetLastError());
+            return tn_gemm_launch<T, G::PCOLS / 16, G::QCOLS / 16>(h, (const T*)a.P, (const T*)a.Q, R, (T*)dW);
+        }
+        return RNNWF_ERR_INVALID;
+    }
+
     static int run(rnnwf_handle* h, GradArgs a, int64_t R, void* dW) {
+        if constexpr (PAIR_OK)
+            if (a.nsb <= (int64_t)GradPair<T, NFULL, NOUT>::NB * h->cu_count && !h->knobs.no_coop) return run_pair(h, a, R, dW);
         const void* fn = kernel();
         const size_t lds = LDS;
         if (lds > 160 * 1024)

@@ -101,7 +101,22 @@ __global__ void __launch_bounds__(1024) head_reduce_kernel(const T* __restrict__
 // NOUT = 1: positive RNN, L = sum_s w_s log P(s).
 // NOUT = 3: complex RNN, L = sum_s [w_re Re log psi(s) + w_im Im log psi(s)]  (J1J2/TrainingRNN_J1J2.py:197:
 //           cost = 2 Re(mean(conj(log psi) E) - conj(mean log psi) mean E); the factor 2 is in inv_norm).
-template <typename T, int NFULL, int WAVES, int NOUT>
+// PAIR (small batches: fewer blocks of 16 chains than SIMD pairs): two waves per block.  Wave F re-runs the forward step of site n - 1
+// (state from the checkpoint, gates, head) while wave B takes site n's derivatives and the transposed products - the two halves of an
+// iteration do not depend on each other, only B's chain dL/dh_n -> dL/dh_{n-1} is sequential.  F hands (h, h', r, u, c, q, z) to B
+// through LDS, two workgroup barriers per site.  At the reference run script's size (N = 20, 50 units, 500 samples = 32 blocks) this
+// kernel is half of a training iteration's device time and every site costs a lone wave 15 000 cycles (profiles/r04_y_small_iteration.txt).
+template <typename T, int NFULL, int NOUT>
+struct GradPair {
+    static constexpr int KT = GruLayout<T, NFULL, NOUT>::KT;
+    static constexpr int NB = 2;                                                   // blocks per workgroup (four waves, one per SIMD)
+    static constexpr size_t SLOT = ((size_t)(6 * KT + NOUT) * 64 * sizeof(T) + 15) / 16 * 16;
+    static constexpr size_t IMG = GruLayout<T, NFULL, NOUT>::BYTES + GradLayout<NFULL, T>::BWD_BYTES;
+    static constexpr size_t LDS = IMG + NB * SLOT;
+    static constexpr bool FITS = !GruLayout<T, NFULL, NOUT>::SPILL && LDS <= 160 * 1024;
+};
+
+template <typename T, int NFULL, int WAVES, int NOUT, bool PAIR = false>
 __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
     using C = GruCore<T, NFULL, NOUT>;
     using G = GradLayout<NFULL, T>;
@@ -131,8 +146,13 @@ __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
         }
     };
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
-    const int64_t gw = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
-    const int64_t nw = (int64_t)gridDim.x * WAVES;
+    // PAIR: wave 2 b is block slot b's forward wave, wave 2 b + 1 its backward wave; both walk the same blocks
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool fwd_role = !PAIR || (wave & 1) == 0, bwd_role = !PAIR || (wave & 1) == 1;
+    constexpr int SLOTS = PAIR ? WAVES / 2 : WAVES;
+    const int64_t gw = (int64_t)blockIdx.x * SLOTS + (PAIR ? wave >> 1 : wave);
+    const int64_t nw = (int64_t)gridDim.x * SLOTS;
+    T* xch = reinterpret_cast<T*>(lds + GradPair<T, NFULL, NOUT>::IMG + (size_t)(wave >> 1) * GradPair<T, NFULL, NOUT>::SLOT) + lane;
     const int N = a.N;
     const T* wd = reinterpret_cast<const T*>(img + C::L::OFF_WD) + q * C::L::WD_Q;
     const int hck_nl = a.hck_nl > 1 ? a.hck_nl : 1;
@@ -143,9 +163,14 @@ __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
 #pragma unroll
         for (int k = 0; k < KT; ++k) hg[o][k] = T(0);
     }
-    for (int64_t sb = gw; sb < a.nsb; sb += nw) {
+    for (int64_t base = 0; base < a.nsb; base += nw) {
+        // PAIR: every wave of the workgroup runs the same number of barriers - a slot without a block of its own walks the last block
+        // again with all its chains invalid (weights 0, nothing stored)
+        const bool active = base + gw < a.nsb;
+        if (!PAIR && !active) break;
+        const int64_t sb = active ? base + gw : a.nsb - 1;
         const int64_t s = sb * kChains + c;
-        const bool valid = s < a.ns;
+        const bool valid = active && s < a.ns;
         const int64_t sc = valid ? s : a.ns - 1;
         T w = T(0), w_im = T(0);
         if (valid) {
@@ -174,7 +199,7 @@ __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
             }
         };
         T hpf[KT];
-        fetch_state(N - 1, hpf);
+        if (fwd_role) fetch_state(N - 1, hpf);
         T dh[KT];
 #pragma unroll
         for (int k = 0; k < KT; ++k) dh[k] = T(0);
@@ -184,18 +209,45 @@ __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
                 num_up += __popc(word(wi) & (32 * wi + 32 <= N ? 0xffffffffu : (1u << (N & 31)) - 1u));
         for (int n = N - 1; n >= 0; --n) {
             T h[KT], hn[KT], rg[KT], ug[KT], cc[KT], qv[KT];
+            if (fwd_role) {
 #pragma unroll
-            for (int k = 0; k < KT; ++k) h[k] = hpf[k];
-            if (n > 0) fetch_state(n - 1, hpf);
+                for (int k = 0; k < KT; ++k) h[k] = hpf[k];
+                if (n > 0) fetch_state(n - 1, hpf);
+            }
             const int sig = (int)((wcur >> (n & 31)) & 1);
             const int sig_in = n == 0 ? -1 : (n & 31) ? (int)((wcur >> ((n - 1) & 31)) & 1) : (int)(wlow >> 31);
             if ((n & 31) == 0 && n > 0) {
                 wcur = wlow;
                 wlow = n >= 64 ? word((n >> 5) - 2) : 0u;
             }
-            C::step_keep(img, sig_in, h, hn, rg, ug, cc, qv, lane);
             T z[NOUT];
-            C::head(img, hn, lane, z);
+            if (fwd_role) {
+                C::step_keep(img, sig_in, h, hn, rg, ug, cc, qv, lane);
+                C::head(img, hn, lane, z);
+            }
+            if constexpr (PAIR) {                                      // F -> B through the block's LDS slot
+                if (fwd_role) {
+#pragma unroll
+                    for (int k = 0; k < KT; ++k) {
+                        xch[(0 * KT + k) * 64] = h[k];  xch[(1 * KT + k) * 64] = hn[k]; xch[(2 * KT + k) * 64] = rg[k];
+                        xch[(3 * KT + k) * 64] = ug[k]; xch[(4 * KT + k) * 64] = cc[k]; xch[(5 * KT + k) * 64] = qv[k];
+                    }
+#pragma unroll
+                    for (int o = 0; o < NOUT; ++o) xch[(6 * KT + o) * 64] = z[o];
+                }
+                __syncthreads();
+                if (bwd_role) {
+#pragma unroll
+                    for (int k = 0; k < KT; ++k) {
+                        h[k] = xch[(0 * KT + k) * 64];  hn[k] = xch[(1 * KT + k) * 64]; rg[k] = xch[(2 * KT + k) * 64];
+                        ug[k] = xch[(3 * KT + k) * 64]; cc[k] = xch[(4 * KT + k) * 64]; qv[k] = xch[(5 * KT + k) * 64];
+                    }
+#pragma unroll
+                    for (int o = 0; o < NOUT; ++o) z[o] = xch[(6 * KT + o) * 64];
+                }
+                __syncthreads();
+                if (!bwd_role) continue;                               // the forward wave is done with this site
+            }
             // gradient of this site's term w.r.t. the head rows
             T g[NOUT];
             const T p1 = T(1) - prob0(z[0]);
@@ -299,7 +351,7 @@ __global__ void __launch_bounds__(WAVES * 64) gru_bwd_kernel(GradArgs a) {
             dh[KT - 1] += accb[NFULL][0];
         }
     }
-    store_head_part<T, NOUT, KT>(reinterpret_cast<T*>(a.head_part) + (size_t)gw * NOUT * G::HEAD_ROW, G::HEAD_ROW, hg, gb, c, q);
+    if (bwd_role) store_head_part<T, NOUT, KT>(reinterpret_cast<T*>(a.head_part) + (size_t)gw * NOUT * G::HEAD_ROW, G::HEAD_ROW, hg, gb, c, q);
 }
 
 // Partial sums of  P[row][:]^T Q[row][:]  over one contiguous chunk of rows per block (4 waves).

@@ -59,6 +59,9 @@ struct TrainState {
     bool host_newer = true;       // the host copy of the parameters changed since the device copy was made
     bool dev_newer = false;       // the device copy was updated by an optimizer step the host copy has not seen
     void* mom_host = nullptr;     // pinned [kMaxSteps][4] doubles: the moments of the K steps of one rnnwf_train_steps call
+    void* mom_host_dev = nullptr; // the same memory as the device addresses it
+    DevBuf combo;                 // the tables of all images back to back: ONE re-pack launch per update (train.hip: repack_all_kernel)
+    int combo_nimg = 0;           // images the combined table was built from
 };
 
 struct ParamSpec {
@@ -118,6 +121,7 @@ struct rnnwf_handle {
     bool last_has_ckpt = false;
     void* pinned = nullptr;  // small pinned staging (moments)
     void* pinned_dev = nullptr;   // the same memory as the device addresses it: kernels write the step's 32 + 24 result bytes there directly
+    double* moments_direct = nullptr;   // device address of the pinned row the moments kernel also writes to (set per iteration by rnnwf_train_steps)
     bool j1j2_cnt_clean = false;  // the J1-J2 item counters are zero (left so by the last assembly kernel)
     void* staging = nullptr; // pinned staging of the host-side all-reduces (comm.hip) and of the gradient's download, grown on demand
     size_t staging_cap = 0;

@@ -94,7 +94,7 @@ int mdrnn_load_batch(rnnwf_handle* h, const int32_t* samples, int64_t ns);
 
 // ---- gradient (grad.hip) ---------------------------------------------------------------------------
 int mdrnn_vmc_gradient(rnnwf_handle* h, double mean_energy, double norm);
-// grad_wide.hip: backward kernels compiled in their own translation unit (0: complex RNN 101..132 units, 1: 133..196, 2: float64 GRU 69..100)
+// grad_wide.hip: backward kernels compiled in their own translation unit (index: grad.hip, GLaunch::WIDE)
 struct GradArgs;
 const void* grad_wide_kernel(int which);
 void grad_wide_launch(int which, unsigned grid, size_t lds, hipStream_t stream, const GradArgs& a);

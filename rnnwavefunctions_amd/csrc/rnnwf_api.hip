@@ -244,7 +244,7 @@ extern "C" int rnnwf_destroy(rnnwf_handle* h) {
                       &h->xrec[0], &h->xrec[1], &h->wsplit_up[0], &h->wsplit_up[1], &h->wsplit_up[2],
                       &h->train.P, &h->train.M, &h->train.V, &h->train.G, &h->train.gidx, &h->train.img[0].table, &h->train.img[1].table,
                       &h->train.img[2].table, &h->train.img[3].table, &h->train.img[4].table, &h->train.img[5].table, &h->train.img[6].table,
-                      &h->train.img[7].table};
+                      &h->train.img[7].table, &h->train.combo};
     static_assert(RNNWF_MAX_LAYERS == 4, "wsplit_up has RNNWF_MAX_LAYERS - 1 entries");
     for (DevBuf* b : bufs) free_buf(*b);
     for (auto& t : h->timers) {
@@ -465,6 +465,7 @@ int rnnwf::run_moments(rnnwf_handle* h, const void* eloc_dev, int64_t ns, bool c
         // single device: the kernel writes the four moments into pinned host memory itself (read behind the step's one stream
         // sync; saves the copy launch - 4 us of config 1's 70); with the in-step all-reduce they travel device -> RCCL -> copy
         double* direct = (moments_host && !h->reduce_in_step) ? (double*)h->pinned_dev : nullptr;
+        if (!moments_host && !h->reduce_in_step && h->moments_direct) direct = h->moments_direct;      // rnnwf_train_steps: iteration k's row of its pinned table
         if (complex_f32)
             moments_kernel<float><<<1, 1024, 0, h->stream>>>((const float*)eloc_dev, ns, 2, 1, (double*)h->moments.p, direct);
         else

@@ -8,7 +8,7 @@
 //     grad_flat_kernel    dW image -> flat f64 gradient in the order of rnnwf_set_params_flat (table probed from the host unpacker)
 //     [RCCL all-reduce of the flat gradient on the stream, multi-rank]
 //     adam_kernel         m, v, theta in f64; theta rounded to the model's type as the host optimizer does
-//     repack_kernel       every weight image rebuilt from theta by replaying the host packers' recorded tables (pack_value.h)
+//     repack_all_kernel   every weight image rebuilt from theta by replaying the host packers' recorded tables (pack_value.h), one launch
 // The arithmetic is the host path's, operation for operation (IEEE f64, no contraction), so a trajectory equals the host-Adam
 // one bit for bit (tests/test_gpu_training.py).  Supported: every model of the four drivers - the positive, parity-symmetric, complex
 // and float64 GRU with one layer or a stack, and the 2D RNN (rnnwf_device_training_supported answers for a handle).
@@ -24,11 +24,8 @@ namespace {
 
 constexpr int kMaxSteps = 1024;
 
-__global__ void repack_kernel(const PackEntry* __restrict__ e, int64_t n, const double* __restrict__ P, char* __restrict__ img) {
+__device__ __forceinline__ void repack_entry(const PackEntry& t, const double* __restrict__ P, char* __restrict__ img) {
 #pragma clang fp contract(off)
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const PackEntry t = e[i];
     double v = P[t.a];
     if (t.b >= 0) v = (t.kind & PACK_MINUS) ? __dsub_rn(v, P[t.b]) : __dadd_rn(v, P[t.b]);
     if (t.d >= 0) v = __dadd_rn(v, P[t.d]);
@@ -51,6 +48,22 @@ __global__ void repack_kernel(const PackEntry* __restrict__ e, int64_t n, const 
     }
 }
 
+// all images in one launch: entry i belongs to the image whose range of the combined table holds it
+struct RepackPlan {
+    int nimg;
+    int64_t start[9];
+    char* target[8];
+};
+__global__ void repack_all_kernel(const PackEntry* __restrict__ e, RepackPlan plan, const double* __restrict__ P) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= plan.start[plan.nimg]) return;
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+        if (k < plan.nimg && i >= plan.start[k]) j = k;
+    repack_entry(e[i], P, plan.target[j]);
+}
+
 template <typename T>
 __global__ void grad_flat_kernel(const int32_t* __restrict__ sidx, int64_t n, const T* __restrict__ dW, double* __restrict__ G) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -60,11 +73,17 @@ __global__ void grad_flat_kernel(const int32_t* __restrict__ sidx, int64_t n, co
 }
 
 // training.py: Adam.step -  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g g;  theta = (theta - lr_t m / (sqrt(v) + eps)).astype(dtype)
-__global__ void adam_kernel(double* __restrict__ P, double* __restrict__ M, double* __restrict__ V, const double* __restrict__ G, int64_t n,
-                            double lr_t, double b1, double b2, double eps, int f32) {
+// FUSED (single rank): the flat gradient is gathered from the dW image here (grad_flat_kernel's line) - one launch less per update
+template <typename T, bool FUSED>
+__global__ void adam_kernel(double* __restrict__ P, double* __restrict__ M, double* __restrict__ V, double* __restrict__ G, int64_t n,
+                            double lr_t, double b1, double b2, double eps, int f32, const int32_t* __restrict__ sidx, const T* __restrict__ dW) {
 #pragma clang fp contract(off)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if constexpr (FUSED) {
+        const int32_t k = sidx[i];
+        G[i] = k > 0 ? (double)dW[k - 1] : k < 0 ? -(double)dW[-k - 1] : 0.0;
+    }
     // every operation rounded on its own, as NumPy evaluates the host optimizer's expressions (no fused multiply-add: the
     // translation unit is compiled with -ffp-contract=off, build.py)
     const double g = G[i];
@@ -164,6 +183,7 @@ int build(rnnwf_handle* h) {
     RNNWF_HIP(h, hipMemset(t.M.p, 0, (size_t)t.nparams * 8));
     RNNWF_HIP(h, hipMemset(t.V.p, 0, (size_t)t.nparams * 8));
     RNNWF_HIP(h, hipHostMalloc(&t.mom_host, (size_t)kMaxSteps * 4 * sizeof(double), hipHostMallocDefault));
+    RNNWF_HIP(h, hipHostGetDevicePointer(&t.mom_host_dev, t.mom_host, 0));
     // gradient: dW image -> flat
     std::vector<int32_t> sidx;
     if (md) {
@@ -233,21 +253,52 @@ int params_to_device(rnnwf_handle* h) {
     return 0;
 }
 
+// the tables of all images back to back (rebuilt when an image joins: the backward image's table is added on first use)
+int ensure_combo(rnnwf_handle* h) {
+    TrainState& t = h->train;
+    if (t.combo_nimg == t.nimg) return 0;
+    int64_t total = 0;
+    for (int i = 0; i < t.nimg; ++i) total += t.img[i].n;
+    if (int rc = ensure(h, t.combo, std::max<int64_t>(total, 1) * sizeof(PackEntry))) return rc;
+    int64_t off = 0;
+    for (int i = 0; i < t.nimg; ++i) {
+        if (t.img[i].n)
+            RNNWF_HIP(h, hipMemcpyAsync((char*)t.combo.p + off * sizeof(PackEntry), t.img[i].table.p, t.img[i].n * sizeof(PackEntry),
+                                        hipMemcpyDeviceToDevice, h->stream));
+        off += t.img[i].n;
+    }
+    t.combo_nimg = t.nimg;
+    return 0;
+}
+
 int launch_update(rnnwf_handle* h, double lr_t, double b1, double b2, double eps) {
     TrainState& t = h->train;
     const unsigned blocks = (unsigned)((t.nparams + 255) / 256);
-    if (t.dw_f64) grad_flat_kernel<double><<<blocks, 256, 0, h->stream>>>((const int32_t*)t.gidx.p, t.nparams, (const double*)h->gradW.p, (double*)t.G.p);
-    else grad_flat_kernel<float><<<blocks, 256, 0, h->stream>>>((const int32_t*)t.gidx.p, t.nparams, (const float*)h->gradW.p, (double*)t.G.p);
-    RNNWF_HIP(h, hipGetLastError());
-    if (h->comm)                                                                          // (also with a one-rank communicator: the single-GPU test walks the road)
+    const int f32 = h->f64 ? 0 : 1;
+    if (h->comm) {            // (also with a one-rank communicator: the single-GPU test walks the road)
+        if (t.dw_f64) grad_flat_kernel<double><<<blocks, 256, 0, h->stream>>>((const int32_t*)t.gidx.p, t.nparams, (const double*)h->gradW.p, (double*)t.G.p);
+        else grad_flat_kernel<float><<<blocks, 256, 0, h->stream>>>((const int32_t*)t.gidx.p, t.nparams, (const float*)h->gradW.p, (double*)t.G.p);
+        RNNWF_HIP(h, hipGetLastError());
         if (int rc = comm_allreduce_device(h, t.G.p, (size_t)t.nparams)) return rc;       // one in-stream RCCL sum of the gradient
-    adam_kernel<<<blocks, 256, 0, h->stream>>>((double*)t.P.p, (double*)t.M.p, (double*)t.V.p, (const double*)t.G.p, t.nparams, lr_t, b1, b2, eps,
-                                               h->f64 ? 0 : 1);
+        adam_kernel<float, false><<<blocks, 256, 0, h->stream>>>((double*)t.P.p, (double*)t.M.p, (double*)t.V.p, (double*)t.G.p, t.nparams, lr_t, b1, b2,
+                                                                 eps, f32, nullptr, nullptr);
+    } else if (t.dw_f64) {
+        adam_kernel<double, true><<<blocks, 256, 0, h->stream>>>((double*)t.P.p, (double*)t.M.p, (double*)t.V.p, (double*)t.G.p, t.nparams, lr_t, b1, b2,
+                                                                 eps, f32, (const int32_t*)t.gidx.p, (const double*)h->gradW.p);
+    } else {
+        adam_kernel<float, true><<<blocks, 256, 0, h->stream>>>((double*)t.P.p, (double*)t.M.p, (double*)t.V.p, (double*)t.G.p, t.nparams, lr_t, b1, b2,
+                                                                eps, f32, (const int32_t*)t.gidx.p, (const float*)h->gradW.p);
+    }
     RNNWF_HIP(h, hipGetLastError());
+    if (int rc = ensure_combo(h)) return rc;
+    RepackPlan plan{};
+    plan.nimg = t.nimg;
     for (int i = 0; i < t.nimg; ++i) {
-        const TrainImage& im = t.img[i];
-        if (!im.n) continue;
-        repack_kernel<<<(unsigned)((im.n + 255) / 256), 256, 0, h->stream>>>((const PackEntry*)im.table.p, im.n, (const double*)t.P.p, (char*)im.target->p);
+        plan.start[i + 1] = plan.start[i] + t.img[i].n;
+        plan.target[i] = (char*)t.img[i].target->p;
+    }
+    if (const int64_t total = plan.start[t.nimg]) {
+        repack_all_kernel<<<(unsigned)((total + 255) / 256), 256, 0, h->stream>>>((const PackEntry*)t.combo.p, plan, (const double*)t.P.p);
         RNNWF_HIP(h, hipGetLastError());
     }
     t.dev_newer = true;
@@ -381,11 +432,15 @@ extern "C" int rnnwf_train_steps(rnnwf_handle* h, int32_t K, int64_t numsamples,
     if (int rc = params_to_device(h)) return rc;
     for (int k = 0; k < K; ++k) {
         int rc;
+        // single rank: the moments kernel writes iteration k's row of the pinned table itself (no copy launch per iteration)
+        h->moments_direct = h->reduce_in_step ? nullptr : (double*)t.mom_host_dev + 4 * k;
         if (cplx) rc = crnn_vmc_step(h, numsamples, seed, step0 + (uint64_t)k, sample_offset, couplings, nullptr, nullptr, nullptr);
         else if (md) rc = mdrnn_vmc_step(h, numsamples, seed, step0 + (uint64_t)k, sample_offset, couplings, nullptr, nullptr, nullptr);
         else rc = prnn_vmc_step(h, numsamples, seed, step0 + (uint64_t)k, sample_offset, couplings, nullptr, nullptr, nullptr);
+        h->moments_direct = nullptr;
         if (rc) return rc;
-        RNNWF_HIP(h, hipMemcpyAsync((double*)t.mom_host + 4 * k, h->moments.p, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (h->reduce_in_step)
+            RNNWF_HIP(h, hipMemcpyAsync((double*)t.mom_host + 4 * k, h->moments.p, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         if (int r2 = md ? mdrnn_grad_device(h, 0.0, 0.0, (const double*)h->moments.p, nullptr)
                         : grad_single_layer_device(h, 0.0, 0.0, 0.0, (const double*)h->moments.p, nullptr)) return r2;
         if (int r2 = ensure_bwd_image(h)) return r2;
